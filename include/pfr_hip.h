@@ -1,0 +1,123 @@
+/* pfr_hip.h — C ABI of libpfr_hip.so: the MI355X (gfx950) kernels behind the feature-extractor hot path of
+ * MarQuisCheshire/Pets-Face-Recognition (train step of the CNN backbone into the ArcFace head, and the
+ * embedding cosine match / candR@K).
+ *
+ * The reference is 100 % Python on PyTorch and has NO FFI boundary of its own; every entry
+ * point below therefore names the PyTorch call on the reference's path that it replaces (file:line relative
+ * to the reference tree).  The reference-side binding a maintainer would add is the ctypes stub shown in
+ * INTEGRATION.md (our own host code in pets-face-recognition_amd/_hip/lib.py is exactly that stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (the library never allocates, frees or retains);
+ *   - tensors are NHWC ("channels last"), dense, channel count a multiple of 16 bytes / sizeof(element);
+ *   - dtype: PFR_F32 = 0 (exact-f32 MFMA, the parity path), PFR_BF16 = 1 (bf16 in, f32 accumulate);
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all calls are asynchronous;
+ *   - workspaces are supplied by the caller; their sizes come from the *_splits / *_blocks / *_mtile queries;
+ *   - return value: 0 = ok, <0 = error (PFR_ERR_*), message via pfr_last_error() (thread-local);
+ *   - no global mutable state; thread-safe per stream.
+ */
+#ifndef PFR_HIP_H
+#define PFR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFR_F32 0
+#define PFR_BF16 1
+#define PFR_OK 0
+#define PFR_ERR_ARG (-1)
+#define PFR_ERR_HIP (-2)
+#define PFR_ERR_UNSUPPORTED (-3)
+
+typedef void* pfr_stream_t; /* hipStream_t */
+
+const char* pfr_last_error(void);
+int pfr_version(void);
+int pfr_device_arch(char* buf, int buflen);
+
+/* ---- convolution / linear (implicit GEMM on MFMA) -------------------------------------------------------
+ * pfr_conv2d_fwd replaces nn.Conv2d.forward / nn.Linear.forward / F.linear of the backbone and head
+ * (torchvision resnet50 built at configs/dog_fe/fe_dogs_config.py:102-103; F.linear at
+ * losses/large_margin.py:71) and — run over dy with flipped/transposed weights and idil_log2 = log2(stride) —
+ * the autograd input gradient of the same ops.
+ *   x [N][H][W][C], w [Cout][R][S][C], y [N*OH*OW][ldy] (ldy<=0 → Cout); ih = oh*stride - pad + r.
+ *   bias [Cout] fp32 or NULL; accumulate: y += result; out_relu: y = max(y,0)
+ *   pro_scale/pro_shift [C] fp32 or NULL: operand is relu?(scale[c]*x + shift[c]) (fused BN-apply of the producer)
+ *   stats_part or NULL: fp32 [ceil(M/mtile)][2][Cout] per-channel (sum, sum of squares) of the stored y,
+ *   mtile = pfr_conv2d_mtile(M, Cout)  (input of pfr_bn_finalize; deterministic, no atomics). */
+int pfr_conv2d_mtile(int M, int Cout);
+int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W, int C,
+                   int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int ldy,
+                   const float* bias, int accumulate, int out_relu, const float* pro_scale, const float* pro_shift,
+                   int pro_relu, float* stats_part, pfr_stream_t stream);
+
+/* pfr_conv2d_wgrad replaces the autograd weight gradient of nn.Conv2d / nn.Linear / F.linear:
+ *   dw[co][r][s][c] (fp32) = scale * sum_m dy[m][co] * act(x)[...]  (+ dw if accumulate)
+ * workspace: fp32 [pfr_conv2d_wgrad_splits(M,Cout,R*S*C)][Cout][R*S*C] (may be NULL when splits == 1). */
+int pfr_conv2d_wgrad_splits(int M, int Cout, int KK);
+int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float* workspace, int dtype, int N, int H, int W, int C,
+                     int Cout, int R, int S, int stride, int pad, int OH, int OW, int lddy, const float* pro_scale,
+                     const float* pro_shift, int pro_relu, float scale, int accumulate, pfr_stream_t stream);
+
+/* ---- layout / dtype helpers -------------------------------------------------------------------------- */
+/* batch['x'] fp32 NCHW (data_loading/dataset.py:125) → NHWC compute dtype with Cp >= C zero-padded channels */
+int pfr_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, pfr_stream_t stream);
+int pfr_cast(const void* x, int src_dtype, void* y, int dst_dtype, size_t n, pfr_stream_t stream);
+/* w [O][R][S][I] → wt [I][R][S][O], taps flipped: the weights pfr_conv2d_fwd needs to compute the data gradient */
+int pfr_weight_dgrad_layout(const void* w, void* wt, int dtype, int O, int R, int S, int I, pfr_stream_t stream);
+int pfr_add(const void* a, const void* b, void* y, int dtype, size_t n, pfr_stream_t stream);
+int pfr_colsum(const void* x, int dtype, int rows, int C, float* out, int accumulate, pfr_stream_t stream);
+
+/* ---- BatchNorm2d (train: batch statistics, eps, momentum, unbiased running var — torchvision resnet) ---- */
+int pfr_colreduce_blocks(int C, int dtype, long rows); /* partial rows written by pfr_bn_stats / pfr_bn_bwd_reduce */
+int pfr_bn_stats(const void* x, int dtype, long rows, int C, float* part, pfr_stream_t stream);
+int pfr_bn_finalize(const float* part, int nparts, int C, float count, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                    float* shift, pfr_stream_t stream);
+int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* scale, float* shift, pfr_stream_t stream);
+/* y = relu?( a1*x1 + b1 (+ a2*x2 + b2 | + x2) ): BN apply, ReLU and the residual add of a bottleneck in one pass */
+int pfr_bn_act(const void* x1, const float* a1, const float* b1, const void* x2, const float* a2, const float* b2, void* y,
+               int dtype, long rows, int C, int relu, pfr_stream_t stream);
+/* backward: g = dout * mask (mask_mode 0 none, 1: out > 0, 2: scale*x+shift > 0);
+ * reduce → partials of (Σg, Σg·x̂); finalize → dgamma, dbeta, coef[3][C]; apply → dx = coef0*g + coef1*x + coef2, gres = g */
+int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* x, const float* mean, const float* invstd,
+                      const float* scale, const float* shift, int mask_mode, int dtype, long rows, int C, float* part,
+                      pfr_stream_t stream);
+int pfr_bn_bwd_finalize(const float* part, int nparts, int C, float count, const float* gamma, const float* mean,
+                        const float* invstd, float* dgamma, float* dbeta, float* coef, int accumulate, pfr_stream_t stream);
+int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x, const float* coef, const float* scale,
+                     const float* shift, int mask_mode, void* dx, void* gres, int dtype, long rows, int C,
+                     pfr_stream_t stream);
+
+/* ---- pooling (nn.MaxPool2d(3,2,1) fused with the stem's BN+ReLU; nn.AdaptiveAvgPool2d(1)) --------------- */
+int pfr_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int dtype, int N,
+                            int H, int W, int C, int relu, pfr_stream_t stream);
+int pfr_maxpool_bwd(const void* dy, const uint8_t* idx, void* dz, int dtype, int N, int H, int W, int C, pfr_stream_t stream);
+int pfr_avgpool_fwd(const void* x, void* y, int dtype, int N, int HW, int C, pfr_stream_t stream);
+int pfr_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int HW, int C, pfr_stream_t stream);
+
+/* ---- ArcFace / CosFace head + (focal) cross-entropy (losses/large_margin.py:30-40,69-84; losses/losses.py:22-28) */
+int pfr_l2norm_fwd(const void* x, int in_dtype, void* xn, void* xnT, int out_dtype, float* inv_norm, int rows, int D,
+                   int ldt, float eps, pfr_stream_t stream);
+int pfr_l2norm_bwd(const void* x, int in_dtype, const float* inv_norm, const float* dxn, void* dx, int out_dtype, int rows,
+                   int D, int accumulate, pfr_stream_t stream);
+/* mode 0 ArcFace hard margin, 1 ArcFace easy margin, 2 CosFace, 3 plain scaled cosine.
+ * logits [B][C] fp32 or NULL, loss_rows [B] fp32 or NULL, dcos [B][ldc] (dcos_dtype) or NULL = grad_scale * d loss_row / d cos */
+int pfr_margin_ce(const float* cosv, const int64_t* label, int B, int C, int ldc, int mode, float s, float m, float gamma,
+                  float grad_scale, float* logits, float* loss_rows, void* dcos, int dcos_dtype, pfr_stream_t stream);
+int pfr_mean(const float* x, float* out, int n, pfr_stream_t stream);
+
+/* ---- optimiser steps over flat fp32 master buffers (configs/dog_fe/fe_dogs_config.py:123-133; body_dog_fe.py:121-131) */
+int pfr_sgd_step(float* p, const float* g, float* mom, void* shadow, int shadow_dtype, size_t n, float lr, float momentum,
+                 float weight_decay, float grad_scale, int first_step, pfr_stream_t stream);
+int pfr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, size_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, pfr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFR_HIP_H */

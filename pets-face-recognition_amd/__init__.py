@@ -1,0 +1,12 @@
+"""pets-face-recognition_amd — MI355X-native feature-extractor hot path of MarQuisCheshire/Pets-Face-Recognition.
+
+Layout
+  csrc/      hand-written HIP kernels for gfx950 + the C-ABI (libpfr_hip.so, declared in include/pfr_hip.h)
+  _hip/      ctypes binding of the C-ABI and thin tensor-level wrappers
+  models/    registry mirroring the reference's `models/` (+ the torchvision-compatible ResNet the configs build)
+  losses/    `SoftmaxBasedMetricLearning`, `ArcMarginProduct`, `AddMarginProduct`, `FocalLoss` (same signatures)
+  engine/    `Controller`, `Trainer` (plain loop replacing the PyTorch-Lightning glue), evaluation (candR@K)
+  utils/     `get_config`, `Config`, `configure_trainer`, device / DDP selection
+  optim/     flat-buffer fused SGD / AdamW
+"""
+__version__ = "0.1.0"

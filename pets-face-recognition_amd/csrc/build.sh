@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds libpfr_hip.so (gfx950 only) next to the sources. Usage: build.sh [-j N]
+set -e
+cd "$(dirname "$0")"
+ARCH=gfx950
+FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast"
+mkdir -p build
+pids=()
+for f in pfr_api pfr_igemm pfr_wgrad pfr_elementwise pfr_head pfr_match; do
+  [ -f $f.hip ] || continue
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ pfr_common.h -nt build/$f.o ] || [ pfr_mma.h -nt build/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=$ARCH -shared -fPIC build/*.o -o libpfr_hip.so
+echo "built $(pwd)/libpfr_hip.so"

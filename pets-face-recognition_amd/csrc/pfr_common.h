@@ -1,0 +1,143 @@
+// pfr_common.h — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Everything here is written for wave64 / MFMA / 160 KiB LDS; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// dtype enum of the C-ABI (include/pfr_hip.h)
+#define PFR_F32 0
+#define PFR_BF16 1
+
+// error codes of the C-ABI
+#define PFR_OK 0
+#define PFR_ERR_ARG (-1)
+#define PFR_ERR_HIP (-2)
+#define PFR_ERR_UNSUPPORTED (-3)
+
+void pfr_set_error(const char* fmt, ...);
+
+#define PFR_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      pfr_set_error(__VA_ARGS__);           \
+      return PFR_ERR_ARG;                   \
+    }                                       \
+  } while (0)
+
+#define PFR_CHECK_LAUNCH()                                            \
+  do {                                                                \
+    hipError_t e_ = hipGetLastError();                                \
+    if (e_ != hipSuccess) {                                           \
+      pfr_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return PFR_ERR_HIP;                                             \
+    }                                                                 \
+  } while (0)
+
+// ---- per-dtype traits: a "chunk" is always 16 bytes -------------------------------------------
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int KPACK = 4;  // elements per 16-byte chunk
+  static constexpr int ID = PFR_F32;
+};
+template <> struct DT<bf16_t> {
+  static constexpr int KPACK = 8;
+  static constexpr int ID = PFR_BF16;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte chunk <-> KPACK floats
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  __device__ __forceinline__ static void unpack(const u32x4& c, float* f) {
+    f[0] = __uint_as_float(c[0]); f[1] = __uint_as_float(c[1]);
+    f[2] = __uint_as_float(c[2]); f[3] = __uint_as_float(c[3]);
+  }
+  __device__ __forceinline__ static u32x4 pack(const float* f) {
+    u32x4 c;
+    c[0] = __float_as_uint(f[0]); c[1] = __float_as_uint(f[1]);
+    c[2] = __float_as_uint(f[2]); c[3] = __float_as_uint(f[3]);
+    return c;
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  __device__ __forceinline__ static void unpack(const u32x4& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(c[i] << 16);
+      f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ static u32x4 pack(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x2 p;
+      p[0] = (bf16_t)f[2 * i];
+      p[1] = (bf16_t)f[2 * i + 1];
+      c[i] = __builtin_bit_cast(uint32_t, p);
+    }
+    return c;
+  }
+};
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// unsigned division by a runtime constant (host-precomputed), n < 2^31
+struct FastDiv {
+  uint32_t d, mul, shr;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  if (d == 1) { f.mul = 0; f.shr = 0; return f; }
+  uint32_t l = 0;
+  while ((1u << l) < d) ++l;              // l = ceil(log2 d)
+  uint64_t m = ((uint64_t(1) << (32 + l)) + d - 1) / d;  // may exceed 32 bits by one bit
+  f.mul = (uint32_t)(m - (uint64_t(1) << 32));
+  f.shr = l;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  uint32_t t = __umulhi(n, f.mul);
+  return (uint32_t)(((uint64_t)t + n) >> f.shr);
+}
+
+// XCD-aware bijective remap of a 1-D block id: consecutive logical tiles land on the same XCD
+// (block b is observed to run on XCD b % 8 — speed only, never correctness).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+  const uint32_t NX = 8;
+  uint32_t xcd = bid % NX, q = nblk / NX, r = nblk % NX;
+  uint32_t base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + bid / NX;
+}

@@ -1,0 +1,774 @@
+// pfr_elementwise.hip — the HBM-bound kernels of the ResNet feature extractor: layout conversion, train/eval
+// BatchNorm (statistics finalise, apply+ReLU+residual, backward reduce / apply), max/avg pooling, optimiser steps.
+//
+// Reference call sites replaced (all via torchvision resnet50, configs/dog_fe/fe_dogs_config.py:102-103):
+// nn.BatchNorm2d (eps 1e-5, momentum 0.1, unbiased running var), nn.ReLU, residual add, nn.MaxPool2d(3,2,1),
+// nn.AdaptiveAvgPool2d(1); torch.optim.SGD(momentum 0.9, per-group lr / weight decay, fe_dogs_config.py:123-133)
+// and torch.optim.AdamW (configs/dog_fe/body_dog_fe.py:121-131).
+//
+// Everything is NHWC with 16-byte channel chunks per lane (8 bf16 / 4 f32): a wave instruction moves 1 KiB of
+// contiguous HBM.  Per-channel reductions keep the channel chunk in the lane and reduce over rows: per-thread
+// partials → LDS across the row-lanes of a block → one deterministic partial row per block (no atomics).
+#include "pfr_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// layout / dtype conversion
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int HW, int Cp) {
+  // one thread per (n, pixel): writes Cp channels (zero padded).  Reads are coalesced per channel plane.
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * HW) return;
+  const size_t n = i / HW, pix = i % HW;
+  T* dst = y + i * Cp;
+  for (int c = 0; c < Cp; ++c) {
+    float v = c < C ? x[(n * C + c) * HW + pix] : 0.f;
+    dst[c] = from_f32<T>(v);
+  }
+}
+
+extern "C" int pfr_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, hipStream_t st) {
+  PFR_CHECK_ARG(x && y && Cp >= C, "pfr_nchw_to_nhwc: bad args");
+  const size_t n = (size_t)N * H * W;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, x, (bf16_t*)y, N, C, H * W, Cp);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, st, x, (float*)y, N, C, H * W, Cp);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+template <typename TI, typename TOo>
+__global__ void cast_kernel(const TI* __restrict__ x, TOo* __restrict__ y, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = from_f32<TOo>(to_f32(x[i]));
+}
+
+extern "C" int pfr_cast(const void* x, int src_dtype, void* y, int dst_dtype, size_t n, hipStream_t st) {
+  PFR_CHECK_ARG(x && y, "pfr_cast: null pointer");
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) return PFR_OK;
+  if (src_dtype == PFR_F32 && dst_dtype == PFR_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const float*)x, (bf16_t*)y, n);
+  else if (src_dtype == PFR_BF16 && dst_dtype == PFR_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (float*)y, n);
+  else if (src_dtype == PFR_F32 && dst_dtype == PFR_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, n);
+  else {
+    pfr_set_error("pfr_cast: unsupported dtype pair %d -> %d", src_dtype, dst_dtype);
+    return PFR_ERR_UNSUPPORTED;
+  }
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// weights [O][R][S][I] -> data-gradient weights [I][R][S][O] with both taps flipped
+template <typename T>
+__global__ void weight_dgrad_kernel(const T* __restrict__ w, T* __restrict__ wt, int O, int R, int S, int I) {
+  const size_t n = (size_t)O * R * S * I;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    // i indexes the OUTPUT [ci][r][s][o] so stores are coalesced
+    size_t rest = i;
+    const int o = rest % O; rest /= O;
+    const int s = rest % S; rest /= S;
+    const int r = rest % R; rest /= R;
+    const int ci = (int)rest;
+    wt[i] = w[(((size_t)o * R + (R - 1 - r)) * S + (S - 1 - s)) * I + ci];
+  }
+}
+
+extern "C" int pfr_weight_dgrad_layout(const void* w, void* wt, int dtype, int O, int R, int S, int I, hipStream_t st) {
+  PFR_CHECK_ARG(w && wt, "pfr_weight_dgrad_layout: null pointer");
+  const size_t n = (size_t)O * R * S * I;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(weight_dgrad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)w, (bf16_t*)wt, O, R, S, I);
+  else
+    hipLaunchKernelGGL(weight_dgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)w, (float*)wt, O, R, S, I);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column-reduction scaffold: thread = (chunk column, row lane)
+struct ColGeom {
+  int cw;      // chunk columns handled per block (power of two <= 256)
+  int rl;      // row lanes per block = 256 / cw
+  int cpr;     // chunks per row (C / KP)
+  int gy;      // blocks along columns
+  int gx;      // blocks along rows
+};
+static ColGeom col_geom(int C, int kp, size_t rows) {
+  ColGeom g;
+  g.cpr = C / kp;
+  int cw = 1;
+  while (cw < g.cpr && cw < 256) cw <<= 1;
+  g.cw = cw;
+  g.rl = 256 / cw;
+  g.gy = (g.cpr + cw - 1) / cw;
+  size_t want = 2048 / g.gy;
+  size_t maxb = (rows + g.rl * 4 - 1) / (g.rl * 4);  // at least 4 rows per lane
+  if (want > maxb) want = maxb;
+  if (want < 1) want = 1;
+  g.gx = (int)want;
+  return g;
+}
+extern "C" int pfr_colreduce_blocks(int C, int dtype, long rows) {
+  return col_geom(C, dtype == PFR_BF16 ? 8 : 4, (size_t)rows).gx;
+}
+
+template <int NQ, int KP>
+__device__ __forceinline__ void col_block_reduce(float (&v)[NQ][KP], float* lds, int cw, int rl, int col, int rlane,
+                                                 int cglob, int cpr, float* out_row, int C) {
+  // lds: [rl][cw][NQ*KP]
+  float* mine = lds + ((size_t)rlane * cw + col) * (NQ * KP);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int e = 0; e < KP; ++e) mine[q * KP + e] = v[q][e];
+  __syncthreads();
+  if (rlane == 0 && cglob < cpr) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < KP; ++e) {
+        float a = 0.f;
+        for (int r = 0; r < rl; ++r) a += lds[((size_t)r * cw + col) * (NQ * KP) + q * KP + e];
+        out_row[(size_t)q * C + cglob * KP + e] = a;
+      }
+  }
+}
+
+// ---- standalone batch statistics (sum, sum of squares) of an NHWC tensor → partials [gx][2][C]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, size_t rows,
+                                                       int C, int cw, int rl, int cpr) {
+  constexpr int KP = DT<T>::KPACK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
+  const int cglob = blockIdx.y * cw + col;
+  float v[2][KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) { v[0][e] = 0.f; v[1][e] = 0.f; }
+  if (cglob < cpr) {
+    for (size_t r = (size_t)blockIdx.x * rl + rlane; r < rows; r += (size_t)gridDim.x * rl) {
+      float f[KP];
+      Chunk<T>::unpack(ld16(x + r * C + cglob * KP), f);
+#pragma unroll
+      for (int e = 0; e < KP; ++e) { v[0][e] += f[e]; v[1][e] = fmaf(f[e], f[e], v[1][e]); }
+    }
+  }
+  col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
+}
+
+extern "C" int pfr_bn_stats(const void* x, int dtype, long rows, int C, float* part, hipStream_t st) {
+  PFR_CHECK_ARG(x && part, "pfr_bn_stats: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_stats: C %% %d != 0", kp);
+  ColGeom g = col_geom(C, kp, (size_t)rows);
+  const size_t sh = (size_t)256 * 2 * kp * sizeof(float);
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), sh, st, (const bf16_t*)x, part, (size_t)rows, C, g.cw, g.rl, g.cpr);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(g.gx, g.gy), dim3(256), sh, st, (const float*)x, part, (size_t)rows, C, g.cw, g.rl, g.cpr);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ---- finalise: partials [nparts][2][C] → mean, invstd, scale = γ·invstd, shift = β − mean·scale, running stats
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, float count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                          float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  // block: 16 channels x 16 part-lanes
+  __shared__ float l1[16][17], l2[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a = 0.f, b = 0.f;
+  if (c < C)
+    for (int i = pl; i < nparts; i += 16) {
+      a += part[((size_t)i * 2 + 0) * C + c];
+      b += part[((size_t)i * 2 + 1) * C + c];
+    }
+  l1[pl][cl] = a;
+  l2[pl][cl] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1 += l1[i][cl]; s2 += l2[i][cl]; }
+    const float mean = s1 / count;
+    float var = s2 / count - mean * mean;  // biased batch variance
+    var = fmaxf(var, 0.f);
+    const float invstd = rsqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    scale[c] = g * invstd;
+    shift[c] = bb - mean * g * invstd;
+    if (running_mean) {
+      const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+  }
+}
+
+extern "C" int pfr_bn_finalize(const float* part, int nparts, int C, float count, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                               float* invstd, float* scale, float* shift, hipStream_t st) {
+  PFR_CHECK_ARG(part && mean && invstd && scale && shift, "pfr_bn_finalize: null pointer");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, nparts, C, count, gamma, beta, eps,
+                     momentum, running_mean, running_var, mean, invstd, scale, shift);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// eval-mode BN: scale/shift from running statistics
+__global__ void bn_eval_coeff_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                     float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = rsqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - rm[c] * g * is;
+}
+extern "C" int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, float* scale, float* shift, hipStream_t st) {
+  PFR_CHECK_ARG(running_mean && running_var && scale && shift, "pfr_bn_eval_coeff: null pointer");
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, running_mean, running_var, eps, scale, shift);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ---- apply: y = act( a1[c]*x1 + b1[c]  (+ a2[c]*x2 + b2[c]  |  + x2) )
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, const float* __restrict__ a1,
+                                                     const float* __restrict__ b1, const T* __restrict__ x2,
+                                                     const float* __restrict__ a2, const float* __restrict__ b2,
+                                                     T* __restrict__ y, size_t nchunks, int cpr, int relu) {
+  constexpr int KP = DT<T>::KPACK;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nchunks; i += stride) {
+    const int c = (int)(i % cpr) * KP;
+    float f[KP], g[KP];
+    Chunk<T>::unpack(ld16(x1 + i * KP), f);
+    if (x2) Chunk<T>::unpack(ld16(x2 + i * KP), g);
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      float z = fmaf(f[e], a1[c + e], b1[c + e]);
+      if (x2) z += a2 ? fmaf(g[e], a2[c + e], b2[c + e]) : g[e];
+      f[e] = relu ? fmaxf(z, 0.f) : z;
+    }
+    st16(y + i * KP, Chunk<T>::pack(f));
+  }
+}
+
+extern "C" int pfr_bn_act(const void* x1, const float* a1, const float* b1, const void* x2, const float* a2,
+                          const float* b2, void* y, int dtype, long rows, int C, int relu, hipStream_t st) {
+  PFR_CHECK_ARG(x1 && a1 && b1 && y, "pfr_bn_act: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_act: C %% %d != 0", kp);
+  const size_t nch = (size_t)rows * (C / kp);
+  unsigned blocks = (unsigned)((nch + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x1, a1, b1, (const bf16_t*)x2, a2, b2, (bf16_t*)y, nch, C / kp, relu);
+  else
+    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x1, a1, b1, (const float*)x2, a2, b2, (float*)y, nch, C / kp, relu);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ---- backward reduce: g = dout * mask ; partials of Σ g and Σ g·x̂  (x̂ = (x − mean)·invstd)
+// mask_mode 0: none; 1: out > 0 (materialised post-activation tensor); 2: scale·x + shift > 0 (recomputed)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                            const T* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            int mask_mode, float* __restrict__ part, size_t rows, int C,
+                                                            int cw, int rl, int cpr) {
+  constexpr int KP = DT<T>::KPACK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
+  const int cglob = blockIdx.y * cw + col;
+  float v[2][KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) { v[0][e] = 0.f; v[1][e] = 0.f; }
+  if (cglob < cpr) {
+    float mu[KP], is[KP], sc[KP], sh[KP];
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      mu[e] = mean[cglob * KP + e];
+      is[e] = invstd[cglob * KP + e];
+      sc[e] = mask_mode == 2 ? scale[cglob * KP + e] : 0.f;
+      sh[e] = mask_mode == 2 ? shift[cglob * KP + e] : 0.f;
+    }
+    for (size_t r = (size_t)blockIdx.x * rl + rlane; r < rows; r += (size_t)gridDim.x * rl) {
+      const size_t off = r * C + cglob * KP;
+      float g[KP], xv[KP], o[KP];
+      Chunk<T>::unpack(ld16(dout + off), g);
+      Chunk<T>::unpack(ld16(x + off), xv);
+      if (mask_mode == 1) Chunk<T>::unpack(ld16(out + off), o);
+#pragma unroll
+      for (int e = 0; e < KP; ++e) {
+        float gg = g[e];
+        if (mask_mode == 1) gg = o[e] > 0.f ? gg : 0.f;
+        if (mask_mode == 2) gg = fmaf(xv[e], sc[e], sh[e]) > 0.f ? gg : 0.f;
+        v[0][e] += gg;
+        v[1][e] = fmaf(gg, (xv[e] - mu[e]) * is[e], v[1][e]);
+      }
+    }
+  }
+  col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
+}
+
+extern "C" int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* x, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, int mask_mode, int dtype,
+                                 long rows, int C, float* part, hipStream_t st) {
+  PFR_CHECK_ARG(dout && x && mean && invstd && part, "pfr_bn_bwd_reduce: null pointer");
+  PFR_CHECK_ARG(mask_mode != 1 || out, "pfr_bn_bwd_reduce: mask_mode 1 needs out");
+  PFR_CHECK_ARG(mask_mode != 2 || (scale && shift), "pfr_bn_bwd_reduce: mask_mode 2 needs scale/shift");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_reduce: C %% %d != 0", kp);
+  ColGeom g = col_geom(C, kp, (size_t)rows);
+  const size_t shb = (size_t)256 * 2 * kp * sizeof(float);
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), shb, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, mean, invstd, scale, shift, mask_mode, part, (size_t)rows, C, g.cw, g.rl, g.cpr);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.gx, g.gy), dim3(256), shb, st, (const float*)dout, (const float*)out, (const float*)x, mean, invstd, scale, shift, mask_mode, part, (size_t)rows, C, g.cw, g.rl, g.cpr);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ---- backward finalise: partials → dgamma, dbeta and the per-channel coefficients of
+//      dx = cg·g + cx·x + c0     (cg = γ·invstd, cx = −γ·invstd²·Σgx̂/M, c0 = −γ·invstd·Σg/M − cx·mean)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef,
+                                                              int accumulate) {
+  __shared__ float l1[16][17], l2[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a = 0.f, b = 0.f;
+  if (c < C)
+    for (int i = pl; i < nparts; i += 16) {
+      a += part[((size_t)i * 2 + 0) * C + c];
+      b += part[((size_t)i * 2 + 1) * C + c];
+    }
+  l1[pl][cl] = a;
+  l2[pl][cl] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sg += l1[i][cl]; sgx += l2[i][cl]; }
+    const float g = gamma ? gamma[c] : 1.f, is = invstd[c], mu = mean[c];
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sgx : sgx;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sg : sg;
+    const float cg = g * is;
+    const float cx = -g * is * is * sgx / count;
+    const float c0 = -g * is * sg / count - cx * mu;
+    coef[c] = cg;
+    coef[C + c] = cx;
+    coef[2 * C + c] = c0;
+  }
+}
+
+extern "C" int pfr_bn_bwd_finalize(const float* part, int nparts, int C, float count, const float* gamma,
+                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                                   int accumulate, hipStream_t st) {
+  PFR_CHECK_ARG(part && mean && invstd && coef, "pfr_bn_bwd_finalize: null pointer");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, nparts, C, count, gamma, mean, invstd, dgamma, dbeta, coef, accumulate);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ---- backward apply: g = dout·mask ; dx = cg·g + cx·x + c0 ; optional gres (+)= g  (gradient of the residual input)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                           const T* __restrict__ x, const float* __restrict__ coef,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int mask_mode, T* __restrict__ dx, T* __restrict__ gres,
+                                                           size_t nchunks, int cpr, int C) {
+  constexpr int KP = DT<T>::KPACK;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nchunks; i += stride) {
+    const int c = (int)(i % cpr) * KP;
+    float g[KP], xv[KP], o[KP];
+    Chunk<T>::unpack(ld16(dout + i * KP), g);
+    Chunk<T>::unpack(ld16(x + i * KP), xv);
+    if (mask_mode == 1) Chunk<T>::unpack(ld16(out + i * KP), o);
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      float gg = g[e];
+      if (mask_mode == 1) gg = o[e] > 0.f ? gg : 0.f;
+      if (mask_mode == 2) gg = fmaf(xv[e], scale[c + e], shift[c + e]) > 0.f ? gg : 0.f;
+      g[e] = gg;
+      xv[e] = fmaf(coef[c + e], gg, fmaf(coef[C + c + e], xv[e], coef[2 * C + c + e]));
+    }
+    st16(dx + i * KP, Chunk<T>::pack(xv));
+    if (gres) st16(gres + i * KP, Chunk<T>::pack(g));
+  }
+}
+
+extern "C" int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x, const float* coef, const float* scale,
+                                const float* shift, int mask_mode, void* dx, void* gres, int dtype, long rows, int C,
+                                hipStream_t st) {
+  PFR_CHECK_ARG(dout && x && coef && dx, "pfr_bn_bwd_apply: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_apply: C %% %d != 0", kp);
+  const size_t nch = (size_t)rows * (C / kp);
+  unsigned blocks = (unsigned)((nch + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, coef, scale, shift, mask_mode, (bf16_t*)dx, (bf16_t*)gres, nch, C / kp, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, coef, scale, shift, mask_mode, (float*)dx, (float*)gres, nch, C / kp, C);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// elementwise y = a + b (gradient joins of the residual graph)
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t nchunks) {
+  constexpr int KP = DT<T>::KPACK;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nchunks; i += stride) {
+    float f[KP], g[KP];
+    Chunk<T>::unpack(ld16(a + i * KP), f);
+    Chunk<T>::unpack(ld16(b + i * KP), g);
+#pragma unroll
+    for (int e = 0; e < KP; ++e) f[e] += g[e];
+    st16(y + i * KP, Chunk<T>::pack(f));
+  }
+}
+extern "C" int pfr_add(const void* a, const void* b, void* y, int dtype, size_t n, hipStream_t st) {
+  PFR_CHECK_ARG(a && b && y, "pfr_add: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(n % kp == 0, "pfr_add: n %% %d != 0", kp);
+  const size_t nch = n / kp;
+  unsigned blocks = (unsigned)((nch + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, nch);
+  else
+    hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, nch);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused BN-apply + ReLU + MaxPool(3,2,1) forward (stem) with argmax index, and its backward
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, T* __restrict__ y,
+                                                                  uint8_t* __restrict__ idx, int N, int H, int W, int C,
+                                                                  int OH, int OW, int relu) {
+  constexpr int KP = DT<T>::KPACK;
+  const int cpr = C / KP;
+  const size_t nch = (size_t)N * OH * OW * cpr;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nch; i += stride) {
+    const int cc = (int)(i % cpr);
+    size_t pix = i / cpr;
+    const int ow = (int)(pix % OW); pix /= OW;
+    const int oh = (int)(pix % OH);
+    const int n = (int)(pix / OH);
+    float best[KP], sc[KP], sh[KP];
+    int bi[KP];
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      best[e] = -INFINITY; bi[e] = 0;
+      sc[e] = scale ? scale[cc * KP + e] : 1.f;
+      sh[e] = shift ? shift[cc * KP + e] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ih = oh * 2 - 1 + r, iw = ow * 2 - 1 + s;
+        if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+        float f[KP];
+        Chunk<T>::unpack(ld16(x + (((size_t)n * H + ih) * W + iw) * C + cc * KP), f);
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          float z = fmaf(f[e], sc[e], sh[e]);
+          if (relu) z = fmaxf(z, 0.f);
+          z = to_f32(from_f32<T>(z));
+          if (z > best[e]) { best[e] = z; bi[e] = r * 3 + s; }
+        }
+      }
+    st16(y + i * KP, Chunk<T>::pack(best));
+    if (idx) {
+      if constexpr (KP == 8) {
+        uint64_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk |= (uint64_t)bi[e] << (8 * e);
+        *reinterpret_cast<uint64_t*>(idx + i * 8) = pk;
+      } else {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk |= (uint32_t)bi[e] << (8 * e);
+        *reinterpret_cast<uint32_t*>(idx + i * 4) = pk;
+      }
+    }
+  }
+}
+
+extern "C" int pfr_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx,
+                                       int dtype, int N, int H, int W, int C, int relu, hipStream_t st) {
+  PFR_CHECK_ARG(x && y, "pfr_bn_relu_maxpool_fwd: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_relu_maxpool_fwd: C %% %d != 0", kp);
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const size_t nch = (size_t)N * OH * OW * (C / kp);
+  unsigned blocks = (unsigned)((nch + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, idx, N, H, W, C, OH, OW, relu);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, idx, N, H, W, C, OH, OW, relu);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// backward: dz[n,h,w,c] = Σ over the ≤4 windows covering (h,w) whose argmax is this tap of dy  (gather, no atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          T* __restrict__ dz, int N, int H, int W, int C, int OH, int OW) {
+  constexpr int KP = DT<T>::KPACK;
+  const int cpr = C / KP;
+  const size_t nch = (size_t)N * H * W * cpr;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nch; i += stride) {
+    const int cc = (int)(i % cpr);
+    size_t pix = i / cpr;
+    const int w = (int)(pix % W); pix /= W;
+    const int h = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float acc[KP];
+#pragma unroll
+    for (int e = 0; e < KP; ++e) acc[e] = 0.f;
+    // windows: oh with oh*2-1+r == h, r in 0..2
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int t = h + 1 - r;
+      if (t < 0 || (t & 1)) continue;
+      const int oh = t >> 1;
+      if (oh >= OH) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int u = w + 1 - s;
+        if (u < 0 || (u & 1)) continue;
+        const int ow = u >> 1;
+        if (ow >= OW) continue;
+        const size_t o = (((size_t)n * OH + oh) * OW + ow) * cpr + cc;
+        float g[KP];
+        Chunk<T>::unpack(ld16(dy + o * KP), g);
+        uint64_t pk;
+        if constexpr (KP == 8) pk = *reinterpret_cast<const uint64_t*>(idx + o * 8);
+        else pk = *reinterpret_cast<const uint32_t*>(idx + o * 4);
+#pragma unroll
+        for (int e = 0; e < KP; ++e)
+          if ((int)((pk >> (8 * e)) & 0xff) == r * 3 + s) acc[e] += g[e];
+      }
+    }
+    st16(dz + i * KP, Chunk<T>::pack(acc));
+  }
+}
+
+extern "C" int pfr_maxpool_bwd(const void* dy, const uint8_t* idx, void* dz, int dtype, int N, int H, int W, int C,
+                               hipStream_t st) {
+  PFR_CHECK_ARG(dy && idx && dz, "pfr_maxpool_bwd: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const size_t nch = (size_t)N * H * W * (C / kp);
+  unsigned blocks = (unsigned)((nch + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, idx, (bf16_t*)dz, N, H, W, C, OH, OW);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, idx, (float*)dz, N, H, W, C, OH, OW);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// global average pool [N][HW][C] -> [N][C] and its backward
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C) {
+  constexpr int KP = DT<T>::KPACK;
+  const int cpr = C / KP;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * cpr) return;
+  const int n = (int)(i / cpr), cc = (int)(i % cpr);
+  float a[KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) a[e] = 0.f;
+  for (int p = 0; p < HW; ++p) {
+    float f[KP];
+    Chunk<T>::unpack(ld16(x + ((size_t)n * HW + p) * C + cc * KP), f);
+#pragma unroll
+    for (int e = 0; e < KP; ++e) a[e] += f[e];
+  }
+  const float inv = 1.f / HW;
+#pragma unroll
+  for (int e = 0; e < KP; ++e) a[e] *= inv;
+  st16(y + i * KP, Chunk<T>::pack(a));
+}
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int HW, int C) {
+  constexpr int KP = DT<T>::KPACK;
+  const int cpr = C / KP;
+  const size_t nch = (size_t)N * HW * cpr;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float inv = 1.f / HW;
+  for (; i < nch; i += stride) {
+    const int cc = (int)(i % cpr);
+    const size_t n = i / ((size_t)HW * cpr);
+    float f[KP];
+    Chunk<T>::unpack(ld16(dy + (n * cpr + cc) * KP), f);
+#pragma unroll
+    for (int e = 0; e < KP; ++e) f[e] *= inv;
+    st16(dx + i * KP, Chunk<T>::pack(f));
+  }
+}
+extern "C" int pfr_avgpool_fwd(const void* x, void* y, int dtype, int N, int HW, int C, hipStream_t st) {
+  PFR_CHECK_ARG(x && y, "pfr_avgpool_fwd: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  const size_t n = (size_t)N * (C / kp);
+  const unsigned blocks = (unsigned)((n + 63) / 64);
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(blocks), dim3(64), 0, st, (const bf16_t*)x, (bf16_t*)y, N, HW, C);
+  else
+    hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(blocks), dim3(64), 0, st, (const float*)x, (float*)y, N, HW, C);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+extern "C" int pfr_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int HW, int C, hipStream_t st) {
+  PFR_CHECK_ARG(dy && dx, "pfr_avgpool_bwd: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  const size_t nch = (size_t)N * HW * (C / kp);
+  unsigned blocks = (unsigned)((nch + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, HW, C);
+  else
+    hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, N, HW, C);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// column sums of a [rows][C] matrix in compute dtype → fp32 (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int C,
+                                                     int accumulate) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  __shared__ float l[4][64];
+  float a = 0.f;
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) a += to_f32(x[(size_t)r * C + c]);
+  l[rl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    a = l[0][threadIdx.x] + l[1][threadIdx.x] + l[2][threadIdx.x] + l[3][threadIdx.x];
+    out[c] = accumulate ? out[c] + a : a;
+  }
+}
+extern "C" int pfr_colsum(const void* x, int dtype, int rows, int C, float* out, int accumulate, hipStream_t st) {
+  PFR_CHECK_ARG(x && out, "pfr_colsum: null pointer");
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, out, rows, C, accumulate);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)x, out, rows, C, accumulate);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimiser steps over flat fp32 master buffers (+ compute-dtype shadow copy of the parameters)
+template <typename TS>
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, TS* __restrict__ shadow,
+                           size_t n, float lr, float momentum, float wd, float gscale, int first) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float w = p[i];
+    float d = fmaf(wd, w, g[i] * gscale);
+    float b = d;
+    if (momentum != 0.f) {
+      b = first ? d : fmaf(momentum, mom[i], d);
+      mom[i] = b;
+    }
+    w = fmaf(-lr, b, w);
+    p[i] = w;
+    if (shadow) shadow[i] = from_f32<TS>(w);
+  }
+}
+extern "C" int pfr_sgd_step(float* p, const float* g, float* mom, void* shadow, int shadow_dtype, size_t n, float lr,
+                            float momentum, float weight_decay, float grad_scale, int first_step, hipStream_t st) {
+  PFR_CHECK_ARG(p && g && (momentum == 0.f || mom), "pfr_sgd_step: null pointer");
+  if (n == 0) return PFR_OK;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (shadow && shadow_dtype == PFR_BF16)
+    hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, p, g, mom, (bf16_t*)shadow, n, lr, momentum, weight_decay, grad_scale, first_step);
+  else
+    hipLaunchKernelGGL(sgd_kernel<float>, dim3(blocks), dim3(256), 0, st, p, g, mom, (float*)shadow, n, lr, momentum, weight_decay, grad_scale, first_step);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+template <typename TS>
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             TS* __restrict__ shadow, size_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2, float gscale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float w = p[i];
+    const float gr = g[i] * gscale;
+    w *= 1.f - lr * wd;
+    const float mm = b1 * m[i] + (1.f - b1) * gr;
+    const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mm;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
+    w -= (lr / bc1) * mm / denom;
+    p[i] = w;
+    if (shadow) shadow[i] = from_f32<TS>(w);
+  }
+}
+extern "C" int pfr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, size_t n,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              float grad_scale, hipStream_t st) {
+  PFR_CHECK_ARG(p && g && m && v && step >= 1, "pfr_adamw_step: bad args");
+  if (n == 0) return PFR_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (shadow && shadow_dtype == PFR_BF16)
+    hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  else
+    hipLaunchKernelGGL(adamw_kernel<float>, dim3(blocks), dim3(256), 0, st, p, g, m, v, (float*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}

@@ -1,0 +1,361 @@
+// pfr_igemm.hip — NHWC implicit-GEMM convolution on MFMA (forward, data-gradient, plain GEMM).
+//
+// Replaces, on the reference's hot path, every `nn.Conv2d` / `nn.Linear` / `F.linear` forward call and the
+// autograd input-gradient of the same ops (torchvision resnet50 built at /root/reference
+// configs/dog_fe/fe_dogs_config.py:102-103; `F.linear` at losses/large_margin.py:71).
+//
+//   y[m][co] = sum_{r,s,c} act(x)[n, oh*ostride - pad + r, ow*ostride - pad + s, c] * w[co][r][s][c]
+//   m = (n*OH + oh)*OW + ow,  act = identity or the fused BatchNorm-apply(+ReLU) prologue of the PRODUCER layer.
+//
+// The data gradient of a stride-u conv is the same kernel run over dy with `idil_log2 = log2(u)` (input dilation:
+// only taps whose dilated coordinate is a multiple of u exist) and tap-flipped, channel-transposed weights.
+//
+// MI355X mapping: 256-thread workgroups (4 waves, 2x2), 128x128 / 128x64 / 64x128 / 64x64 output tiles,
+// v_mfma_f32_32x32x16_bf16 (or the exact-f32 v_mfma_f32_32x32x2_f32 for the parity path), operand tiles gathered
+// straight from NHWC HBM in 16-byte channel chunks into double-buffered LDS (80-byte padded rows), accumulators
+// transposed through LDS in the epilogue so that HBM stores are whole 16-byte row segments, per-channel
+// sum / sum-of-squares partials for the FOLLOWING train-mode BatchNorm produced from the same LDS tile
+// (deterministic: one partial row per m-tile, no atomics), XCD-aware tile order (n-tiles of one m-tile adjacent).
+#include "pfr_mma.h"
+
+struct IgemmParams {
+  const void* x;
+  const void* w;
+  void* y;
+  int N, H, W, C;
+  int R, S, OH, OW, ostride, pad, idil_log2;
+  int Cout, ldy;
+  int M, K;
+  float* stats_part;  // [tilesM][2][Cout] or nullptr
+  const float* bias;  // [Cout] or nullptr
+  int accumulate;
+  const float* pro_scale;  // [C] or nullptr
+  const float* pro_shift;
+  int pro_relu;
+  int out_relu;
+  FastDiv div_ohow, div_ow;
+  int tilesM, tilesN;
+};
+
+template <typename T, typename TO, int BQ, int BP, bool PRO>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+  constexpr int KP = DT<T>::KPACK;
+  constexpr int BK = KStep<T>::BK;
+  constexpr int TP = BP / 64, TQ = BQ / 64;
+  constexpr int QCH = BQ / 64, PCH = BP / 64;  // 16-byte chunks per thread per k-step
+  constexpr int STAGE = (BP + BQ) * PFR_ROWB;
+  constexpr int KPO = 16 / (int)sizeof(TO);
+  constexpr int OROWB = BP * (int)sizeof(TO) + 16;
+  constexpr int EPI = BQ * OROWB;
+  constexpr int RED = 4 * BP * 2 * 4;
+  constexpr int SMEM = (2 * STAGE > EPI + RED) ? 2 * STAGE : EPI + RED;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wq = wave & 1;
+
+  const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = t % p.tilesN, tm = t / p.tilesN;
+  const int m0 = tm * BQ, n0 = tn * BP;
+
+  const int cc = tid & 3, r0 = tid >> 2;
+
+  // ---- per-row gather state for the activation (Q) operand
+  int ihb[QCH], iwb[QCH], pixb[QCH];
+#pragma unroll
+  for (int j = 0; j < QCH; ++j) {
+    const int m = m0 + r0 + 64 * j;
+    if (m < p.M) {
+      const uint32_t n_img = fdiv((uint32_t)m, p.div_ohow);
+      const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
+      const uint32_t oh = fdiv(rem, p.div_ow);
+      const uint32_t ow = rem - oh * p.OW;
+      ihb[j] = (int)oh * p.ostride - p.pad;
+      iwb[j] = (int)ow * p.ostride - p.pad;
+      pixb[j] = n_img * p.H * p.W;
+    } else {
+      ihb[j] = -(1 << 28);
+      iwb[j] = -(1 << 28);
+      pixb[j] = 0;
+    }
+  }
+  // ---- k-chunk -> (tap r, tap s, channel c) of this thread's chunk column
+  int kel = cc * KP;
+  int tap = kel / p.C;
+  int c = kel - tap * p.C;
+  int tr = tap / p.S;
+  int ts = tap - tr * p.S;
+
+  const char* xb = reinterpret_cast<const char*>(p.x);
+  const char* wb = reinterpret_cast<const char*>(p.w);
+  const int dmask = (1 << p.idil_log2) - 1;
+
+  u32x4 qreg[QCH], preg[PCH];
+  float psc[PRO ? KP : 1], psh[PRO ? KP : 1];
+  uint32_t qok = 0;
+
+  auto gload = [&]() {
+    const bool kok = kel < p.K;
+    qok = 0;
+#pragma unroll
+    for (int j = 0; j < QCH; ++j) {
+      int ih = ihb[j] + tr, iw = iwb[j] + ts;
+      bool ok = kok && (((ih | iw) & dmask) == 0);
+      ih >>= p.idil_log2;
+      iw >>= p.idil_log2;
+      ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const size_t off = ((size_t)(pixb[j] + ih * p.W + iw) * p.C + c) * sizeof(T);
+        v = ld16(xb + off);
+        qok |= 1u << j;
+      }
+      qreg[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int row = n0 + r0 + 64 * j;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kok && row < p.Cout) v = ld16(wb + ((size_t)row * p.K + kel) * sizeof(T));
+      preg[j] = v;
+    }
+    if constexpr (PRO) {
+      if (kok) {
+#pragma unroll
+        for (int e = 0; e < KP; e += 4) {
+          f32x4 a = *reinterpret_cast<const f32x4*>(p.pro_scale + c + e);
+          f32x4 b = *reinterpret_cast<const f32x4*>(p.pro_shift + c + e);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { psc[e + u] = a[u]; psh[e + u] = b[u]; }
+        }
+      }
+    }
+    // advance to the next k-step
+    kel += BK;
+    c += BK;
+    while (c >= p.C) {
+      c -= p.C;
+      if (++ts == p.S) { ts = 0; ++tr; }
+    }
+  };
+
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) st16(base + (r0 + 64 * j) * PFR_ROWB + cc * 16, preg[j]);
+#pragma unroll
+    for (int j = 0; j < QCH; ++j) {
+      u32x4 v = qreg[j];
+      if constexpr (PRO) {
+        if (qok & (1u << j)) {
+          float f[KP];
+          Chunk<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < KP; ++e) {
+            float z = fmaf(f[e], psc[e], psh[e]);
+            f[e] = p.pro_relu ? fmaxf(z, 0.f) : z;
+          }
+          v = Chunk<T>::pack(f);
+        }
+      }
+      st16(base + (BP + r0 + 64 * j) * PFR_ROWB + cc * 16, v);
+    }
+  };
+
+  f32x16 acc[TP][TQ];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload();
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload();
+    const char* base = smem + buf * STAGE;
+    mma_kstep<T, TP, TQ>(base + (wp * (BP / 2)) * PFR_ROWB, base + (BP + wq * (BQ / 2)) * PFR_ROWB, lane, acc);
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue phase 1: accumulators -> LDS tile [BQ rows m][BP couts] of TO
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int mrow = wq * (BQ / 2) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int co = wp * (BP / 2) + i * 32 + 8 * qd + 4 * (lane >> 5);
+        char* dst = smem + mrow * OROWB + co * (int)sizeof(TO);
+        if constexpr (sizeof(TO) == 4) {
+          f32x4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          bf16x4 v;
+          v[0] = (bf16_t)acc[i][j][4 * qd];
+          v[1] = (bf16_t)acc[i][j][4 * qd + 1];
+          v[2] = (bf16_t)acc[i][j][4 * qd + 2];
+          v[3] = (bf16_t)acc[i][j][4 * qd + 3];
+          *reinterpret_cast<bf16x4*>(dst) = v;
+        }
+      }
+    }
+  __syncthreads();
+
+  // ---- epilogue phase 2: row-major 16-byte chunks: bias / accumulate / relu / BN partial sums / store
+  constexpr int CPR = BP * (int)sizeof(TO) / 16;  // chunks per output row
+  constexpr int RPP = 256 / CPR;                  // rows per pass
+  const int oc = tid % CPR, rl = tid / CPR;
+  const int co = n0 + oc * KPO;
+  float s1[KPO], s2[KPO], bia[KPO];
+#pragma unroll
+  for (int e = 0; e < KPO; ++e) {
+    s1[e] = 0.f;
+    s2[e] = 0.f;
+    bia[e] = (p.bias && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+  }
+  const bool vec_ok = (co + KPO <= p.Cout) && ((p.ldy * (int)sizeof(TO)) % 16 == 0);
+  char* yb = reinterpret_cast<char*>(p.y);
+#pragma unroll 4
+  for (int rr = rl; rr < BQ; rr += RPP) {
+    const int m = m0 + rr;
+    if (m >= p.M || co >= p.Cout) continue;
+    u32x4 v = *reinterpret_cast<const u32x4*>(smem + rr * OROWB + oc * 16);
+    float f[KPO];
+    Chunk<TO>::unpack(v, f);
+    char* dst = yb + ((size_t)m * p.ldy + co) * sizeof(TO);
+    const bool post = p.bias || p.accumulate || p.out_relu;
+    if (post) {
+      if (p.accumulate) {
+        float g[KPO];
+        if (vec_ok) {
+          Chunk<TO>::unpack(ld16(dst), g);
+        } else {
+#pragma unroll
+          for (int e = 0; e < KPO; ++e) g[e] = (co + e < p.Cout) ? to_f32(reinterpret_cast<TO*>(dst)[e]) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < KPO; ++e) f[e] += g[e];
+      }
+#pragma unroll
+      for (int e = 0; e < KPO; ++e) {
+        f[e] += bia[e];
+        if (p.out_relu) f[e] = fmaxf(f[e], 0.f);
+      }
+      v = Chunk<TO>::pack(f);
+      Chunk<TO>::unpack(v, f);  // statistics see the value as stored
+    }
+    if (p.stats_part) {
+#pragma unroll
+      for (int e = 0; e < KPO; ++e) {
+        s1[e] += f[e];
+        s2[e] = fmaf(f[e], f[e], s2[e]);
+      }
+    }
+    if (vec_ok) {
+      st16(dst, v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < KPO; ++e)
+        if (co + e < p.Cout) reinterpret_cast<TO*>(dst)[e] = from_f32<TO>(f[e]);
+    }
+  }
+  if (p.stats_part) {
+    // lanes with equal (lane % CPR) hold partials of the same channels
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < KPO; ++e) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    float* red = reinterpret_cast<float*>(smem + EPI);  // [4 waves][2][BP]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < KPO; ++e) {
+        red[(wave * 2 + 0) * BP + oc * KPO + e] = s1[e];
+        red[(wave * 2 + 1) * BP + oc * KPO + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BP) {
+      const int which = tid / BP, ch = tid % BP;
+      if (n0 + ch < p.Cout) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a += red[(w * 2 + which) * BP + ch];
+        p.stats_part[((size_t)tm * 2 + which) * p.Cout + n0 + ch] = a;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, int BQ, int BP>
+static int launch_tile(IgemmParams& p, hipStream_t st) {
+  p.tilesM = (p.M + BQ - 1) / BQ;
+  p.tilesN = (p.Cout + BP - 1) / BP;
+  const dim3 grid((unsigned)(p.tilesM * p.tilesN));
+  if (p.pro_scale)
+    hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false>), grid, dim3(256), 0, st, p);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// m-tile height the launcher will pick (the caller sizes stats_part with it)
+static int pick_bq(int M, int Cout) {
+  const int bp = Cout >= 128 ? 128 : 64;
+  const long tiles128 = (long)((M + 127) / 128) * ((Cout + bp - 1) / bp);
+  return tiles128 >= 512 ? 128 : 64;
+}
+
+template <typename T, typename TO>
+static int launch_igemm(IgemmParams& p, hipStream_t st) {
+  const int bq = pick_bq(p.M, p.Cout);
+  if (p.Cout >= 128) {
+    if (bq == 128) return launch_tile<T, TO, 128, 128>(p, st);
+    return launch_tile<T, TO, 64, 128>(p, st);
+  }
+  if (bq == 128) return launch_tile<T, TO, 128, 64>(p, st);
+  return launch_tile<T, TO, 64, 64>(p, st);
+}
+
+extern "C" int pfr_conv2d_mtile(int M, int Cout) { return pick_bq(M, Cout); }
+
+extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
+                              int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
+                              int ldy, const float* bias, int accumulate, int out_relu, const float* pro_scale,
+                              const float* pro_shift, int pro_relu, float* stats_part, hipStream_t stream) {
+  PFR_CHECK_ARG(x && w && y, "pfr_conv2d_fwd: null pointer");
+  PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_conv2d_fwd: bad dtype %d", dtype);
+  PFR_CHECK_ARG(out_dtype == dtype || out_dtype == PFR_F32, "pfr_conv2d_fwd: out_dtype must be dtype or f32");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_conv2d_fwd: C=%d must be a multiple of %d (16-byte channel chunks)", C, kp);
+  PFR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && R > 0 && S > 0 && OH > 0 && OW > 0 && stride > 0,
+                "pfr_conv2d_fwd: bad geometry");
+  PFR_CHECK_ARG((long)N * OH * OW < (1L << 31) && (long)N * H * W * C < (1L << 31), "pfr_conv2d_fwd: tensor too large");
+  PFR_CHECK_ARG(!pro_scale || (C % 4 == 0 && pro_shift), "pfr_conv2d_fwd: prologue needs scale and shift");
+  IgemmParams p;
+  p.x = x; p.w = w; p.y = y;
+  p.N = N; p.H = H; p.W = W; p.C = C;
+  p.R = R; p.S = S; p.OH = OH; p.OW = OW; p.ostride = stride; p.pad = pad; p.idil_log2 = idil_log2;
+  p.Cout = Cout; p.ldy = ldy > 0 ? ldy : Cout;
+  p.M = N * OH * OW; p.K = R * S * C;
+  p.stats_part = stats_part; p.bias = bias; p.accumulate = accumulate; p.out_relu = out_relu;
+  p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
+  p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
+  p.div_ow = make_fastdiv((uint32_t)OW);
+  if (dtype == PFR_BF16) {
+    if (out_dtype == PFR_BF16) return launch_igemm<bf16_t, bf16_t>(p, stream);
+    return launch_igemm<bf16_t, float>(p, stream);
+  }
+  return launch_igemm<float, float>(p, stream);
+}

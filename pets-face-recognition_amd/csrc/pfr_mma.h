@@ -1,0 +1,56 @@
+// pfr_mma.h — the MFMA tile engine shared by the implicit-GEMM conv kernels (fwd / dgrad / wgrad / plain GEMM).
+//
+// Geometry (identical in BYTES for both dtypes):
+//   * an LDS operand tile is ROWS x 64 B of k-values (32 bf16 or 16 f32) per k-step, row stride 80 B
+//     (64 + 16 pad → ds_read_b128 by the 16-lane groups of gfx950 is bank-conflict free);
+//   * a k-step holds two "k-groups" of 32 B per row; a k-group feeds ONE v_mfma_f32_32x32x16_bf16
+//     (lane = row, lane>>5 selects the 16-byte half) or FOUR v_mfma_f32_32x32x2_f32 (element j of both
+//     operands' 16-byte chunk is k-slot {j, 4+j}: any k-permutation is legal as long as A and B agree);
+//   * 256 threads = 4 waves in a 2x2 grid; wave (wp, wq) owns P-rows [wp*BP/2, +BP/2) x Q-rows [wq*BQ/2, +BQ/2)
+//     as (BP/64) x (BQ/64) accumulators of 32x32.  The P operand is the MFMA "A" (accumulator ROW index),
+//     the Q operand the MFMA "B" (accumulator COLUMN index = lane & 31).
+#pragma once
+#include "pfr_common.h"
+
+#define PFR_ROWB 80   // LDS row stride in bytes for operand tiles
+#define PFR_KSTEP_BYTES 64
+
+template <typename T> struct KStep;  // elements per k-step
+template <> struct KStep<float> { static constexpr int BK = 16; };
+template <> struct KStep<bf16_t> { static constexpr int BK = 32; };
+
+template <typename T, int TP, int TQ>
+__device__ __forceinline__ void mma_kstep(const char* ldsP, const char* ldsQ, int lane, f32x16 (&acc)[TP][TQ]) {
+  // ldsP / ldsQ point at row 0 of THIS WAVE's slice of the operand tiles.
+  const int row = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg) {
+    u32x4 fp[TP], fq[TQ];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+      fp[i] = *reinterpret_cast<const u32x4*>(ldsP + (i * 32 + row) * PFR_ROWB + kg * 32 + half * 16);
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+      fq[j] = *reinterpret_cast<const u32x4*>(ldsQ + (j * 32 + row) * PFR_ROWB + kg * 32 + half * 16);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fp[i]),
+                                                               __builtin_bit_cast(bf16x8, fq[j]), acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fp[i][e]), __uint_as_float(fq[j][e]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
+// accumulator element (reg r of a 32x32 tile) -> row within the tile; column is lane & 31.
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

@@ -1,0 +1,307 @@
+// pfr_wgrad.hip — weight gradient of an NHWC convolution / linear layer on MFMA.
+//
+// Replaces the autograd weight-gradient of every `nn.Conv2d` / `nn.Linear` / `F.linear` on the reference's hot
+// path (backward of torchvision resnet50, configs/dog_fe/fe_dogs_config.py:102-103, and of
+// losses/large_margin.py:71):
+//
+//   dw[co][r][s][c] = sum_m dy[m][co] * act(x)[n, oh*stride - pad + r, ow*stride - pad + s, c]
+//
+// GEMM view: rows = co (MFMA A), cols = kk = (r,s,c) (MFMA B), reduction = m.  BOTH operands are m-major in HBM
+// (channels contiguous), so tiles are staged into LDS exactly as they lie in memory ([m][channel], coalesced
+// 16-byte chunks, no register shuffling) and the per-lane "8 consecutive k" MFMA operand is produced by the
+// gfx950 LDS transpose read `ds_read_b64_tr_b16` (bf16) or plain `ds_read_b32` (f32: one k per lane).
+// The reduction over m is split across workgroups; each split writes an fp32 partial slab
+// [split][Cout][KK] (deterministic), summed by pfr_wgrad_reduce.
+#include "pfr_mma.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+  const void* x;
+  const void* dy;
+  float* dw;
+  int N, H, W, C, R, S, OH, OW, stride, pad;
+  int Cout, lddy, M, KK;
+  int splits, mchunk;
+  const float* pro_scale;
+  const float* pro_shift;
+  int pro_relu;
+  FastDiv div_ohow, div_ow;
+  int tilesP, tilesQ;
+};
+
+template <typename T> struct WG {
+  static constexpr int BMR = 64 / (int)sizeof(T);  // reduction rows per k-step: 32 bf16 / 16 f32
+};
+
+template <typename T, int BP, int BQ, bool PRO>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  constexpr int KP = DT<T>::KPACK;
+  constexpr int BMR = WG<T>::BMR;
+  constexpr int TP = BP / 64, TQ = BQ / 64;
+  constexpr int RSP = BP * (int)sizeof(T) + 64;  // row strides: ≡ 16 dwords (mod 64) → tr-read rows on disjoint banks
+  constexpr int RSQ = BQ * (int)sizeof(T) + 64;
+  constexpr int TILEP = BMR * RSP, TILEQ = BMR * RSQ;
+  constexpr int STAGE = TILEP + TILEQ;
+  constexpr int CPRP = BP / KP, CPRQ = BQ / KP;   // 16-byte chunks per tile row
+  constexpr int NCHP = BMR * CPRP / 256, NCHQ = BMR * CPRQ / 256;  // chunks per thread
+  static_assert(NCHP >= 1 && NCHQ >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wq = wave & 1;
+
+  const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = p.tilesP * p.tilesQ;
+  const int split = t / ntile, tile = t % ntile;
+  const int tq = tile % p.tilesQ, tpp = tile / p.tilesQ;
+  const int co0 = tpp * BP, kk0 = tq * BQ;
+  const int mbeg = split * p.mchunk;
+  const int mend = min(p.M, mbeg + p.mchunk);
+
+  // P (dy) chunk geometry of this thread
+  const int pch = tid % CPRP, prow0 = tid / CPRP;  // rows prow0 + i*(256/CPRP)
+  const int pco = co0 + pch * KP;
+  // Q (x) chunk geometry
+  const int qch = tid % CPRQ, qrow0 = tid / CPRQ;
+  const int kk = kk0 + qch * KP;
+  const bool kkok = kk < p.KK;
+  const int tap = kkok ? kk / p.C : 0;
+  const int ci = kk - tap * p.C;
+  const int tr = tap / p.S, ts = tap - tr * p.S;
+
+  const char* xb = reinterpret_cast<const char*>(p.x);
+  const char* dyb = reinterpret_cast<const char*>(p.dy);
+
+  float psc[PRO ? KP : 1], psh[PRO ? KP : 1];
+  if constexpr (PRO) {
+    if (kkok) {
+#pragma unroll
+      for (int e = 0; e < KP; ++e) { psc[e] = p.pro_scale[ci + e]; psh[e] = p.pro_shift[ci + e]; }
+    }
+  }
+
+  u32x4 preg[NCHP], qreg[NCHQ];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < NCHP; ++i) {
+      const int m = mb + prow0 + i * (256 / CPRP);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m < mend && pco < p.Cout) v = ld16(dyb + ((size_t)m * p.lddy + pco) * sizeof(T));
+      preg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NCHQ; ++i) {
+      const int m = mb + qrow0 + i * (256 / CPRQ);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m < mend && kkok) {
+        const uint32_t n_img = fdiv((uint32_t)m, p.div_ohow);
+        const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
+        const uint32_t oh = fdiv(rem, p.div_ow);
+        const uint32_t ow = rem - oh * p.OW;
+        const int ih = (int)oh * p.stride - p.pad + tr, iw = (int)ow * p.stride - p.pad + ts;
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+          v = ld16(xb + ((size_t)((n_img * p.H + ih) * p.W + iw) * p.C + ci) * sizeof(T));
+          if constexpr (PRO) {
+            float f[KP];
+            Chunk<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < KP; ++e) {
+              float z = fmaf(f[e], psc[e], psh[e]);
+              f[e] = p.pro_relu ? fmaxf(z, 0.f) : z;
+            }
+            v = Chunk<T>::pack(f);
+          }
+        }
+      }
+      qreg[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NCHP; ++i) st16(base + (prow0 + i * (256 / CPRP)) * RSP + pch * 16, preg[i]);
+#pragma unroll
+    for (int i = 0; i < NCHQ; ++i) st16(base + TILEP + (qrow0 + i * (256 / CPRQ)) * RSQ + qch * 16, qreg[i]);
+  };
+
+  f32x16 acc[TP][TQ];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (mend - mbeg + BMR - 1) / BMR;
+  if (nk > 0) {
+    gload(mbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(mbeg + (kt + 1) * BMR);
+    const char* bp = smem + buf * STAGE + (wp * (BP / 2)) * (int)sizeof(T);
+    const char* bq = smem + buf * STAGE + TILEP + (wq * (BQ / 2)) * (int)sizeof(T);
+    if constexpr (sizeof(T) == 2) {
+      // lane l: g = l>>4 ; block column (channel) = (g&1)*16 + (l&15) = l&31 ; k-half = g>>1 = l>>5
+      const int g = lane >> 4, s = lane & 15;
+      const int roff = (g >> 1) * 8 + (s >> 2);          // row within the 16-row k-group (plus q*4)
+      const int coff = ((g & 1) * 16 + (s & 3) * 4) * 2;  // byte offset of this lane's 8-byte piece
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        bf16x8 fp[TP], fq[TQ];
+#pragma unroll
+        for (int i = 0; i < TP; ++i) {
+          const char* a = bp + (kg * 16 + roff) * RSP + i * 64 + coff;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 4 * RSP));
+          u32x4 u;
+          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          u[0] = l2[0]; u[1] = l2[1]; u[2] = h2[0]; u[3] = h2[1];
+          fp[i] = __builtin_bit_cast(bf16x8, u);
+        }
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+          const char* a = bq + (kg * 16 + roff) * RSQ + j * 64 + coff;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 4 * RSQ));
+          u32x4 u;
+          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          u[0] = l2[0]; u[1] = l2[1]; u[2] = h2[0]; u[3] = h2[1];
+          fq[j] = __builtin_bit_cast(bf16x8, u);
+        }
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[i], fq[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const int row = lane & 31, kh = lane >> 5;
+#pragma unroll
+      for (int e = 0; e < BMR / 2; ++e) {
+        float fp[TP], fq[TQ];
+#pragma unroll
+        for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const float*>(bp + (2 * e + kh) * RSP + (i * 32 + row) * 4);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const float*>(bq + (2 * e + kh) * RSQ + (j * 32 + row) * 4);
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fp[i], fq[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.dw + (size_t)split * p.Cout * p.KK;
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int col = kk0 + wq * (BQ / 2) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wp * (BP / 2) + i * 32 + acc_row(r, lane);
+        if (co < p.Cout && col < p.KK) out[(size_t)co * p.KK + col] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int splits,
+                                    float scale, int accumulate) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) a += *reinterpret_cast<const f32x4*>(part + (size_t)s * n + i);
+    a *= scale;
+    if (accumulate) a += *reinterpret_cast<const f32x4*>(dw + i);
+    *reinterpret_cast<f32x4*>(dw + i) = a;
+  } else {
+    for (size_t k = i; k < n; ++k) {
+      float a = 0.f;
+      for (int s = 0; s < splits; ++s) a += part[(size_t)s * n + k];
+      a *= scale;
+      if (accumulate) a += dw[k];
+      dw[k] = a;
+    }
+  }
+}
+
+template <typename T, int BP, int BQ>
+static int launch_wgrad(WgradParams& p, hipStream_t st) {
+  p.tilesP = (p.Cout + BP - 1) / BP;
+  p.tilesQ = (p.KK + BQ - 1) / BQ;
+  const dim3 grid((unsigned)(p.tilesP * p.tilesQ * p.splits));
+  if (p.pro_scale)
+    hipLaunchKernelGGL((wgrad_kernel<T, BP, BQ, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<T, BP, BQ, false>), grid, dim3(256), 0, st, p);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+static void wgrad_tiles(int Cout, int KK, int* bp, int* bq) {
+  *bp = Cout >= 128 ? 128 : 64;
+  *bq = KK >= 128 ? 128 : 64;
+}
+
+// number of m-splits the launcher uses (the caller sizes the workspace as splits*Cout*KK floats)
+extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
+  int bp, bq;
+  wgrad_tiles(Cout, KK, &bp, &bq);
+  const long tiles = (long)((Cout + bp - 1) / bp) * ((KK + bq - 1) / bq);
+  long want = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU in flight
+  const long maxs = (M + 255) / 256;       // at least 256 reduction rows per split
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float* workspace, int dtype, int N, int H,
+                                int W, int C, int Cout, int R, int S, int stride, int pad, int OH, int OW, int lddy,
+                                const float* pro_scale, const float* pro_shift, int pro_relu, float scale,
+                                int accumulate, hipStream_t stream) {
+  PFR_CHECK_ARG(x && dy && dw, "pfr_conv2d_wgrad: null pointer");
+  PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_conv2d_wgrad: bad dtype %d", dtype);
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_conv2d_wgrad: C=%d must be a multiple of %d", C, kp);
+  PFR_CHECK_ARG(Cout % kp == 0 && (lddy <= 0 || lddy % kp == 0), "pfr_conv2d_wgrad: Cout=%d / lddy must be multiples of %d", Cout, kp);
+  WgradParams p;
+  p.x = x; p.dy = dy;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.R = R; p.S = S; p.OH = OH; p.OW = OW; p.stride = stride; p.pad = pad;
+  p.Cout = Cout; p.lddy = lddy > 0 ? lddy : Cout; p.M = N * OH * OW; p.KK = R * S * C;
+  p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
+  p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
+  p.div_ow = make_fastdiv((uint32_t)OW);
+  p.splits = pfr_conv2d_wgrad_splits(p.M, Cout, p.KK);
+  const int bmr = dtype == PFR_BF16 ? 32 : 16;
+  int mchunk = (p.M + p.splits - 1) / p.splits;
+  mchunk = (mchunk + bmr - 1) / bmr * bmr;
+  p.mchunk = mchunk;
+  const bool direct = (p.splits == 1 && scale == 1.0f && !accumulate);
+  PFR_CHECK_ARG(direct || workspace, "pfr_conv2d_wgrad: workspace required (splits=%d)", p.splits);
+  p.dw = direct ? dw : workspace;
+  int bp, bq, rc;
+  wgrad_tiles(Cout, p.KK, &bp, &bq);
+#define PFR_WG_DISPATCH(T)                                        \
+  if (bp == 128 && bq == 128) rc = launch_wgrad<T, 128, 128>(p, stream); \
+  else if (bp == 128) rc = launch_wgrad<T, 128, 64>(p, stream);   \
+  else if (bq == 128) rc = launch_wgrad<T, 64, 128>(p, stream);   \
+  else rc = launch_wgrad<T, 64, 64>(p, stream);
+  if (dtype == PFR_BF16) { PFR_WG_DISPATCH(bf16_t) } else { PFR_WG_DISPATCH(float) }
+#undef PFR_WG_DISPATCH
+  if (rc != PFR_OK) return rc;
+  if (!direct) {
+    const size_t n = (size_t)Cout * p.KK;
+    const unsigned blocks = (unsigned)((n / 4 + 256) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, n, p.splits, scale, accumulate);
+    PFR_CHECK_LAUNCH();
+  }
+  return PFR_OK;
+}

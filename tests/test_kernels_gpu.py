@@ -1,0 +1,309 @@
+"""HIP kernel numerics vs plain PyTorch fp32 CPU references of the same op (called through the C-ABI)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from pets_face_recognition_amd._hip import ops as o
+    return o
+
+
+def tol(dtype):
+    return dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=2e-4)
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+def nhwc(x):  # NCHW -> NHWC contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, C, Cout, R, stride, pad
+    (2, 16, 16, 64, 64, 1, 1, 0),
+    (2, 16, 16, 64, 256, 1, 1, 0),
+    (3, 14, 14, 128, 128, 3, 1, 1),
+    (2, 15, 15, 64, 128, 3, 2, 1),
+    (2, 16, 16, 256, 512, 1, 2, 0),
+    (2, 32, 32, 8, 64, 7, 2, 3),
+    (5, 7, 7, 512, 512, 3, 1, 1),
+    (1, 9, 11, 32, 96, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    o = ops()
+    N, H, W, C, Cout, R, stride, pad = case
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Cout, C, R, R, generator=g) / math.sqrt(C * R * R)
+    if dtype == torch.bfloat16:  # compare on identical (bf16-representable) inputs
+        x = x.bfloat16().float()
+        w = w.bfloat16().float()
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    y.backward(dy)
+
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    wd = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV, dtype)  # [Cout,R,S,C]
+    yd, part = o.conv2d_fwd(xd, wd, stride=stride, pad=pad, stats=True)
+    torch.cuda.synchronize()
+    yr = nhwc(y.detach())
+    assert yd.shape == yr.shape
+    e = rel_err(yd.cpu(), yr)
+    assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), f"fwd rel err {e}"
+    # fused per-channel statistics of the stored output
+    s = part.sum(0).cpu()
+    ydf = yd.float().cpu().reshape(-1, Cout)
+    assert torch.allclose(s[0], ydf.sum(0), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(s[1], (ydf * ydf).sum(0), rtol=1e-3, atol=1e-2)
+
+    dyd = nhwc(dy).to(DEV, dtype)
+    wt = o.weight_dgrad_layout(wd)
+    dxd = o.conv2d_dgrad(dyd, wt, (H, W), stride, pad, R, R)
+    torch.cuda.synchronize()
+    e = rel_err(dxd.cpu(), nhwc(x.grad))
+    assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), f"dgrad rel err {e}"
+
+    dwd = o.conv2d_wgrad(xd, dyd, R, R, stride, pad)
+    torch.cuda.synchronize()
+    e = rel_err(dwd.cpu(), w.grad.permute(0, 2, 3, 1))
+    assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), f"wgrad rel err {e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_prologue_bias_accumulate(dtype):
+    o = ops()
+    g = torch.Generator().manual_seed(7)
+    N, H, W, C, Cout = 2, 10, 10, 64, 72
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) / 24
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.3
+    bias = torch.randn(Cout, generator=g)
+    y0 = torch.randn(N, Cout, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, y0 = x.bfloat16().float(), w.bfloat16().float(), y0.bfloat16().float()
+    xa = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    if dtype == torch.bfloat16:
+        xa = xa.bfloat16().float()
+    ref = F.relu(F.conv2d(xa, w, bias=bias, padding=1) + y0)
+    xd = nhwc(x).to(DEV, dtype)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    out = nhwc(y0).to(DEV, dtype)
+    o.conv2d_fwd(xd, wd, stride=1, pad=1, out=out, bias=bias.to(DEV), accumulate=True, out_relu=True,
+                 pro=(sc.to(DEV), sh.to(DEV), 1))
+    torch.cuda.synchronize()
+    e = rel_err(out.cpu(), nhwc(ref))
+    assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), e
+    # wgrad with the same prologue
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    wq = w.clone().requires_grad_(True)
+    F.conv2d(xa, wq, padding=1).backward(dy)
+    dwd = o.conv2d_wgrad(xd, nhwc(dy).to(DEV, dtype), 3, 3, 1, 1, pro=(sc.to(DEV), sh.to(DEV), 1))
+    torch.cuda.synchronize()
+    e = rel_err(dwd.cpu(), wq.grad.permute(0, 2, 3, 1))
+    assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), e
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_f32_out_odd_cols(dtype):
+    """plain GEMM (1x1 conv, H=W=1) with fp32 output, N not a multiple of the tile and a padded row pitch"""
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    B, D, C = 37, 512, 100
+    x = torch.randn(B, D, generator=g)
+    w = torch.randn(C, D, generator=g) / 22
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = x @ w.t()
+    ld = 104
+    out = torch.zeros(B, 1, 1, ld, dtype=torch.float32, device=DEV)
+    xd = x.view(B, 1, 1, D).to(DEV, dtype)
+    wd = w.view(C, 1, 1, D).to(DEV, dtype)
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    lib.pfr_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), out.data_ptr(), dtype_id(dtype), 0, B, 1, 1, D, C, 1, 1, 1, 0, 0, 1, 1,
+                       ld, 0, 0, 0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.view(B, ld).cpu()
+    assert rel_err(got[:, :C], ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+    assert (got[:, C:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 256, 2048])
+def test_batchnorm_train_fwd_bwd(dtype, C):
+    o = ops()
+    g = torch.Generator().manual_seed(11)
+    N, H, W = 4, 9, 9
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    res = torch.randn(N, C, H, W, generator=g)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    if dtype == torch.bfloat16:
+        x, res = x.bfloat16().float(), res.bfloat16().float()
+    x.requires_grad_(True)
+    res.requires_grad_(True)
+    gam = gamma.clone().requires_grad_(True)
+    bet = beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.relu(F.batch_norm(x, rm, rv, gam, bet, training=True, momentum=0.1, eps=1e-5) + res)
+    dy = torch.randn(y.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    y.backward(dy)
+
+    xd, resd = nhwc(x.detach()).to(DEV, dtype), nhwc(res.detach()).to(DEV, dtype)
+    part = o.bn_stats(xd)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    coef = o.bn_finalize(part, N * H * W, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rmd, rvd)
+    yd = o.bn_act(xd, coef[2], coef[3], x2=resd, relu=True)
+    torch.cuda.synchronize()
+    t = tol(dtype)
+    assert torch.allclose(rmd.cpu(), rm, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rvd.cpu(), rv, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(yd.float().cpu(), nhwc(y.detach()), **t)
+    dx, gres, dgam, dbet = o.bn_bwd(nhwc(dy).to(DEV, dtype), xd, coef[0], coef[1], gamma.to(DEV), N * H * W, mask_mode=1,
+                                     out_act=yd, want_gres=True)
+    torch.cuda.synchronize()
+    # compare against autograd on values where the ReLU mask agrees (bf16 output rounding can flip exact zeros)
+    assert rel_err(dx.cpu(), nhwc(x.grad)) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+    assert rel_err(gres.cpu(), nhwc(res.grad)) < (2e-2 if dtype == torch.bfloat16 else 1e-5)
+    assert rel_err(dgam.cpu(), gam.grad) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+    assert rel_err(dbet.cpu(), bet.grad) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_relu_maxpool_and_avgpool(dtype):
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 3, 64, 18, 18
+    x = torch.randn(N, C, H, W, generator=g)
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.5
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    z = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    if dtype == torch.bfloat16:
+        z = z.bfloat16().float()
+    z.requires_grad_(True)
+    y = F.max_pool2d(z, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    y.backward(dy)
+    xd = nhwc(x).to(DEV, dtype)
+    yd, idx = o.bn_relu_maxpool_fwd(xd, sc.to(DEV), sh.to(DEV))
+    dz = o.maxpool_bwd(nhwc(dy).to(DEV, dtype), idx, (H, W))
+    torch.cuda.synchronize()
+    assert torch.allclose(yd.float().cpu(), nhwc(y.detach()), **tol(dtype))
+    assert rel_err(dz.cpu(), nhwc(z.grad)) < (1e-2 if dtype == torch.bfloat16 else 1e-6)
+    # global average pool
+    a = torch.randn(N, 7, 7, 256, generator=g)
+    ad = a.to(DEV, dtype)
+    p = o.avgpool_fwd(ad)
+    torch.cuda.synchronize()
+    assert torch.allclose(p.float().cpu(), ad.float().cpu().mean(dim=(1, 2)), **tol(dtype))
+    d = o.avgpool_bwd(p, (7, 7))
+    torch.cuda.synchronize()
+    assert torch.allclose(d.float().cpu(), (p.float().cpu() / 49)[:, None, None, :].expand(N, 7, 7, 256), **tol(dtype))
+
+
+def _arcface_ref(x, w, label, s, m, easy, cosface=False, gamma=0.0):
+    cos = F.linear(F.normalize(x), F.normalize(w))
+    if cosface:
+        phi = cos - m
+    else:
+        sine = torch.sqrt(1.0 - cos * cos)
+        phi = cos * math.cos(m) - sine * math.sin(m)
+        if easy:
+            phi = torch.where(cos > 0, phi, cos)
+        else:
+            phi = torch.where(cos > math.cos(math.pi - m), phi, cos - math.sin(math.pi - m) * m)
+    oh = torch.zeros_like(cos)
+    oh.scatter_(1, label.view(-1, 1), 1)
+    logits = s * (oh * phi + (1 - oh) * cos)
+    logp = F.cross_entropy(logits, label, reduction="none")
+    p = torch.exp(-logp)
+    return logits, ((1 - p) ** gamma * logp).mean(), cos
+
+
+@pytest.mark.parametrize("mode,gamma", [("arc", 0.0), ("arc_easy", 0.0), ("cos", 0.0), ("arc", 2.0)])
+def test_margin_ce_and_l2norm(mode, gamma):
+    o = ops()
+    g = torch.Generator().manual_seed(21)
+    B, D, C = 33, 512, 1000
+    x = torch.randn(B, D, generator=g, requires_grad=True)
+    w = (torch.randn(C, D, generator=g) * 0.05).requires_grad_(True)
+    label = torch.randint(0, C, (B,), generator=g)
+    s, m = 64.0, (0.5 if mode != "cos" else 0.4)
+    logits, loss, cos = _arcface_ref(x, w, label, s, m, mode == "arc_easy", mode == "cos", gamma)
+    cos.retain_grad()
+    loss.backward()
+    cosd = cos.detach().to(DEV)
+    lg, lrows, dcos = o.margin_ce(cosd, label.to(DEV), C, mode, s, m, gamma=gamma, grad_scale=1.0 / B, dcos_dtype=torch.float32)
+    lossd = o.mean(lrows)
+    torch.cuda.synchronize()
+    assert torch.allclose(lg.cpu(), logits.detach(), rtol=1e-5, atol=1e-4)
+    assert abs(lossd.item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    assert rel_err(dcos.cpu(), cos.grad) < 1e-4
+    # l2 normalisation fwd/bwd
+    xd = x.detach().to(DEV)
+    xn, xnT, inv = o.l2norm_fwd(xd, torch.float32, want_t=True, ldt=40)
+    torch.cuda.synchronize()
+    ref = F.normalize(x.detach())
+    assert torch.allclose(xn.cpu(), ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(xnT.cpu()[:, :B], ref.t(), rtol=1e-5, atol=1e-6)
+    xx = x.detach().clone().requires_grad_(True)
+    gg = torch.randn(B, D, generator=g)
+    F.normalize(xx).backward(gg)
+    dx = o.l2norm_bwd(xd, inv, gg.to(DEV), torch.float32)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu(), xx.grad) < 1e-5
+
+
+def test_sgd_and_adamw_steps():
+    o = ops()
+    g = torch.Generator().manual_seed(9)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) for _ in range(3)]
+    # SGD
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, md = p0.clone().to(DEV), torch.zeros(n, device=DEV)
+    sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for i, gr in enumerate(grads):
+        pr.grad = gr.clone()
+        opt.step()
+        o.sgd_step(pd, gr.to(DEV), md, sh, 0.01, 0.9, 1e-4, first_step=(i == 0))
+    torch.cuda.synchronize()
+    assert torch.allclose(pd.cpu(), pr.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sh.float().cpu(), pr.detach().bfloat16().float(), rtol=1e-2, atol=1e-3)
+    # AdamW
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=1e-2)
+    pd, m1, v1 = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, gr in enumerate(grads):
+        pr.grad = gr.clone()
+        opt.step()
+        o.adamw_step(pd, gr.to(DEV), m1, v1, None, 1e-3, 0.9, 0.999, 1e-8, 1e-2, i + 1)
+    torch.cuda.synchronize()
+    assert torch.allclose(pd.cpu(), pr.detach(), rtol=1e-5, atol=1e-6)
