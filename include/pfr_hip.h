@@ -46,7 +46,7 @@ int pfr_device_arch(char* buf, int buflen);
  *   x [N][H][W][C], w [Cout][R][S][C], y [N*OH*OW][ldy] (ldy<=0 → Cout); ih = oh*stride - pad + r.
  *   bias [Cout] fp32 or NULL; accumulate: y += result; out_relu: y = max(y,0)
  *   pro_scale/pro_shift [C] fp32 or NULL: operand is relu?(scale[c]*x + shift[c]) (fused BN-apply of the producer)
- *   stats_part or NULL: fp32 [ceil(M/mtile)][2][Cout] per-channel (sum, sum of squares) of the stored y,
+ *   stats_part or NULL: fp32 [ceil(M/mtile)][2][Cout] per-channel (mean, M2 = Σ(y-mean)²) of each m-tile of the stored y,
  *   mtile = pfr_conv2d_mtile(M, Cout)  (input of pfr_bn_finalize; deterministic, no atomics). */
 int pfr_conv2d_mtile(int M, int Cout);
 int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W, int C,
@@ -70,13 +70,18 @@ int pfr_cast(const void* x, int src_dtype, void* y, int dst_dtype, size_t n, pfr
 int pfr_weight_dgrad_layout(const void* w, void* wt, int dtype, int O, int R, int S, int I, pfr_stream_t stream);
 int pfr_add(const void* a, const void* b, void* y, int dtype, size_t n, pfr_stream_t stream);
 int pfr_colsum(const void* x, int dtype, int rows, int C, float* out, int accumulate, pfr_stream_t stream);
+int pfr_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long rows, int cols, float scale, int accumulate,
+                   pfr_stream_t stream);
 
 /* ---- BatchNorm2d (train: batch statistics, eps, momentum, unbiased running var — torchvision resnet) ---- */
 int pfr_colreduce_blocks(int C, int dtype, long rows); /* partial rows written by pfr_bn_stats / pfr_bn_bwd_reduce */
 int pfr_bn_stats(const void* x, int dtype, long rows, int C, float* part, pfr_stream_t stream);
-int pfr_bn_finalize(const float* part, int nparts, int C, float count, const float* gamma, const float* beta, float eps,
-                    float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                    float* shift, pfr_stream_t stream);
+long pfr_bn_stats_rows_per_part(int C, int dtype, long rows);
+/* part: [nparts][2][C] = (mean_t, M2_t) of rows [t*rows_per_part, min(count, (t+1)*rows_per_part)) — written by
+ * pfr_conv2d_fwd (rows_per_part = pfr_conv2d_mtile) or pfr_bn_stats (rows_per_part = pfr_bn_stats_rows_per_part). */
+int pfr_bn_finalize(const float* part, int nparts, long rows_per_part, int C, float count, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                    float* invstd, float* scale, float* shift, pfr_stream_t stream);
 int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, pfr_stream_t stream);
 /* y = relu?( a1*x1 + b1 (+ a2*x2 + b2 | + x2) ): BN apply, ReLU and the residual add of a bottleneck in one pass */
@@ -108,7 +113,11 @@ int pfr_l2norm_bwd(const void* x, int in_dtype, const float* inv_norm, const flo
 /* mode 0 ArcFace hard margin, 1 ArcFace easy margin, 2 CosFace, 3 plain scaled cosine.
  * logits [B][C] fp32 or NULL, loss_rows [B] fp32 or NULL, dcos [B][ldc] (dcos_dtype) or NULL = grad_scale * d loss_row / d cos */
 int pfr_margin_ce(const float* cosv, const int64_t* label, int B, int C, int ldc, int mode, float s, float m, float gamma,
-                  float grad_scale, float* logits, float* loss_rows, void* dcos, int dcos_dtype, pfr_stream_t stream);
+                  float grad_scale, const float* grad_scale_dev, float* logits, float* loss_rows, void* dcos, int dcos_dtype,
+                  pfr_stream_t stream);
+/* standalone margin backward: dcos = s * dlogits (* dphi/dcos on the target column) */
+int pfr_margin_bwd(const float* cosv, const int64_t* label, int B, int C, int ldc, int mode, float s, float m,
+                   const float* dlogits, void* dcos, int dcos_dtype, pfr_stream_t stream);
 int pfr_mean(const float* x, float* out, int n, pfr_stream_t stream);
 
 /* ---- optimiser steps over flat fp32 master buffers (configs/dog_fe/fe_dogs_config.py:123-133; body_dog_fe.py:121-131) */

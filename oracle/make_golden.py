@@ -1,0 +1,252 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python modules (imported from /root/reference in the
+build container) and checks the oracle restatement against them.  Run: `python oracle/make_golden.py`.
+
+The reference tree does not exist on the GPU box: only the resulting data fixtures (inputs + expected outputs) and
+this script are committed.  What is imported / executed from the reference:
+  losses/__init__.py, losses/large_margin.py, losses/losses.py   (as-is)
+  models/swin.py                                                 (as-is)
+  engine/controller.py  Controller.test_epoch_end                (with sys.modules stubs for pytorch_lightning /
+                                                                  torchmetrics, which are not installed)
+  configs/dog_fe/fe_dogs_config.py  similarity_f                 (that one function, extracted with ast)
+"""
+import ast
+import contextlib
+import importlib.util
+import io
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import arcface_ref, match_ref, resnet_ref  # noqa: E402
+
+
+def load_ref_module(name, relpath, package_path=None):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath),
+                                                  submodule_search_locations=package_path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def ref_losses():
+    return load_ref_module("ref_losses", "losses/__init__.py", [os.path.join(REF, "losses")])
+
+
+def ref_similarity_f():
+    src = open(os.path.join(REF, "configs/dog_fe/fe_dogs_config.py")).read()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "similarity_f")
+    ns = {"torch": torch, "F": torch.nn.functional}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "fe_dogs_config.similarity_f", "exec"), ns)
+    return ns["similarity_f"]
+
+
+def ref_controller():
+    """engine/controller.py with stand-ins for the two missing third-party packages (test-side stubs only)."""
+    from sklearn.metrics import roc_auc_score, roc_curve
+
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = torch.nn.Module
+    lg = types.ModuleType("pytorch_lightning.loggers")
+    lg.MLFlowLogger = object
+    ut = types.ModuleType("pytorch_lightning.utilities")
+    ty = types.ModuleType("pytorch_lightning.utilities.types")
+    for n in ("STEP_OUTPUT", "EPOCH_OUTPUT", "TRAIN_DATALOADERS", "EVAL_DATALOADERS"):
+        setattr(ty, n, object)
+    tm = types.ModuleType("torchmetrics")
+
+    class AUROC:
+        def __call__(self, s, l):
+            return torch.tensor(roc_auc_score(l.numpy(), s.numpy()))
+
+    class ROC:
+        def __call__(self, s, l):
+            fpr, tpr, thr = roc_curve(l.numpy(), s.numpy())
+            return torch.tensor(fpr), torch.tensor(tpr), torch.tensor(thr)
+
+    tm.AUROC, tm.ROC = AUROC, ROC
+    for n in ("AveragePrecision", "Recall", "Precision", "StatScores", "Accuracy", "ConfusionMatrix"):
+        setattr(tm, n, object)
+    sys.modules.update({"pytorch_lightning": pl, "pytorch_lightning.loggers": lg, "pytorch_lightning.utilities": ut,
+                        "pytorch_lightning.utilities.types": ty, "torchmetrics": tm})
+    return load_ref_module("ref_controller", "engine/controller.py")
+
+
+def gen_arcface(L):
+    out = {}
+    g = torch.Generator().manual_seed(123)
+    cases = [("arc_hard", dict(arc_margin=True, easy_margin=False), 16, 100),
+             ("arc_easy", dict(arc_margin=True, easy_margin=True), 16, 100),
+             ("cosface", dict(arc_margin=False), 16, 100),
+             ("arc_hard_400", dict(arc_margin=True, easy_margin=False), 32, 400)]
+    for name, kw, B, C in cases:
+        for gamma in ((0,) if C > 100 else (0, 2)):
+            x = torch.randn(B, 512, generator=g)
+            label = torch.randint(0, C, (B,), generator=g)
+            wrap = L.SoftmaxBasedMetricLearning(torch.nn.Identity(), C, 512, is_focal=True, loss_kwargs=dict(gamma=gamma), **kw)
+            w = wrap.add_margin.weight.detach().clone()
+            if name == "arc_hard" and gamma == 0:
+                # edge rows: target cosine beyond the threshold cos(pi - m), and an almost-aligned pair
+                x[0] = -w[label[0]] * 3.0 + 2e-3 * torch.randn(512, generator=g)
+                x[1] = w[label[1]] * 2.0 + 1e-3 * torch.randn(512, generator=g)
+            xr = x.clone().requires_grad_(True)
+            res = wrap(xr, label)
+            res["loss"].backward()
+            key = f"{name}_g{gamma}"
+            out[key + "_x"] = x.numpy(); out[key + "_w"] = w.numpy(); out[key + "_label"] = label.numpy()
+            out[key + "_logits"] = res["logits"].detach().numpy(); out[key + "_loss"] = res["loss"].detach().numpy()
+            out[key + "_dx"] = xr.grad.numpy(); out[key + "_dw"] = wrap.add_margin.weight.grad.numpy()
+            # oracle check
+            xo = x.clone().requires_grad_(True); wo = w.clone().requires_grad_(True)
+            s, m = wrap.add_margin.s, wrap.add_margin.m
+            if kw.get("arc_margin"):
+                lo = arcface_ref.arc_margin_logits(xo, wo, label, s, m, kw.get("easy_margin", False))
+            else:
+                lo = arcface_ref.add_margin_logits(xo, wo, label, s, m)
+            loss = arcface_ref.focal_loss(lo, label, gamma)
+            loss.backward()
+            assert torch.allclose(lo, res["logits"], rtol=1e-6, atol=1e-5), key
+            assert abs(loss.item() - res["loss"].item()) < 1e-5, key
+            assert torch.allclose(xo.grad, xr.grad, rtol=1e-4, atol=1e-6), key
+            assert torch.allclose(wo.grad, wrap.add_margin.weight.grad, rtol=1e-4, atol=1e-6), key
+            out[key + "_s"] = np.float32(s); out[key + "_m"] = np.float32(m)
+    np.savez_compressed(os.path.join(OUT, "arcface.npz"), **out)
+    print("arcface.npz:", len(out), "arrays; oracle == reference")
+
+
+def gen_recall(ctrl_mod, sim_f):
+    out = {}
+    for name, N, ncls, noise, ties in [("n256", 256, 40, 1.7, False), ("n400", 400, 80, 2.1, False), ("ties", 96, 12, 1.5, True)]:
+        g = torch.Generator().manual_seed(7 + N)
+        centers = torch.randn(ncls, 512, generator=g)
+        classes = torch.randint(0, ncls, (N,), generator=g)
+        emb = centers[classes] + noise * torch.randn(N, 512, generator=g) * (512 ** 0.5) / 8
+        if ties:
+            emb[10] = emb[3]; emb[11] = emb[3]; emb[40] = 2.0 * emb[41]  # exact duplicates / colinear rows
+        idx = torch.randperm(N, generator=g)
+        pairs = [(int(a), int(b)) for a, b in torch.randint(0, N, (300, 2), generator=g).tolist()]
+        plabels = [int(classes[a] == classes[b]) for a, b in pairs]
+
+        class PG:
+            corrected_indices = pairs
+            labels = plabels
+
+        class Cfg(dict):
+            def pair_generator(self, i):
+                return "Val", PG
+
+            similarity_f = staticmethod(sim_f)
+
+            def items(self):
+                return []
+
+        c = ctrl_mod.Controller.__new__(ctrl_mod.Controller)
+        torch.nn.Module.__init__(c)
+        c.config = Cfg()
+        # outputs: List[dataloader][batch] of dicts, shuffled order, 'index' restores it (controller.py:51-56)
+        emb_s, cls_s = emb[idx], classes[idx]
+        batches = [{"emb": emb_s[i:i + 20], "label": cls_s[i:i + 20], "index": idx[i:i + 20]} for i in range(0, N, 20)]
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            c.test_epoch_end([batches])
+        txt = buf.getvalue()
+        vals = {k: float(v) for k, v in re.findall(r"Val ([^\t]+)\t([0-9.eE+-]+)", txt)}
+        ours = match_ref.recall_at_k_loop(emb, classes, (10, 100))
+        ours_m = match_ref.recall_at_k_matrix(emb, classes, (10, 100))
+        for k in (10, 100):
+            ref_ratio = vals[f"Recall@K={k}"]
+            assert abs(ours[k][0] / ours[k][1] - ref_ratio) < 1e-12 or ties, (name, k, ours[k], ref_ratio)
+            assert ours[k] == ours_m[k] or ties, (name, k, ours[k], ours_m[k])
+            out[f"{name}_recall{k}_ref"] = np.float64(ref_ratio)
+            out[f"{name}_recall{k}_counts"] = np.array(ours[k])
+        out[f"{name}_emb"] = emb.numpy().astype(np.float32); out[f"{name}_classes"] = classes.numpy()
+        out[f"{name}_auc_ref"] = np.float64(vals["ROC AUC"]); out[f"{name}_acc_ref"] = np.float64(vals["Accuracy"])
+        out[f"{name}_pairs"] = np.array(pairs); out[f"{name}_plabels"] = np.array(plabels)
+        sc = sim_f([(emb[a], emb[b]) for a, b in pairs])
+        assert torch.allclose(sc, arcface_ref.similarity_f(emb[[a for a, _ in pairs]], emb[[b for _, b in pairs]]), atol=1e-7)
+        out[f"{name}_pair_scores"] = sc.numpy()
+        print(f"recall {name}: ref R@10={vals['Recall@K=10']:.4f} R@100={vals['Recall@K=100']:.4f} counts={ours}")
+    np.savez_compressed(os.path.join(OUT, "recall.npz"), **out)
+
+
+def gen_swin():
+    ref = load_ref_module("ref_swin", "models/swin.py")
+    torch.manual_seed(1234)
+    m = ref.swin_t(num_classes=512)
+    g = torch.Generator().manual_seed(99)
+    x = torch.rand(2, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        s1 = m.stage1(x)
+        y = m(x)
+    np.savez_compressed(os.path.join(OUT, "swin_t.npz"), seed=1234, x_seed=99, emb=y.numpy(),
+                        stage1_sample=s1[:, :8, :6, :6].numpy(), n_params=sum(p.numel() for p in m.parameters()),
+                        keys=np.array(sorted(m.state_dict().keys())))
+    print("swin_t.npz: emb", tuple(y.shape))
+
+
+def gen_train_trace(L):
+    """5 SGD steps of ResNet-18 (oracle restatement; torchvision is absent) inside the REFERENCE's
+    SoftmaxBasedMetricLearning (ArcFace s=64 m=0.5 + FocalLoss γ=0), optimiser groups as fe_dogs_config.py:123-133."""
+    arch, C, B, HW = "resnet18", 100, 8, 96
+    sd = resnet_ref.init_state_dict(arch, 512, seed=5)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.ParameterDict({k.replace(".", "__"): torch.nn.Parameter(v.clone()) for k, v in sd.items()
+                                             if v.dtype.is_floating_point and "running" not in k})
+            self.stats = {k: v.clone() for k, v in sd.items() if "running" in k}
+
+        def forward(self, x):
+            cur = {k.replace("__", "."): v for k, v in self.p.items()}
+            cur.update(self.stats)
+            new = {}
+            y = resnet_ref.forward(cur, x, arch, train=True, new_stats=new)
+            self.stats.update(new)
+            return y
+
+    torch.manual_seed(11)
+    net = Net()
+    wrap = L.SoftmaxBasedMetricLearning(net, C, 512, is_focal=True, arc_margin=True)
+    w0 = wrap.add_margin.weight.detach().clone()
+    fc = [p for n, p in net.p.items() if n.startswith("fc")]
+    rest = [p for n, p in net.p.items() if not n.startswith("fc")]
+    opt = torch.optim.SGD([{"lr": 5e-3, "params": rest}, {"lr": 1e-2, "params": fc},
+                           {"lr": 1e-2, "params": wrap.add_margin.parameters(), "weight_decay": 1e-4}], 0.01, momentum=0.9)
+    g = torch.Generator().manual_seed(321)
+    x8 = torch.randint(0, 256, (5, B, 3, HW, HW), generator=g, dtype=torch.uint8)  # ToTensor(): uint8 / 255
+    xs = x8.float() / 255.0
+    ys = torch.randint(0, C, (5, B), generator=g)
+    losses, emb0 = [], None
+    for i in range(5):
+        opt.zero_grad()
+        r = wrap(xs[i], ys[i])
+        if i == 0:
+            emb0 = r["emb"].detach().clone()
+        r["loss"].backward()
+        opt.step()
+        losses.append(r["loss"].item())
+    np.savez_compressed(os.path.join(OUT, "train_trace_r18.npz"), arch=arch, C=C, B=B, HW=HW, init_seed=5, x_u8=x8.numpy(),
+                        y=ys.numpy(), head_w0=w0.numpy(), losses=np.array(losses), emb0=emb0.numpy(),
+                        rm_bn1=net.stats["bn1.running_mean"].numpy(), rv_bn1=net.stats["bn1.running_var"].numpy(),
+                        fc_bias_final=net.p["fc__bias"].detach().numpy())
+    print("train_trace_r18.npz: losses", [round(v, 5) for v in losses])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    L = ref_losses()
+    gen_arcface(L)
+    gen_recall(ref_controller(), ref_similarity_f())
+    gen_swin()
+    gen_train_trace(L)

@@ -145,16 +145,16 @@ def bn_stats(x):
     nb = lib.pfr_colreduce_blocks(C, dtype_id(x.dtype), rows)
     part = torch.empty((nb, 2, C), dtype=torch.float32, device=x.device)
     lib.pfr_bn_stats(_p(x), dtype_id(x.dtype), rows, C, _p(part), _stream())
-    return part
+    return part, lib.pfr_bn_stats_rows_per_part(C, dtype_id(x.dtype), rows)
 
 
-def bn_finalize(part, count, gamma, beta, eps, momentum, running_mean, running_var, out=None):
+def bn_finalize(part, rows_per_part, count, gamma, beta, eps, momentum, running_mean, running_var, out=None):
     """→ (mean, invstd, scale, shift) rows of a [4,C] fp32 tensor"""
     C = part.shape[-1]
     nparts = part.numel() // (2 * C)
     if out is None:
         out = torch.empty((4, C), dtype=torch.float32, device=part.device)
-    lib.pfr_bn_finalize(_p(part), nparts, C, float(count), _p(gamma), _p(beta), float(eps), float(momentum),
+    lib.pfr_bn_finalize(_p(part), nparts, int(rows_per_part), C, float(count), _p(gamma), _p(beta), float(eps), float(momentum),
                         _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream())
     return out
 
@@ -261,7 +261,7 @@ def l2norm_bwd(x, inv, dxn, out_dtype, out=None, accumulate=False):
 MARGIN_MODES = {"arc": 0, "arc_easy": 1, "cos": 2, "none": 3}
 
 
-def margin_ce(cosv, label, C, mode, s, m, gamma=0.0, grad_scale=1.0, want_logits=True, dcos_dtype=None, dcos=None,
+def margin_ce(cosv, label, C, mode, s, m, gamma=0.0, grad_scale=1.0, grad_scale_dev=None, want_logits=True, dcos_dtype=None, dcos=None,
               logits=None, loss_rows=None):
     B, ldc = cosv.shape
     assert cosv.dtype == torch.float32 and label.dtype == torch.int64
@@ -272,7 +272,7 @@ def margin_ce(cosv, label, C, mode, s, m, gamma=0.0, grad_scale=1.0, want_logits
     if dcos_dtype is not None and dcos is None:
         dcos = torch.zeros((B, ldc), dtype=dcos_dtype, device=cosv.device)
     lib.pfr_margin_ce(_p(cosv), _p(label), B, C, ldc, MARGIN_MODES[mode], float(s), float(m), float(gamma), float(grad_scale),
-                      _p(logits), _p(loss_rows), _p(dcos), PFR_F32 if dcos is None else dtype_id(dcos.dtype), _stream())
+                      _p(grad_scale_dev), _p(logits), _p(loss_rows), _p(dcos), PFR_F32 if dcos is None else dtype_id(dcos.dtype), _stream())
     return logits, loss_rows, dcos
 
 

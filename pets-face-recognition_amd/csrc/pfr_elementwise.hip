@@ -144,26 +144,56 @@ __device__ __forceinline__ void col_block_reduce(float (&v)[NQ][KP], float* lds,
   }
 }
 
-// ---- standalone batch statistics (sum, sum of squares) of an NHWC tensor → partials [gx][2][C]
+// ---- standalone batch statistics of an NHWC tensor → partials [gx][2][C] = (mean_b, M2_b) of block b's row range
+//      [b*rpb, (b+1)*rpb); sums are taken around the block's first row (shift) to avoid E[x²]−E[x]² cancellation.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, size_t rows,
-                                                       int C, int cw, int rl, int cpr) {
+                                                       int C, int cw, int rl, int cpr, size_t rpb) {
   constexpr int KP = DT<T>::KPACK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
   const int cglob = blockIdx.y * cw + col;
-  float v[2][KP];
+  const size_t rbeg = (size_t)blockIdx.x * rpb;
+  const size_t rend = rbeg + rpb < rows ? rbeg + rpb : rows;
+  float v[2][KP], k[KP];
 #pragma unroll
-  for (int e = 0; e < KP; ++e) { v[0][e] = 0.f; v[1][e] = 0.f; }
-  if (cglob < cpr) {
-    for (size_t r = (size_t)blockIdx.x * rl + rlane; r < rows; r += (size_t)gridDim.x * rl) {
+  for (int e = 0; e < KP; ++e) { v[0][e] = 0.f; v[1][e] = 0.f; k[e] = 0.f; }
+  if (cglob < cpr && rbeg < rows) {
+    Chunk<T>::unpack(ld16(x + rbeg * C + cglob * KP), k);
+    for (size_t r = rbeg + rlane; r < rend; r += rl) {
       float f[KP];
       Chunk<T>::unpack(ld16(x + r * C + cglob * KP), f);
 #pragma unroll
-      for (int e = 0; e < KP; ++e) { v[0][e] += f[e]; v[1][e] = fmaf(f[e], f[e], v[1][e]); }
+      for (int e = 0; e < KP; ++e) { const float d = f[e] - k[e]; v[0][e] += d; v[1][e] = fmaf(d, d, v[1][e]); }
     }
   }
-  col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
+  // reduce over row lanes, then convert to (mean, M2)
+  float* mine = lds + ((size_t)rlane * cw + col) * (2 * KP);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < KP; ++e) mine[q * KP + e] = v[q][e];
+  __syncthreads();
+  if (rlane == 0 && cglob < cpr) {
+    const float nt = (float)(rend > rbeg ? rend - rbeg : 1);
+    float* out_row = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < rl; ++r) {
+        a += lds[((size_t)r * cw + col) * (2 * KP) + e];
+        b += lds[((size_t)r * cw + col) * (2 * KP) + KP + e];
+      }
+      out_row[cglob * KP + e] = k[e] + a / nt;
+      out_row[(size_t)C + cglob * KP + e] = b - a * a / nt;
+    }
+  }
+}
+
+// rows handled by one partial of pfr_bn_stats
+extern "C" long pfr_bn_stats_rows_per_part(int C, int dtype, long rows) {
+  ColGeom g = col_geom(C, dtype == PFR_BF16 ? 8 : 4, (size_t)rows);
+  return (long)(((size_t)rows + g.gx - 1) / g.gx);
 }
 
 extern "C" int pfr_bn_stats(const void* x, int dtype, long rows, int C, float* part, hipStream_t st) {
@@ -171,42 +201,58 @@ extern "C" int pfr_bn_stats(const void* x, int dtype, long rows, int C, float* p
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_stats: C %% %d != 0", kp);
   ColGeom g = col_geom(C, kp, (size_t)rows);
+  const size_t rpb = ((size_t)rows + g.gx - 1) / g.gx;
   const size_t sh = (size_t)256 * 2 * kp * sizeof(float);
   if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), sh, st, (const bf16_t*)x, part, (size_t)rows, C, g.cw, g.rl, g.cpr);
+    hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), sh, st, (const bf16_t*)x, part, (size_t)rows, C, g.cw, g.rl, g.cpr, rpb);
   else
-    hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(g.gx, g.gy), dim3(256), sh, st, (const float*)x, part, (size_t)rows, C, g.cw, g.rl, g.cpr);
+    hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(g.gx, g.gy), dim3(256), sh, st, (const float*)x, part, (size_t)rows, C, g.cw, g.rl, g.cpr, rpb);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
 
-// ---- finalise: partials [nparts][2][C] → mean, invstd, scale = γ·invstd, shift = β − mean·scale, running stats
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, float count,
+// ---- finalise: partials [nparts][2][C] of (mean_t, M2_t), part t covering rows [t*rpp, min(count,(t+1)*rpp)) →
+//      mean, invstd, scale = γ·invstd, shift = β − mean·scale, running stats.  Two passes (Chan merge about the grand mean).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, long rpp, int C, float count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ mean_out,
                                                           float* __restrict__ invstd_out, float* __restrict__ scale,
                                                           float* __restrict__ shift) {
   // block: 16 channels x 16 part-lanes
-  __shared__ float l1[16][17], l2[16][17];
+  __shared__ float l1[16][17];
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
-  float a = 0.f, b = 0.f;
+  const long total = (long)count;
+  float a = 0.f;
   if (c < C)
     for (int i = pl; i < nparts; i += 16) {
-      a += part[((size_t)i * 2 + 0) * C + c];
-      b += part[((size_t)i * 2 + 1) * C + c];
+      const long left = total - (long)i * rpp;
+      const float nt = (float)(left < rpp ? left : rpp);
+      a = fmaf(nt, part[((size_t)i * 2 + 0) * C + c], a);
     }
   l1[pl][cl] = a;
-  l2[pl][cl] = b;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mean += l1[i][cl];
+  mean /= count;
+  __syncthreads();
+  float m2 = 0.f;
+  if (c < C)
+    for (int i = pl; i < nparts; i += 16) {
+      const long left = total - (long)i * rpp;
+      const float nt = (float)(left < rpp ? left : rpp);
+      const float d = part[((size_t)i * 2 + 0) * C + c] - mean;
+      m2 += part[((size_t)i * 2 + 1) * C + c] + nt * d * d;
+    }
+  l1[pl][cl] = m2;
   __syncthreads();
   if (pl == 0 && c < C) {
-    float s1 = 0.f, s2 = 0.f;
+    float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s1 += l1[i][cl]; s2 += l2[i][cl]; }
-    const float mean = s1 / count;
-    float var = s2 / count - mean * mean;  // biased batch variance
-    var = fmaxf(var, 0.f);
+    for (int i = 0; i < 16; ++i) s2 += l1[i][cl];
+    float var = fmaxf(s2 / count, 0.f);  // biased batch variance
     const float invstd = rsqrtf(var + eps);
     const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
     mean_out[c] = mean;
@@ -221,12 +267,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-extern "C" int pfr_bn_finalize(const float* part, int nparts, int C, float count, const float* gamma, const float* beta,
-                               float eps, float momentum, float* running_mean, float* running_var, float* mean,
-                               float* invstd, float* scale, float* shift, hipStream_t st) {
+extern "C" int pfr_bn_finalize(const float* part, int nparts, long rows_per_part, int C, float count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                               float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
   PFR_CHECK_ARG(part && mean && invstd && scale && shift, "pfr_bn_finalize: null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, nparts, C, count, gamma, beta, eps,
-                     momentum, running_mean, running_var, mean, invstd, scale, shift);
+  PFR_CHECK_ARG(rows_per_part > 0 && (long)nparts * rows_per_part >= (long)count, "pfr_bn_finalize: parts do not cover count");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, nparts, rows_per_part, C, count, gamma,
+                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
@@ -769,6 +816,30 @@ extern "C" int pfr_adamw_step(float* p, const float* g, float* m, float* v, void
     hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
   else
     hipLaunchKernelGGL(adamw_kernel<float>, dim3(blocks), dim3(256), 0, st, p, g, m, v, (float*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// strided 2-D fp32 copy (extracting the real channels of the channel-padded stem weight gradient)
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, size_t rows, int cols,
+                              float scale, int accumulate) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = rows * cols, stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const size_t r = i / cols;
+    const int c = (int)(i % cols);
+    const float v = src[r * lds_ + c] * scale;
+    dst[r * ldd + c] = accumulate ? dst[r * ldd + c] + v : v;
+  }
+}
+extern "C" int pfr_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long rows, int cols, float scale,
+                              int accumulate, hipStream_t st) {
+  PFR_CHECK_ARG(src && dst && rows >= 0 && cols >= 0, "pfr_copy2d_f32: bad args");
+  const size_t n = (size_t)rows * cols;
+  if (n == 0) return PFR_OK;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks), dim3(256), 0, st, src, ld_src, dst, ld_dst, (size_t)rows, cols, scale, accumulate);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

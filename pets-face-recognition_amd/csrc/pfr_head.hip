@@ -121,8 +121,10 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
 template <typename TG>
 __global__ __launch_bounds__(256) void margin_ce_kernel(const float* __restrict__ cosv, const int64_t* __restrict__ label,
                                                         MarginParams mp, float* __restrict__ logits, float* __restrict__ loss_rows,
-                                                        TG* __restrict__ dcos, int C, int ldc, float gscale) {
+                                                        TG* __restrict__ dcos, int C, int ldc, float gscale,
+                                                        const float* __restrict__ gscale_dev) {
   __shared__ float sh[4];
+  if (gscale_dev) gscale *= gscale_dev[0];
   const int row = blockIdx.x;
   const float* cr = cosv + (size_t)row * ldc;
   const int t = (int)label[row];
@@ -179,8 +181,8 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(const float* __restrict_
 }
 
 extern "C" int pfr_margin_ce(const float* cosv, const int64_t* label, int B, int C, int ldc, int mode, float s, float m,
-                             float gamma, float grad_scale, float* logits, float* loss_rows, void* dcos, int dcos_dtype,
-                             hipStream_t st) {
+                             float gamma, float grad_scale, const float* grad_scale_dev, float* logits, float* loss_rows, void* dcos,
+                             int dcos_dtype, hipStream_t st) {
   PFR_CHECK_ARG(cosv && label && B > 0 && C > 0, "pfr_margin_ce: bad args");
   PFR_CHECK_ARG(mode >= 0 && mode <= 3, "pfr_margin_ce: bad margin mode %d", mode);
   MarginParams mp;
@@ -191,9 +193,9 @@ extern "C" int pfr_margin_ce(const float* cosv, const int64_t* label, int B, int
   mp.mm = (float)(sin(M_PI - (double)m) * (double)m);
   if (ldc <= 0) ldc = C;
   if (dcos_dtype == PFR_BF16)
-    hipLaunchKernelGGL(margin_ce_kernel<bf16_t>, dim3(B), dim3(256), 0, st, cosv, label, mp, logits, loss_rows, (bf16_t*)dcos, C, ldc, grad_scale);
+    hipLaunchKernelGGL(margin_ce_kernel<bf16_t>, dim3(B), dim3(256), 0, st, cosv, label, mp, logits, loss_rows, (bf16_t*)dcos, C, ldc, grad_scale, grad_scale_dev);
   else
-    hipLaunchKernelGGL(margin_ce_kernel<float>, dim3(B), dim3(256), 0, st, cosv, label, mp, logits, loss_rows, (float*)dcos, C, ldc, grad_scale);
+    hipLaunchKernelGGL(margin_ce_kernel<float>, dim3(B), dim3(256), 0, st, cosv, label, mp, logits, loss_rows, (float*)dcos, C, ldc, grad_scale, grad_scale_dev);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
@@ -209,6 +211,46 @@ __global__ void mean_kernel(const float* __restrict__ x, float* __restrict__ out
 extern "C" int pfr_mean(const float* x, float* out, int n, hipStream_t st) {
   PFR_CHECK_ARG(x && out && n > 0, "pfr_mean: bad args");
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, x, out, n);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// standalone backward of the margin: dcos = s·dlogits (·dphi/dcos on the target column)  — used when
+// ArcMarginProduct / AddMarginProduct run as separate modules (losses/large_margin.py:30-40,69-84)
+template <typename TG>
+__global__ __launch_bounds__(256) void margin_bwd_kernel(const float* __restrict__ cosv, const int64_t* __restrict__ label,
+                                                         MarginParams mp, const float* __restrict__ dlogits,
+                                                         TG* __restrict__ dcos, int C, int ldc) {
+  const int row = blockIdx.x;
+  const int t = (int)label[row];
+  const float ct = cosv[(size_t)row * ldc + t];
+  float dphi = 1.f;
+  if (mp.mode == 0 || mp.mode == 1) {
+    const float sine = sqrtf(fmaxf(1.f - ct * ct, 0.f));
+    const float dph = mp.cos_m + (sine > 0.f ? mp.sin_m * ct / sine : 0.f);
+    const bool take = mp.mode == 1 ? (ct > 0.f) : (ct > mp.th);
+    dphi = take ? dph : 1.f;
+  }
+  for (int j = threadIdx.x; j < C; j += 256) {
+    float d = dlogits[(size_t)row * C + j] * mp.s;
+    if (j == t) d *= dphi;
+    dcos[(size_t)row * ldc + j] = from_f32<TG>(d);
+  }
+}
+extern "C" int pfr_margin_bwd(const float* cosv, const int64_t* label, int B, int C, int ldc, int mode, float s, float m,
+                              const float* dlogits, void* dcos, int dcos_dtype, hipStream_t st) {
+  PFR_CHECK_ARG(cosv && label && dlogits && dcos, "pfr_margin_bwd: null pointer");
+  MarginParams mp;
+  mp.s = s; mp.m = m; mp.mode = mode; mp.gamma = 0.f;
+  mp.cos_m = (float)cos((double)m);
+  mp.sin_m = (float)sin((double)m);
+  mp.th = (float)cos(M_PI - (double)m);
+  mp.mm = (float)(sin(M_PI - (double)m) * (double)m);
+  if (ldc <= 0) ldc = C;
+  if (dcos_dtype == PFR_BF16)
+    hipLaunchKernelGGL(margin_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, st, cosv, label, mp, dlogits, (bf16_t*)dcos, C, ldc);
+  else
+    hipLaunchKernelGGL(margin_bwd_kernel<float>, dim3(B), dim3(256), 0, st, cosv, label, mp, dlogits, (float*)dcos, C, ldc);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

@@ -26,7 +26,7 @@ struct IgemmParams {
   int R, S, OH, OW, ostride, pad, idil_log2;
   int Cout, ldy;
   int M, K;
-  float* stats_part;  // [tilesM][2][Cout] or nullptr
+  float* stats_part;  // [tilesM][2][Cout] (tile mean, tile M2) or nullptr
   const float* bias;  // [Cout] or nullptr
   int accumulate;
   const float* pro_scale;  // [C] or nullptr
@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr int RPP = 256 / CPR;                  // rows per pass
   const int oc = tid % CPR, rl = tid / CPR;
   const int co = n0 + oc * KPO;
-  float s1[KPO], s2[KPO], bia[KPO];
+  float s1[KPO], s2[KPO], bia[KPO], kshift[KPO];
+  // statistics are accumulated around a per-channel shift K (the tile's first row) so that the tile variance does not
+  // suffer the E[x²]−E[x]² cancellation; each tile publishes (mean_t, M2_t) and pfr_bn_finalize merges them (Chan).
+  Chunk<TO>::unpack(*reinterpret_cast<const u32x4*>(smem + oc * 16), kshift);
 #pragma unroll
   for (int e = 0; e < KPO; ++e) {
     s1[e] = 0.f;
@@ -254,8 +257,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     if (p.stats_part) {
 #pragma unroll
       for (int e = 0; e < KPO; ++e) {
-        s1[e] += f[e];
-        s2[e] = fmaf(f[e], f[e], s2[e]);
+        const float d = f[e] - kshift[e];
+        s1[e] += d;
+        s2[e] = fmaf(d, d, s2[e]);
       }
     }
     if (vec_ok) {
@@ -284,14 +288,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       }
     }
     __syncthreads();
-    if (tid < 2 * BP) {
-      const int which = tid / BP, ch = tid % BP;
-      if (n0 + ch < p.Cout) {
-        float a = 0.f;
+    if (tid < BP && n0 + tid < p.Cout) {
+      const int ch = tid;
+      float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) a += red[(w * 2 + which) * BP + ch];
-        p.stats_part[((size_t)tm * 2 + which) * p.Cout + n0 + ch] = a;
+      for (int w = 0; w < 4; ++w) {
+        a += red[(w * 2 + 0) * BP + ch];
+        b += red[(w * 2 + 1) * BP + ch];
       }
+      const float nt = (float)min(BQ, p.M - m0);
+      const float k = to_f32(*reinterpret_cast<const TO*>(smem + ch * (int)sizeof(TO)));
+      p.stats_part[((size_t)tm * 2 + 0) * p.Cout + n0 + ch] = k + a / nt;          // tile mean
+      p.stats_part[((size_t)tm * 2 + 1) * p.Cout + n0 + ch] = b - a * a / nt;      // tile M2 = Σ (x − mean_t)²
     }
   }
 }

@@ -1,0 +1,559 @@
+"""FEEngine — executes a ResNet feature extractor (forward, backward) on the gfx950 kernels of libpfr_hip.so.
+
+This is the MI355X counterpart of what, in the reference, is `self.module(img)` + autograd through torchvision's
+resnet (/root/reference/losses/__init__.py:38-41 called from engine/controller.py:27-29).  Design:
+
+  * parameters live in ONE flat fp32 master buffer (conv weights stored [Cout][R][S][Cin] = NHWC-friendly; the
+    nn.Parameters the reference API exposes are strided views of it, so state_dict()/optimizers/DDP see ordinary
+    tensors with torchvision names) and gradients in ONE flat fp32 buffer of the same layout → one fused optimizer
+    launch per param group, one RCCL all-reduce per bucket range;
+  * activations are NHWC in the compute dtype (bf16, or f32 for the parity path); every buffer of a step is
+    allocated once per input shape and the whole step is a pre-built list of C-ABI calls (a "plan") with fixed
+    device pointers — no allocator traffic, no autograd graph, trivially capturable in a hipGraph;
+  * BN-apply + ReLU of a conv's producer is fused into the consumer's operand prologue (the normalised activation
+    never exists in HBM), batch statistics come out of the producing conv's epilogue, the bottleneck tail
+    (BN + residual add + ReLU) is one pass, backward recomputes the ReLU masks instead of storing them.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .._hip import lib, dtype_id, PfrError
+from .._hip.ops import conv_out_hw
+
+_ALIGN = 64  # elements; keeps every parameter 16-byte aligned in both fp32 and bf16 shadows
+
+
+def default_compute_dtype():
+    v = os.environ.get("PFR_COMPUTE_DTYPE", "bf16").lower()
+    return torch.float32 if v in ("f32", "fp32", "float32") else torch.bfloat16
+
+
+class _Conv:
+    pass
+
+
+class _BN:
+    pass
+
+
+class _Plan:
+    __slots__ = ("ops", "bufs", "meta")
+
+    def __init__(self):
+        self.ops = []
+        self.bufs = {}
+        self.meta = {}
+
+    def run(self, stream, hook=None):
+        for fn, args in self.ops:
+            if fn is None:
+                if hook is not None:
+                    hook(*args)
+            else:
+                fn(*args, stream)
+
+
+class FEEngine:
+    def __init__(self, model, device, compute_dtype=None):
+        if not str(device).startswith("cuda"):
+            raise PfrError("FEEngine runs on the HIP device only (no CPU fallback)")
+        lib.pfr_version()  # fail loudly if the shared library is missing
+        self.device = torch.device(device)
+        self.dtype = compute_dtype or default_compute_dtype()
+        self.did = dtype_id(self.dtype)
+        self.kp = 8 if self.dtype == torch.bfloat16 else 4
+        self.model_id = id(model)
+        self.fc_id = id(model.fc)
+        self.plans = {}
+        self.grad_ready_hook = None     # callable(lo, hi): flat-grad range [lo, hi) is final (DDP bucket hook)
+        self.bucket_elems = 6 * 1024 * 1024
+        self._adopt(model)
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def _adopt(self, model):
+        dev = self.device
+        named = list(model.named_parameters())
+        offs, total = {}, 0
+        for name, p in named:
+            offs[name] = total
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.n_flat = total
+        self.master = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.shadow = self.master if self.dtype == torch.float32 else torch.zeros(total, dtype=self.dtype, device=dev)
+        self.offs = offs
+        self.param_list = []
+        self._views = {}
+        for name, p in named:
+            o, n = offs[name], p.numel()
+            if p.dim() == 4:
+                O, I, R, S = p.shape
+                mv = self.master[o:o + n].view(O, R, S, I)
+                mv.copy_(p.data.detach().to(dev).permute(0, 2, 3, 1))
+                pv = mv.permute(0, 3, 1, 2)
+                gv = self.grad[o:o + n].view(O, R, S, I).permute(0, 3, 1, 2)
+            else:
+                mv = self.master[o:o + n].view(p.shape)
+                mv.copy_(p.data.detach().to(dev))
+                pv = mv
+                gv = self.grad[o:o + n].view(p.shape)
+            p.data = pv
+            p.grad = None
+            self._views[name] = (p, gv)
+            self.param_list.append(p)
+        self.first_param = named[0][1]
+        # BN buffers → flat
+        bns = [(n, m) for n, m in model.named_modules() if isinstance(m, nn.BatchNorm2d)]
+        nstat = sum(m.num_features for _, m in bns)
+        self.stats = torch.zeros(2 * nstat, dtype=torch.float32, device=dev)
+        self.nbt = torch.zeros(len(bns), dtype=torch.int64, device=dev)
+        so = 0
+        self._bn_of = {}
+        for i, (n, m) in enumerate(bns):
+            C = m.num_features
+            rm = self.stats[so:so + C]
+            rv = self.stats[nstat + so:nstat + so + C]
+            rm.copy_(m.running_mean.detach().to(dev))
+            rv.copy_(m.running_var.detach().to(dev))
+            self.nbt[i] = int(m.num_batches_tracked.item())
+            m.running_mean = rm
+            m.running_var = rv
+            m.num_batches_tracked = self.nbt[i]
+            so += C
+            b = _BN()
+            b.C, b.eps, b.momentum = C, m.eps, (m.momentum if m.momentum is not None else 0.1)
+            b.gamma = self.master[offs[n + ".weight"]:offs[n + ".weight"] + C]
+            b.beta = self.master[offs[n + ".bias"]:offs[n + ".bias"] + C]
+            b.dgamma = self.grad[offs[n + ".weight"]:offs[n + ".weight"] + C]
+            b.dbeta = self.grad[offs[n + ".bias"]:offs[n + ".bias"] + C]
+            b.g_off = offs[n + ".weight"]
+            b.rm, b.rv = rm, rv
+            b.coef = torch.zeros((4, C), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+            b.bcoef = torch.zeros((3, C), dtype=torch.float32, device=dev)  # backward coefficients
+            self._bn_of[id(m)] = b
+        self.bn_list = [self._bn_of[id(m)] for _, m in bns]
+
+        # conv / fc records
+        def conv_rec(name, m):
+            c = _Conv()
+            c.name = name
+            c.Cout, c.Cin, c.R, c.S = m.weight.shape
+            c.stride, c.pad = m.stride[0], m.padding[0]
+            c.off = offs[name + ".weight"]
+            n = m.weight.numel()
+            c.w = self.shadow[c.off:c.off + n].view(c.Cout, c.R, c.S, c.Cin)
+            c.g = self.grad[c.off:c.off + n].view(c.Cout, c.R, c.S, c.Cin)
+            c.wt = torch.zeros((c.Cin, c.R, c.S, c.Cout), dtype=self.dtype, device=dev)
+            c.need_wt = True
+            return c
+
+        self._conv_of = {}
+        for n, m in model.named_modules():
+            if isinstance(m, nn.Conv2d):
+                if m.bias is not None or m.groups != 1 or m.dilation[0] != 1:
+                    raise PfrError(f"{n}: only bias-free, dense, undilated convolutions are supported")
+                self._conv_of[id(m)] = conv_rec(n, m)
+        # stem: channel-padded weight copy (3 → kp channels so that a channel chunk is 16 bytes)
+        st = self._conv_of[id(model.conv1)]
+        st.need_wt = False
+        self.cp = (st.Cin + self.kp - 1) // self.kp * self.kp
+        st.w_pad = torch.zeros((st.Cout, st.R, st.S, self.cp), dtype=self.dtype, device=dev)
+        st.g_pad = torch.zeros((st.Cout, st.R, st.S, self.cp), dtype=torch.float32, device=dev)
+        self.stem = (st, self._bn_of[id(model.bn1)])
+        # blocks
+        self.blocks = []
+        for layer in (model.layer1, model.layer2, model.layer3, model.layer4):
+            for blk in layer:
+                convs = []
+                i = 1
+                while hasattr(blk, f"conv{i}"):
+                    convs.append((self._conv_of[id(getattr(blk, f"conv{i}"))], self._bn_of[id(getattr(blk, f"bn{i}"))]))
+                    i += 1
+                down = None
+                if blk.downsample is not None:
+                    down = (self._conv_of[id(blk.downsample[0])], self._bn_of[id(blk.downsample[1])])
+                self.blocks.append((convs, down))
+        # fc
+        fc = model.fc
+        if not isinstance(fc, nn.Linear):
+            raise PfrError("model.fc must be an nn.Linear")
+        f = _Conv()
+        f.name = "fc"
+        f.Cout, f.Cin, f.R, f.S, f.stride, f.pad = fc.out_features, fc.in_features, 1, 1, 1, 0
+        f.off = offs["fc.weight"]
+        n = fc.weight.numel()
+        f.w = self.shadow[f.off:f.off + n].view(f.Cout, 1, 1, f.Cin)
+        f.g = self.grad[f.off:f.off + n].view(f.Cout, 1, 1, f.Cin)
+        f.wt = torch.zeros((f.Cin, 1, 1, f.Cout), dtype=self.dtype, device=dev)
+        f.need_wt = True
+        if fc.bias is not None:
+            bo = offs["fc.bias"]
+            f.bias = self.master[bo:bo + f.Cout]
+            f.dbias = self.grad[bo:bo + f.Cout]
+        else:
+            f.bias = f.dbias = None
+        self.fc = f
+        self.emb_dim = f.Cout
+        self.all_convs = [c for c in self._conv_of.values()] + [f]
+        # wgrad workspace (max over layers is found at plan-build time)
+        self.ws = None
+        torch.cuda.synchronize(dev)
+
+    def matches(self, model):
+        return (id(model) == self.model_id and id(model.fc) == self.fc_id
+                and self.first_param.data.data_ptr() == self.master.data_ptr())
+
+    def attach_grads(self):
+        """Point every parameter's .grad at its slice of the flat gradient buffer."""
+        for p, gv in self._views.values():
+            p.grad = gv
+
+    def flat_ranges(self, params):
+        """Contiguous [lo, hi) ranges of the flat buffers covered by `params` (for fused optimizers / buckets)."""
+        base = self.master.data_ptr()
+        spans = []
+        for p in params:
+            lo = (p.data.data_ptr() - base) // 4
+            if lo < 0 or lo >= self.n_flat:
+                raise PfrError("parameter does not belong to this engine")
+            hi = lo + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            spans.append((lo, hi))
+        spans.sort()
+        out = []
+        for lo, hi in spans:
+            if out and out[-1][1] == lo:
+                out[-1] = (out[-1][0], hi)
+            else:
+                out.append((lo, hi))
+        return out
+
+    # ------------------------------------------------------------------------------------------ weights
+    def refresh_weights(self, stream, for_backward=True):
+        """master fp32 → compute-dtype shadow, channel-padded stem weights, data-gradient weight layouts."""
+        if self.dtype != torch.float32:
+            lib.pfr_cast(self.master.data_ptr(), 0, self.shadow.data_ptr(), self.did, self.n_flat, stream)
+        st = self.stem[0]
+        lib.pfr_nchw_to_nhwc(self.master.data_ptr() + 4 * st.off, st.w_pad.data_ptr(), self.did, st.Cout * st.R * st.S,
+                             st.Cin, 1, 1, self.cp, stream)
+        if for_backward:
+            for c in self.all_convs:
+                if c.need_wt:
+                    lib.pfr_weight_dgrad_layout(c.w.data_ptr(), c.wt.data_ptr(), self.did, c.Cout, c.R, c.S, c.Cin, stream)
+
+    # ------------------------------------------------------------------------------------------ plan building
+    def _A(self, plan, shape, dtype=None):
+        t = torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
+        plan.bufs[len(plan.bufs)] = t
+        return t
+
+    def _conv_fwd(self, ops, x, xshape, w, y, c, stride, pad, OH, OW, pro=None, part=None, bias=None, idil=0,
+                  accumulate=0, Cout=None, R=None, S=None):
+        N, H, W, C = xshape
+        Cout = Cout or c.Cout
+        R = R or c.R
+        S = S or c.S
+        ps = psh = 0
+        prelu = 0
+        if pro is not None:
+            ps, psh, prelu = pro[0].data_ptr(), pro[1].data_ptr(), 1
+        ops.append((lib.pfr_conv2d_fwd, (x.data_ptr(), w.data_ptr(), y.data_ptr(), self.did, dtype_id(y.dtype), N, H, W, C,
+                                         Cout, R, S, stride, pad, idil, OH, OW, y.shape[-1],
+                                         0 if bias is None else bias.data_ptr(), accumulate, 0, ps, psh, prelu,
+                                         0 if part is None else part.data_ptr())))
+
+    def _stats_buf(self, plan, M, Cout):
+        mt = lib.pfr_conv2d_mtile(M, Cout)
+        nt = (M + mt - 1) // mt
+        return self._A(plan, (nt, 2, Cout), torch.float32), nt
+
+    def _bn_fwd(self, ops, bn, part, nparts, count, train):
+        if train:
+            ops.append((lib.pfr_bn_finalize, (part.data_ptr(), nparts, lib.pfr_conv2d_mtile(int(count), bn.C), bn.C, float(count), bn.gamma.data_ptr(),
+                                              bn.beta.data_ptr(), float(bn.eps), float(bn.momentum), bn.rm.data_ptr(),
+                                              bn.rv.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
+                                              bn.coef[2].data_ptr(), bn.coef[3].data_ptr())))
+        else:
+            ops.append((lib.pfr_bn_eval_coeff, (bn.C, bn.gamma.data_ptr(), bn.beta.data_ptr(), bn.rm.data_ptr(),
+                                                bn.rv.data_ptr(), float(bn.eps), bn.coef[2].data_ptr(),
+                                                bn.coef[3].data_ptr())))
+
+    def _conv_bn(self, plan, ops, x, xshape, c, bn, train, pro=None, w=None):
+        N, H, W, C = xshape
+        OH, OW = conv_out_hw(H, W, c.R, c.S, c.stride, c.pad)
+        y = self._A(plan, (N, OH, OW, c.Cout))
+        part, nt = (None, 0)
+        if train:
+            part, nt = self._stats_buf(plan, N * OH * OW, c.Cout)
+        self._conv_fwd(ops, x, xshape, w if w is not None else c.w, y, c, c.stride, c.pad, OH, OW, pro=pro, part=part)
+        self._bn_fwd(ops, bn, part, nt, N * OH * OW, train)
+        return y, (N, OH, OW, c.Cout)
+
+    def build_plan(self, N, H, W, train, with_backward):
+        plan = _Plan()
+        ops = plan.ops
+        T = self.dtype
+        st, stbn = self.stem
+        x_nhwc = self._A(plan, (N, H, W, self.cp))
+        plan.meta["x_nhwc"] = x_nhwc
+        saved = {}
+        # ---- stem: conv 7x7/2 → (BN+ReLU+MaxPool fused)
+        c1, s1 = self._conv_bn(plan, ops, x_nhwc, (N, H, W, self.cp), st, stbn, train, w=st.w_pad)
+        _, H1, W1, _ = s1
+        PH, PW = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        pooled = self._A(plan, (N, PH, PW, st.Cout))
+        idx = self._A(plan, (N, PH, PW, st.Cout), torch.uint8) if with_backward else None
+        ops.append((lib.pfr_bn_relu_maxpool_fwd, (c1.data_ptr(), stbn.coef[2].data_ptr(), stbn.coef[3].data_ptr(),
+                                                  pooled.data_ptr(), 0 if idx is None else idx.data_ptr(), self.did, N, H1,
+                                                  W1, st.Cout, 1)))
+        saved["stem"] = (c1, s1, idx, (N, PH, PW, st.Cout))
+        cur, cshape = pooled, (N, PH, PW, st.Cout)
+        # ---- residual blocks
+        bsaved = []
+        for convs, down in self.blocks:
+            xin, xshape = cur, cshape
+            raws = []
+            pro = None
+            src, sshape = xin, xshape
+            for (c, bn) in convs:
+                y, yshape = self._conv_bn(plan, ops, src, sshape, c, bn, train, pro=pro)
+                raws.append((y, yshape))
+                pro = (bn.coef[2], bn.coef[3])
+                src, sshape = y, yshape
+            lastc, lastbn = convs[-1]
+            out = self._A(plan, sshape)
+            rows = sshape[0] * sshape[1] * sshape[2]
+            cd = None
+            if down is not None:
+                dc, dbn = down
+                cd, _ = self._conv_bn(plan, ops, xin, xshape, dc, dbn, train)
+                ops.append((lib.pfr_bn_act, (src.data_ptr(), lastbn.coef[2].data_ptr(), lastbn.coef[3].data_ptr(),
+                                             cd.data_ptr(), dbn.coef[2].data_ptr(), dbn.coef[3].data_ptr(), out.data_ptr(),
+                                             self.did, rows, sshape[3], 1)))
+            else:
+                ops.append((lib.pfr_bn_act, (src.data_ptr(), lastbn.coef[2].data_ptr(), lastbn.coef[3].data_ptr(),
+                                             xin.data_ptr(), 0, 0, out.data_ptr(), self.did, rows, sshape[3], 1)))
+            bsaved.append((xin, xshape, raws, cd, out, sshape))
+            cur, cshape = out, sshape
+        # ---- global average pool + fc
+        Nn, Hh, Ww, Cf = cshape
+        gap = self._A(plan, (N, Cf))
+        ops.append((lib.pfr_avgpool_fwd, (cur.data_ptr(), gap.data_ptr(), self.did, N, Hh * Ww, Cf)))
+        emb = self._A(plan, (N, self.emb_dim), torch.float32)
+        f = self.fc
+        self._conv_fwd(ops, gap, (N, 1, 1, Cf), f.w, emb, f, 1, 0, 1, 1, bias=f.bias)
+        plan.meta["emb"] = emb
+        plan.meta["n_fwd"] = len(ops)
+        if not with_backward:
+            return plan
+
+        # =================================================================== backward (appended after n_fwd)
+        pool = {}
+
+        def G(shape, dtype=None):
+            key = (tuple(shape), dtype or T)
+            lst = pool.setdefault(key, [])
+            if lst:
+                return lst.pop()
+            return self._A(plan, shape, dtype)
+
+        def release(t):
+            pool.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+        ws_need = [0]
+
+        def wgrad(x, xshape, dy, dyshape, c, pro=None, out=None, C=None, acc=0):
+            Nq, Hq, Wq, Cq = xshape
+            _, OH, OW, Co = dyshape
+            KK = c.R * c.S * Cq
+            splits = lib.pfr_conv2d_wgrad_splits(Nq * OH * OW, Co, KK)
+            ws_need[0] = max(ws_need[0], splits * Co * KK)
+            ps = psh = 0
+            prelu = 0
+            if pro is not None:
+                ps, psh, prelu = pro[0].data_ptr(), pro[1].data_ptr(), 1
+            dst = out if out is not None else c.g
+            ops.append(("wgrad_noacc" if out is not None else "wgrad", (x.data_ptr(), dy.data_ptr(), dst.data_ptr(), None, self.did, Nq, Hq, Wq, Cq, Co, c.R, c.S,
+                                  c.stride, c.pad, OH, OW, Co, ps, psh, prelu, 1.0, acc)))
+
+        def dgrad(dy, dyshape, c, dx, dxshape, accumulate=0):
+            log2 = {1: 0, 2: 1}[c.stride]
+            self._conv_fwd(ops, dy, dyshape, c.wt, dx, c, 1, c.R - 1 - c.pad, dxshape[1], dxshape[2], idil=log2,
+                           accumulate=accumulate, Cout=c.Cin)
+
+        def bn_bwd(dout, out_act, x, xshape, bn, mask_mode, dx, gres, acc):
+            rows = xshape[0] * xshape[1] * xshape[2]
+            C = xshape[3]
+            nb = lib.pfr_colreduce_blocks(C, self.did, rows)
+            part = G((nb, 2, C), torch.float32)
+            oa = 0 if out_act is None else out_act.data_ptr()
+            ops.append((lib.pfr_bn_bwd_reduce, (dout.data_ptr(), oa, x.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
+                                                bn.coef[2].data_ptr(), bn.coef[3].data_ptr(), mask_mode, self.did, rows, C,
+                                                part.data_ptr())))
+            ops.append((lib.pfr_bn_bwd_finalize, (part.data_ptr(), nb, C, float(rows), bn.gamma.data_ptr(), bn.coef[0].data_ptr(),
+                                                  bn.coef[1].data_ptr(), bn.dgamma.data_ptr(), bn.dbeta.data_ptr(),
+                                                  bn.bcoef.data_ptr(), acc)))
+            ops.append((lib.pfr_bn_bwd_apply, (dout.data_ptr(), oa, x.data_ptr(), bn.bcoef.data_ptr(), bn.coef[2].data_ptr(),
+                                               bn.coef[3].data_ptr(), mask_mode, dx.data_ptr(),
+                                               0 if gres is None else gres.data_ptr(), self.did, rows, C)))
+            release(part)
+
+        acc = 0  # placeholder: _finalize_plan emits an overwrite (0) and an accumulate (1) variant of every grad write
+        # fc
+        demb = self._A(plan, (N, self.emb_dim))
+        plan.meta["demb"] = demb
+        if f.dbias is not None:
+            ops.append(("colsum", (demb.data_ptr(), self.did, N, self.emb_dim, f.dbias.data_ptr(), acc)))
+        wgrad(gap, (N, 1, 1, Cf), demb, (N, 1, 1, self.emb_dim), f)
+        dgap = G((N, Cf))
+        dgrad(demb, (N, 1, 1, self.emb_dim), f, dgap, (N, 1, 1, Cf))
+        self._mark(ops, f.off)
+        dcur = G(cshape)
+        ops.append((lib.pfr_avgpool_bwd, (dgap.data_ptr(), dcur.data_ptr(), self.did, N, Hh * Ww, Cf)))
+        release(dgap)
+        # blocks in reverse
+        for (convs, down), (xin, xshape, raws, cd, out, oshape) in zip(reversed(self.blocks), reversed(bsaved)):
+            lastc, lastbn = convs[-1]
+            ylast, _ = raws[-1]
+            gres = G(oshape)
+            # BN(last) + residual + ReLU backward; dx in place over dcur
+            bn_bwd(dcur, out, ylast, oshape, lastbn, 1, dcur, gres, acc)
+            dy, dyshape = dcur, oshape
+            for i in range(len(convs) - 1, 0, -1):
+                c, bn = convs[i]
+                pc, pbn = convs[i - 1]
+                xraw, xrs = raws[i - 1]
+                wgrad(xraw, xrs, dy, dyshape, c, pro=(pbn.coef[2], pbn.coef[3]))
+                dz = G(xrs)
+                dgrad(dy, dyshape, c, dz, xrs)
+                release(dy)
+                bn_bwd(dz, None, xraw, xrs, pbn, 2, dz, None, acc)
+                dy, dyshape = dz, xrs
+            c0, bn0 = convs[0]
+            wgrad(xin, xshape, dy, dyshape, c0)
+            if down is not None:
+                dc, dbn = down
+                bn_bwd(gres, None, cd, oshape, dbn, 0, gres, None, acc)
+                wgrad(xin, xshape, gres, oshape, dc)
+                dxin = G(xshape)
+                dgrad(gres, oshape, dc, dxin, xshape)
+                release(gres)
+            else:
+                dxin = gres
+            dgrad(dy, dyshape, c0, dxin, xshape, accumulate=1)
+            self._mark(ops, c0.off)  # conv1.weight is the block's first parameter: flat grads [c0.off, end) are final
+            release(dy)
+            dcur = dxin
+        # stem
+        c1, s1, idx, pshape = saved["stem"]
+        dz = G(s1)
+        ops.append((lib.pfr_maxpool_bwd, (dcur.data_ptr(), idx.data_ptr(), dz.data_ptr(), self.did, N, s1[1], s1[2], s1[3])))
+        release(dcur)
+        bn_bwd(dz, None, c1, s1, stbn, 2, dz, None, acc)
+        wgrad(x_nhwc, (N, H, W, self.cp), dz, s1, st, out=st.g_pad)
+        ops.append(("copy2d", (st.g_pad.data_ptr(), self.cp, st.g.data_ptr(), st.Cin, st.Cout * st.R * st.S, st.Cin, 1.0, acc)))
+        self._mark(ops, 0)
+        # workspace
+        if self.ws is None or self.ws.numel() < ws_need[0]:
+            self.ws = torch.empty(ws_need[0], dtype=torch.float32, device=self.device)
+        plan.meta["ws_need"] = ws_need[0]
+        return plan
+
+    def _mark(self, ops, off):
+        ops.append((None, (off,)))
+
+    # ------------------------------------------------------------------------------------------ execution
+    def get_plan(self, N, H, W, train, with_backward):
+        key = (N, H, W, train, with_backward)
+        p = self.plans.get(key)
+        if p is None:
+            if len(self.plans) >= 6:
+                self.plans.pop(next(iter(self.plans)))
+            p = self.build_plan(N, H, W, train, with_backward)
+            self._finalize_plan(p)
+            self.plans[key] = p
+        return p
+
+    def _finalize_plan(self, plan):
+        """Resolve symbolic ops (workspace pointer, accumulate flag) into two concrete op lists."""
+        fwd = plan.ops[:plan.meta["n_fwd"]]
+        bwd = plan.ops[plan.meta["n_fwd"]:]
+        plan.meta["fwd"] = fwd
+        for acc in (0, 1):
+            res = []
+            for fn, args in bwd:
+                if fn in ("wgrad", "wgrad_noacc"):
+                    a = list(args)
+                    a[3] = self.ws.data_ptr()
+                    a[-1] = acc if fn == "wgrad" else 0
+                    res.append((lib.pfr_conv2d_wgrad, tuple(a)))
+                elif fn == "colsum":
+                    res.append((lib.pfr_colsum, tuple(args[:-1]) + (acc,)))
+                elif fn == "copy2d":
+                    res.append((lib.pfr_copy2d_f32, tuple(args[:-1]) + (acc,)))
+                elif fn is lib.pfr_bn_bwd_finalize:
+                    res.append((fn, tuple(args[:-1]) + (acc,)))
+                else:
+                    res.append((fn, args))
+            plan.meta["bwd%d" % acc] = res
+        plan.meta["ws_ptr"] = self.ws.data_ptr() if self.ws is not None else 0
+
+    def forward(self, x, train, with_backward):
+        if x.dim() != 4 or x.shape[1] != self.stem[0].Cin:
+            raise PfrError(f"expected NCHW input with {self.stem[0].Cin} channels, got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        plan = self.get_plan(N, H, W, train, with_backward)
+        if with_backward and plan.meta.get("ws_ptr", 0) != (self.ws.data_ptr() if self.ws is not None else 0):
+            self._finalize_plan(plan)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh_weights(stream, for_backward=with_backward)
+        lib.pfr_nchw_to_nhwc(x.data_ptr(), plan.meta["x_nhwc"].data_ptr(), self.did, N, x.shape[1], H, W, self.cp, stream)
+        for fn, args in plan.meta["fwd"]:
+            fn(*args, stream)
+        if train:
+            self.nbt.add_(1)
+        self._last_plan = plan
+        return plan.meta["emb"]
+
+    def backward(self, demb):
+        plan = self._last_plan
+        stream = torch.cuda.current_stream().cuda_stream
+        demb = demb.contiguous()
+        lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan.meta["demb"].data_ptr(), self.did, demb.numel(), stream)
+        acc = 1 if self.first_param.grad is not None else 0
+        hook = self.grad_ready_hook
+        for fn, args in plan.meta["bwd%d" % acc]:
+            if fn is None:
+                if hook is not None:
+                    hook(args[0])
+            else:
+                fn(*args, stream)
+        if not acc:
+            self.attach_grads()
+
+
+class _FEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        eng = model.hip_engine(x.device)
+        emb = eng.forward(x, model.training, True)  # only reached when a backward pass can follow (see fe_forward)
+        ctx.eng = eng
+        ctx.nparams = len(params)
+        return emb.clone()
+
+    @staticmethod
+    def backward(ctx, demb):
+        ctx.eng.backward(demb)
+        # parameter gradients are delivered by side effect into the flat gradient buffer (p.grad views)
+        return (None, None) + (None,) * ctx.nparams
+
+
+def fe_forward(model, x):
+    eng = model.hip_engine(x.device)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in eng.param_list):
+        return _FEFunction.apply(x, model, *eng.param_list)
+    return eng.forward(x, model.training, False).clone()

@@ -67,11 +67,14 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     assert yd.shape == yr.shape
     e = rel_err(yd.cpu(), yr)
     assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), f"fwd rel err {e}"
-    # fused per-channel statistics of the stored output
-    s = part.sum(0).cpu()
-    ydf = yd.float().cpu().reshape(-1, Cout)
-    assert torch.allclose(s[0], ydf.sum(0), rtol=1e-3, atol=1e-2)
-    assert torch.allclose(s[1], (ydf * ydf).sum(0), rtol=1e-3, atol=1e-2)
+    # fused per-channel statistics (per-m-tile mean / M2, merged by pfr_bn_finalize) of the stored output
+    from pets_face_recognition_amd._hip import lib
+    M = yd.numel() // Cout
+    coef = o.bn_finalize(part, lib.pfr_conv2d_mtile(M, Cout), M, None, None, 1e-5, 0.1, None, None)
+    torch.cuda.synchronize()
+    ydf = yd.double().cpu().reshape(-1, Cout)
+    assert torch.allclose(coef[0].cpu().double(), ydf.mean(0), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(coef[1].cpu().double(), 1.0 / torch.sqrt(ydf.var(0, unbiased=False) + 1e-5), rtol=1e-4, atol=1e-5)
 
     dyd = nhwc(dy).to(DEV, dtype)
     wt = o.weight_dgrad_layout(wd)
@@ -171,9 +174,9 @@ def test_batchnorm_train_fwd_bwd(dtype, C):
     y.backward(dy)
 
     xd, resd = nhwc(x.detach()).to(DEV, dtype), nhwc(res.detach()).to(DEV, dtype)
-    part = o.bn_stats(xd)
+    part, rpp = o.bn_stats(xd)
     rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-    coef = o.bn_finalize(part, N * H * W, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rmd, rvd)
+    coef = o.bn_finalize(part, rpp, N * H * W, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rmd, rvd)
     yd = o.bn_act(xd, coef[2], coef[3], x2=resd, relu=True)
     torch.cuda.synchronize()
     t = tol(dtype)

@@ -1,0 +1,190 @@
+"""End-to-end parity of the HIP feature-extractor path against the CPU oracle (oracle/) and the golden fixtures
+generated from the reference (tests/golden/, see oracle/make_golden.py).  Tolerances: fp32 path embeddings within
+1e-3 relative (north_star); bf16 deviation is measured and bounded separately."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def build(arch, dtype, sd):
+    import pets_face_recognition_amd.models as M
+    m = getattr(M, arch)(compute_dtype=dtype)
+    m.fc = torch.nn.Linear(m.fc.in_features, 512)
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("arch,dtype,tol_emb,grad_factor", [
+    ("resnet18", torch.float32, 1e-3, 3.0),
+    ("resnet50", torch.float32, 1e-3, 3.0),
+    ("resnet18", torch.bfloat16, 4e-2, None),
+    ("resnet50", torch.bfloat16, 4e-2, None),
+])
+def test_backbone_fwd_bwd_vs_oracle(arch, dtype, tol_emb, grad_factor):
+    """Embeddings: HIP vs the fp32 CPU oracle within 1e-3 relative (fp32 path).  Gradients of a randomly initialised
+    50-layer train-mode-BN network are ill-conditioned (the fp32 CPU oracle itself is ~2e-2 away from an fp64 run of
+    the same restatement), so the gradient criterion is: HIP-vs-fp64 error <= 3x the CPU-fp32-vs-fp64 error + 1e-3."""
+    from oracle import resnet_ref
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = resnet_ref.init_state_dict(arch, 512, seed=3)
+    if dtype == torch.bfloat16:
+        # A randomly initialised ResNet with unit residual gains amplifies ANY perturbation ~1.5x per block (two bf16
+        # evaluations that differ only in summation order end up 26 % apart after 16 blocks), so the bf16 end-to-end
+        # check uses damped residual branches (last-BN gain 0.2, the usual zero-init-residual practice).
+        last = ".bn3.weight" if arch == "resnet50" else ".bn2.weight"
+        for k in sd:
+            if k.startswith("layer") and k.endswith(last):
+                sd[k] = torch.full_like(sd[k], 0.2)
+    g = torch.Generator().manual_seed(17)
+    N, HW = 6, 64
+    x = torch.rand(N, 3, HW, HW, generator=g)
+    demb = torch.randn(N, 512, generator=g) * 0.05
+    names = resnet_ref.param_names(sd)
+    ps = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd.items()}
+    new = {}
+    emb_ref = resnet_ref.forward(ps, x, arch, train=True, new_stats=new)
+    emb_ref.backward(demb)
+    p64 = {k: (v.double().requires_grad_(True) if k in names else (v.double() if v.dtype.is_floating_point else v.clone()))
+           for k, v in sd.items()}
+    resnet_ref.forward(p64, x.double(), arch, train=True).backward(demb.double())
+    # HIP
+    m = build(arch, dtype, sd)
+    m.train()
+    emb = m(x.to(DEV))
+    emb.backward(demb.to(DEV))
+    torch.cuda.synchronize()
+    e = rel(emb, emb_ref)
+    assert e < tol_emb, f"embedding rel err {e}"
+    if dtype == torch.bfloat16:
+        # against the oracle with bf16 rounding emulated at the path's storage points the agreement is much tighter
+        with torch.no_grad():
+            emb_q = resnet_ref.forward(sd, x, arch, train=True, quant=resnet_ref.bf16_round)
+        eq = rel(emb, emb_q)
+        assert eq < 1.5e-2, f"embedding rel err vs bf16-emulating oracle {eq}"
+    got = m.state_dict()
+    assert rel(got["bn1.running_mean"], new["bn1.running_mean"]) < 5 * tol_emb
+    assert rel(got["layer4.1.bn2.running_var"], new["layer4.1.bn2.running_var"]) < 5 * tol_emb
+    assert int(got["bn1.num_batches_tracked"].item()) == 1
+    worst = ("", 0.0, 0.0)
+    cos_min = 1.0
+    flat_h, flat_r = [], []
+    for name, p in m.named_parameters():
+        assert p.grad is not None, name
+        g64 = p64[name].grad
+        eh = ((p.grad.double().cpu() - g64).norm() / (g64.norm() + 1e-30)).item()
+        ec = ((ps[name].grad.double() - g64).norm() / (g64.norm() + 1e-30)).item()
+        cs = torch.nn.functional.cosine_similarity(p.grad.double().cpu().flatten(), g64.flatten(), dim=0).item()
+        cos_min = min(cos_min, cs)
+        flat_h.append(p.grad.double().cpu().flatten())
+        flat_r.append(g64.flatten())
+        if grad_factor is not None and eh > grad_factor * ec + 1e-3 and eh > worst[1]:
+            worst = (name, eh, ec)
+    assert worst[1] == 0.0, f"gradient error above the fp32 conditioning floor: {worst}"
+    cos_all = torch.nn.functional.cosine_similarity(torch.cat(flat_h), torch.cat(flat_r), dim=0).item()
+    # bf16: an fp32 backward through a forward with bf16-rounded activations (oracle quant=bf16_round, i.e. what any
+    # bf16-activation training does) is itself at cos 0.93 (R50) / 0.98 (R18) to the fp64 gradient — measured with
+    # tools/diag_bf16grad.py; the HIP bf16 path sits at the same distance, so the bound below is that floor.
+    assert cos_all > (0.9999 if dtype == torch.float32 else 0.9), f"whole-gradient cosine similarity {cos_all}"
+    assert cos_min > (0.999 if dtype == torch.float32 else 0.4), f"min per-parameter gradient cosine similarity {cos_min}"
+    # eval mode uses the running statistics
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.to(DEV))
+    ps2 = {k: v.detach() for k, v in ps.items()}
+    ps2.update(new)
+    ev_ref = resnet_ref.forward(ps2, x, arch, train=False)
+    assert rel(ev, ev_ref) < tol_emb
+
+
+def test_fused_head_vs_reference_golden():
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    G = np.load(os.path.join(GOLD, "arcface.npz"))
+    for name, kw in [("arc_hard", dict(arc_margin=True)), ("arc_easy", dict(arc_margin=True, easy_margin=True)),
+                     ("cosface", dict(arc_margin=False)), ("arc_hard_400", dict(arc_margin=True))]:
+        for gamma in (0, 2):
+            key = f"{name}_g{gamma}"
+            if key + "_x" not in G:
+                continue
+            x = torch.tensor(G[key + "_x"]).to(DEV).requires_grad_(True)
+            label = torch.tensor(G[key + "_label"]).to(DEV)
+            C = G[key + "_w"].shape[0]
+            wrap = SoftmaxBasedMetricLearning(torch.nn.Identity(), C, 512, is_focal=True, loss_kwargs=dict(gamma=gamma), **kw)
+            wrap.add_margin.compute_dtype = torch.float32
+            wrap = wrap.to(DEV)
+            with torch.no_grad():
+                wrap.add_margin.weight.copy_(torch.tensor(G[key + "_w"]))
+            r = wrap(x, label)
+            r["loss"].backward()
+            torch.cuda.synchronize()
+            assert torch.allclose(r["logits"].cpu(), torch.tensor(G[key + "_logits"]), rtol=1e-4, atol=2e-3), key
+            assert abs(r["loss"].item() - float(G[key + "_loss"])) < 1e-4 * max(1, abs(float(G[key + "_loss"]))), key
+            assert rel(x.grad, torch.tensor(G[key + "_dx"])) < 1e-3, key
+            assert rel(wrap.add_margin.weight.grad, torch.tensor(G[key + "_dw"])) < 1e-3, key
+    # modular (unfused) path: standalone ArcMarginProduct + FocalLoss modules
+    from pets_face_recognition_amd.losses import ArcMarginProduct, FocalLoss
+    key = "arc_hard_g2"
+    head = ArcMarginProduct(512, G[key + "_w"].shape[0], s=float(G[key + "_s"]), m=float(G[key + "_m"])).to(DEV)
+    head.compute_dtype = torch.float32
+    with torch.no_grad():
+        head.weight.copy_(torch.tensor(G[key + "_w"]))
+    x = torch.tensor(G[key + "_x"]).to(DEV).requires_grad_(True)
+    label = torch.tensor(G[key + "_label"]).to(DEV)
+    logits = head(x, label)
+    loss = FocalLoss(100, gamma=2)(logits, label)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(G[key + "_loss"])) < 1e-4 * abs(float(G[key + "_loss"]))
+    assert rel(x.grad, torch.tensor(G[key + "_dx"])) < 1e-3
+    assert rel(head.weight.grad, torch.tensor(G[key + "_dw"])) < 1e-3
+
+
+def test_train_trace_r18_vs_reference_golden():
+    """5 optimizer steps (fp32 path): loss trace of ResNet-18 + ArcFace + SGD groups must follow the trace captured
+    from the reference's SoftmaxBasedMetricLearning (oracle/make_golden.py:gen_train_trace)."""
+    from oracle import resnet_ref
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    from pets_face_recognition_amd.optim import FusedSGD
+    G = np.load(os.path.join(GOLD, "train_trace_r18.npz"))
+    sd = resnet_ref.init_state_dict("resnet18", 512, seed=int(G["init_seed"]))
+    m = build("resnet18", torch.float32, sd)
+    wrap = SoftmaxBasedMetricLearning(m, int(G["C"]), 512, is_focal=True, arc_margin=True).to(DEV)
+    wrap.add_margin.compute_dtype = torch.float32
+    with torch.no_grad():
+        wrap.add_margin.weight.copy_(torch.tensor(G["head_w0"]))
+    wrap.train()
+    p1 = [p for n, p in wrap.module.named_parameters() if "fc" not in n]
+    p2 = [p for n, p in wrap.module.named_parameters() if "fc" in n]
+    opt = FusedSGD([{"lr": 5e-3, "params": p1}, {"lr": 1e-2, "params": p2},
+                    {"lr": 1e-2, "params": wrap.add_margin.parameters(), "weight_decay": 1e-4}], 0.01, momentum=0.9)
+    xs = torch.tensor(G["x_u8"]).float() / 255.0
+    ys = torch.tensor(G["y"])
+    losses = []
+    for i in range(5):
+        opt.zero_grad()
+        r = wrap(xs[i].to(DEV), ys[i].to(DEV))
+        if i == 0:
+            assert rel(r["emb"], torch.tensor(G["emb0"])) < 1e-3
+        r["loss"].backward()
+        opt.step()
+        losses.append(r["loss"].item())
+    ref = G["losses"]
+    # rounding differences are amplified ~7x per step by the training dynamics of this random-init net (conditioning,
+    # see test_backbone_fwd_bwd_vs_oracle), hence the widening tolerance; steps 1-3 pin forward, backward and the
+    # momentum / weight-decay / per-group-lr update.
+    for got_l, ref_l, tol in zip(losses, ref, [1e-5, 1e-4, 1e-3, 1e-2, 3e-2]):
+        assert abs(got_l - ref_l) <= tol * abs(ref_l), (losses, ref.tolist())
+    got = wrap.module.state_dict()
+    # after 5 ill-conditioned steps (see test_backbone_fwd_bwd_vs_oracle) the weights agree to a few per cent
+    assert rel(got["bn1.running_mean"], torch.tensor(G["rm_bn1"])) < 0.15
+    assert rel(got["fc.bias"], torch.tensor(G["fc_bias_final"])) < 0.15
