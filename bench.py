@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py — FE train images/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = forward + backward + optimizer (+ gradient all-reduce when N > 1) of ResNet-50 → ArcFace(10 000 ids) on a
+synthetic 224x224x3 batch of 256 images per GPU that is already resident in HBM (BASELINE.json configs[1] / [2]).
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every kernel launch of extra,
+instrumented steps after the timed region; `cpu_baseline` times the oracle restatement of the reference path
+(PyTorch-CPU fp32) on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work (SURVEY.md §8d / BASELINE.md §2): conv MACs per image, forward
+CONV_GMAC = {"resnet50": 4.0871, "resnet18": 1.8136}
+CONV1_GMAC = 0.1180
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_flops_per_img(arch):
+    # fwd + dgrad + wgrad of every conv; the stem has no data gradient
+    return 2.0 * (3.0 * CONV_GMAC[arch] - CONV1_GMAC) * 1e9
+
+
+def build(args, device):
+    import pets_face_recognition_amd.models as M
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    from pets_face_recognition_amd.optim import FusedSGD
+
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(123)
+    backbone = getattr(M, args.arch)(compute_dtype=dt)
+    backbone.fc = torch.nn.Linear(backbone.fc.in_features, 512)
+    ml = SoftmaxBasedMetricLearning(backbone, args.classes, 512, is_focal=True, arc_margin=True)
+    ml.add_margin.compute_dtype = dt
+    ml.return_logits = True
+    ml = ml.to(device)
+    ml.train()
+    backbone.hip_engine(device)  # adopt parameters into the flat buffers before the optimizer captures them
+    p1 = [p for n, p in ml.module.named_parameters() if "fc" not in n]
+    p2 = [p for n, p in ml.module.named_parameters() if "fc" in n]
+    # optimizer groups of the reference recipe (configs/dog_fe/fe_dogs_config.py:123-133)
+    opt = FusedSGD([{"lr": 5e-3, "params": p1}, {"lr": 1e-2, "params": p2},
+                    {"lr": 1e-2, "params": ml.add_margin.parameters(), "weight_decay": 1e-4}], 0.01, momentum=0.9)
+    return ml, opt
+
+
+def cpu_baseline(args):
+    """The reference path restated on PyTorch-CPU (oracle/), timed on the host cores on a bounded sample."""
+    from oracle import resnet_ref, arcface_ref
+    nthreads = min(64, os.cpu_count() or 1)   # more threads than this only adds contention on the 2x64-core host
+    torch.set_num_threads(nthreads)
+    B = args.cpu_batch
+    sd = resnet_ref.init_state_dict(args.arch, 512, seed=0)
+    names = resnet_ref.param_names(sd)
+    ps = {k: (v.requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(123)
+    w = (torch.randn(args.classes, 512, generator=g) * 0.02).requires_grad_(True)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, args.classes, (B,), generator=g)
+    params = [ps[k] for k in names] + [w]
+    opt = torch.optim.SGD(params, 0.01, momentum=0.9)
+
+    def step():
+        opt.zero_grad()
+        emb = resnet_ref.forward(ps, x, args.arch, train=True)
+        loss = arcface_ref.focal_loss(arcface_ref.arc_margin_logits(emb, w, y, 64.0, 0.5), y)
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < 12 and n < 10):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": nthreads, "kind": "port",
+            "sample": f"{n} train steps of {args.arch}+ArcFace(C={args.classes}) at bs={B}, PyTorch-CPU fp32 oracle "
+                      f"restatement (torchvision absent), {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--classes", type=int, default=10000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    ml, opt = build(args, device)
+    ddp = None
+    if world > 1:
+        from pets_face_recognition_amd.engine import FlatDDP
+        ddp = FlatDDP(ml)
+
+    g = torch.Generator(device="cpu").manual_seed(123 + rank)
+    x = torch.rand(args.batch, 3, 224, 224, generator=g).to(device)
+    y = torch.randint(0, args.classes, (args.batch,), generator=g).to(device)
+
+    def step():
+        opt.zero_grad()
+        out = ml(x, y)
+        out["loss"].backward()
+        if ddp is not None:
+            ddp.finish_backward()
+        opt.step()
+        return out["loss"]
+
+    for _ in range(args.warmup):
+        loss = step()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss.item())
+    ms = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        from pets_face_recognition_amd._hip import set_tracer, EventTracer
+        tr = EventTracer()
+        nprof = 3
+        torch.cuda.synchronize()
+        set_tracer(tr)
+        for _ in range(nprof):
+            opt.zero_grad()
+            out = ml(x, y)
+            out["loss"].backward()
+            opt.step()
+        set_tracer(None)
+        summ = tr.summary()
+        conv_ms = sum(v[1] for k, v in summ.items() if k in ("pfr_conv2d_fwd", "pfr_conv2d_wgrad")) / nprof
+        total_ms = sum(v[1] for v in summ.values()) / nprof
+        flops = conv_flops_per_img(args.arch) * args.batch
+        ach = flops / (conv_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        roof = {"bound": "mfma", "kernel": "igemm_kernel + wgrad_kernel (all conv/linear launches of a step)",
+                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(total_ms, 3),
+                "whole_step_frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
+                "by_entry_point_ms": {k: round(v[1] / nprof, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
+    if dist is not None and world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        line = {"metric": "FE train images/sec @224^2 bs=256/GPU", "value": round(value, 1), "unit": "images/sec",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"{args.arch} FE + ArcFace(s=64,m=0.5) + CE, {args.classes} ids, 224x224x3, "
+                                       f"fwd+bwd+SGD(momentum 0.9, 3 param groups)", "global_batch": args.batch * world,
+                           "per_gpu_batch": args.batch, "parallelism": f"dp{world}", "loss": round(final_loss, 4)},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,9 +79,10 @@ int pfr_bn_stats(const void* x, int dtype, long rows, int C, float* part, pfr_st
 long pfr_bn_stats_rows_per_part(int C, int dtype, long rows);
 /* part: [nparts][2][C] = (mean_t, M2_t) of rows [t*rows_per_part, min(count, (t+1)*rows_per_part)) — written by
  * pfr_conv2d_fwd (rows_per_part = pfr_conv2d_mtile) or pfr_bn_stats (rows_per_part = pfr_bn_stats_rows_per_part). */
+long pfr_bn_finalize_ws_floats(int nparts, int C); /* scratch floats for a parallel two-level merge (0: not needed) */
 int pfr_bn_finalize(const float* part, int nparts, long rows_per_part, int C, float count, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
-                    float* invstd, float* scale, float* shift, pfr_stream_t stream);
+                    float* invstd, float* scale, float* shift, float* workspace, pfr_stream_t stream);
 int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, pfr_stream_t stream);
 /* y = relu?( a1*x1 + b1 (+ a2*x2 + b2 | + x2) ): BN apply, ReLU and the residual add of a bottleneck in one pass */

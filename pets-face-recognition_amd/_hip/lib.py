@@ -73,6 +73,8 @@ class _Lib:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"(or pets-face-recognition_amd/csrc/build.sh). There is no CPU/PyTorch fallback for the HIP path."
             )
+        # torch first: its bundled HIP runtime must be the one this process uses (one runtime, shared streams)
+        import torch  # noqa: F401
         self._dll = ctypes.CDLL(LIB_PATH)
         self._protos = parse_header()
         for name, (restype, argtypes, _names) in self._protos.items():
@@ -92,7 +94,12 @@ class _Lib:
         fn = getattr(self._dll, name)
         if self._protos[name][0] is ctypes.c_int and name not in _NO_CHECK:
             def checked(*args, _fn=fn, _name=name):
+                tr = _TRACER[0]
+                if tr is not None:
+                    tr.before(_name, args)
                 rc = _fn(*args)
+                if tr is not None:
+                    tr.after(_name, args)
                 if rc != 0:
                     raise PfrError(f"{_name} failed (rc={rc}): {self._dll.pfr_last_error().decode()}")
                 return rc
@@ -107,9 +114,45 @@ class _Lib:
 
 
 # queries that return a value rather than an error code
-_NO_CHECK = {"pfr_version", "pfr_bn_stats_rows_per_part", "pfr_conv2d_mtile", "pfr_conv2d_wgrad_splits", "pfr_colreduce_blocks", "pfr_match_ws_bytes"}
+_NO_CHECK = {"pfr_version", "pfr_bn_stats_rows_per_part", "pfr_bn_finalize_ws_floats", "pfr_conv2d_mtile", "pfr_conv2d_wgrad_splits", "pfr_colreduce_blocks", "pfr_match_ws_bytes"}
 
 lib = _Lib()
+
+# optional per-launch tracer (bench.py uses it to bracket every kernel launch with HIP events)
+_TRACER = [None]
+
+
+def set_tracer(tracer):
+    _TRACER[0] = tracer
+
+
+class EventTracer:
+    """Brackets every C-ABI launch with a pair of HIP events on the launching stream."""
+
+    def __init__(self):
+        import torch
+        self._torch = torch
+        self.records = []
+
+    def before(self, name, args):
+        e = self._torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._cur = e
+
+    def after(self, name, args):
+        e = self._torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((name, args, self._cur, e))
+
+    def summary(self):
+        """-> {name: [n_launches, total_ms]} (synchronises)"""
+        self._torch.cuda.synchronize()
+        out = {}
+        for name, args, a, b in self.records:
+            o = out.setdefault(name, [0, 0.0])
+            o[0] += 1
+            o[1] += a.elapsed_time(b)
+        return out
 
 
 def is_available() -> bool:

@@ -154,8 +154,10 @@ def bn_finalize(part, rows_per_part, count, gamma, beta, eps, momentum, running_
     nparts = part.numel() // (2 * C)
     if out is None:
         out = torch.empty((4, C), dtype=torch.float32, device=part.device)
+    nws = lib.pfr_bn_finalize_ws_floats(nparts, C)
+    ws = torch.empty(nws, dtype=torch.float32, device=part.device) if nws else None
     lib.pfr_bn_finalize(_p(part), nparts, int(rows_per_part), C, float(count), _p(gamma), _p(beta), float(eps), float(momentum),
-                        _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream())
+                        _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _p(ws), _stream())
     return out
 
 

@@ -212,47 +212,82 @@ extern "C" int pfr_bn_stats(const void* x, int dtype, long rows, int C, float* p
 }
 
 // ---- finalise: partials [nparts][2][C] of (mean_t, M2_t), part t covering rows [t*rpp, min(count,(t+1)*rpp)) →
-//      mean, invstd, scale = γ·invstd, shift = β − mean·scale, running stats.  Two passes (Chan merge about the grand mean).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, long rpp, int C, float count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, float momentum, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ mean_out,
-                                                          float* __restrict__ invstd_out, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
-  // block: 16 channels x 16 part-lanes
-  __shared__ float l1[16][17];
-  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  const long total = (long)count;
-  float a = 0.f;
+//      mean, invstd, scale = γ·invstd, shift = β − mean·scale, running stats.
+// Two-pass Chan merge about the group / grand mean.  Level 1 (only when there are many parts) merges groups of parts
+// in parallel (grid = C/16 x groups) into a small [groups][2][C] (+ counts) buffer, level 2 finishes.
+__device__ __forceinline__ float part_rows(long total, long rpp, int i) {
+  const long left = total - (long)i * rpp;
+  return (float)(left < rpp ? left : rpp);
+}
+
+// merges parts [pbeg, pend) for 16 channels; returns (via lane pl==0) n, mean, M2.  counts: optional per-part row counts.
+__device__ __forceinline__ void merge_parts(const float* __restrict__ part, const float* __restrict__ counts, int pbeg,
+                                            int pend, long rpp, long total, int C, int c, int cl, int pl,
+                                            float (*l1)[17], float (*l2)[17], float& n_out, float& mean_out, float& m2_out) {
+  float a = 0.f, n = 0.f;
   if (c < C)
-    for (int i = pl; i < nparts; i += 16) {
-      const long left = total - (long)i * rpp;
-      const float nt = (float)(left < rpp ? left : rpp);
+    for (int i = pbeg + pl; i < pend; i += 16) {
+      const float nt = counts ? counts[i] : part_rows(total, rpp, i);
+      n += nt;
       a = fmaf(nt, part[((size_t)i * 2 + 0) * C + c], a);
     }
   l1[pl][cl] = a;
+  l2[pl][cl] = n;
   __syncthreads();
-  float mean = 0.f;
+  float sa = 0.f, sn = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) mean += l1[i][cl];
-  mean /= count;
+  for (int i = 0; i < 16; ++i) { sa += l1[i][cl]; sn += l2[i][cl]; }
+  const float mean = sn > 0.f ? sa / sn : 0.f;
   __syncthreads();
   float m2 = 0.f;
   if (c < C)
-    for (int i = pl; i < nparts; i += 16) {
-      const long left = total - (long)i * rpp;
-      const float nt = (float)(left < rpp ? left : rpp);
+    for (int i = pbeg + pl; i < pend; i += 16) {
+      const float nt = counts ? counts[i] : part_rows(total, rpp, i);
       const float d = part[((size_t)i * 2 + 0) * C + c] - mean;
       m2 += part[((size_t)i * 2 + 1) * C + c] + nt * d * d;
     }
   l1[pl][cl] = m2;
   __syncthreads();
-  if (pl == 0 && c < C) {
-    float s2 = 0.f;
+  float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s2 += l1[i][cl];
-    float var = fmaxf(s2 / count, 0.f);  // biased batch variance
+  for (int i = 0; i < 16; ++i) s2 += l1[i][cl];
+  __syncthreads();
+  n_out = sn;
+  mean_out = mean;
+  m2_out = s2;
+}
+
+__global__ __launch_bounds__(256) void bn_merge_groups_kernel(const float* __restrict__ part, int nparts, long rpp, long total,
+                                                              int C, int per_group, float* __restrict__ gpart,
+                                                              float* __restrict__ gcount) {
+  __shared__ float l1[16][17], l2[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int g = blockIdx.y;
+  const int pbeg = g * per_group, pend = min(nparts, pbeg + per_group);
+  float n, mean, m2;
+  merge_parts(part, nullptr, pbeg, pend, rpp, total, C, c, cl, pl, l1, l2, n, mean, m2);
+  if (pl == 0 && c < C) {
+    gpart[((size_t)g * 2 + 0) * C + c] = mean;
+    gpart[((size_t)g * 2 + 1) * C + c] = m2;
+    if (c == 0) gcount[g] = n;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ counts,
+                                                          int nparts, long rpp, int C, float count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                          float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  __shared__ float l1[16][17], l2[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float n, mean, m2;
+  merge_parts(part, counts, 0, nparts, rpp, (long)count, C, c, cl, pl, l1, l2, n, mean, m2);
+  if (pl == 0 && c < C) {
+    float var = fmaxf(m2 / count, 0.f);  // biased batch variance
     const float invstd = rsqrtf(var + eps);
     const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
     mean_out[c] = mean;
@@ -267,13 +302,32 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+#define PFR_BN_GROUPS 64
+// scratch floats pfr_bn_finalize needs when nparts is large (0 → none needed)
+extern "C" long pfr_bn_finalize_ws_floats(int nparts, int C) {
+  return nparts > 4 * PFR_BN_GROUPS ? (long)PFR_BN_GROUPS * (2 * C + 1) : 0;
+}
+
 extern "C" int pfr_bn_finalize(const float* part, int nparts, long rows_per_part, int C, float count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                               float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
+                               float* mean, float* invstd, float* scale, float* shift, float* workspace, hipStream_t st) {
   PFR_CHECK_ARG(part && mean && invstd && scale && shift, "pfr_bn_finalize: null pointer");
   PFR_CHECK_ARG(rows_per_part > 0 && (long)nparts * rows_per_part >= (long)count, "pfr_bn_finalize: parts do not cover count");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, nparts, rows_per_part, C, count, gamma,
-                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  const float* counts = nullptr;
+  if (workspace && pfr_bn_finalize_ws_floats(nparts, C) > 0) {
+    const int per_group = (nparts + PFR_BN_GROUPS - 1) / PFR_BN_GROUPS;
+    const int groups = (nparts + per_group - 1) / per_group;
+    float* gpart = workspace;
+    float* gcount = workspace + (size_t)PFR_BN_GROUPS * 2 * C;
+    hipLaunchKernelGGL(bn_merge_groups_kernel, dim3((C + 15) / 16, groups), dim3(256), 0, st, part, nparts, rows_per_part,
+                       (long)count, C, per_group, gpart, gcount);
+    PFR_CHECK_LAUNCH();
+    part = gpart;
+    counts = gcount;
+    nparts = groups;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, counts, nparts, rows_per_part, C, count,
+                     gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
@@ -297,26 +351,36 @@ extern "C" int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, c
 }
 
 // ---- apply: y = act( a1[c]*x1 + b1[c]  (+ a2[c]*x2 + b2[c]  |  + x2) )
+// thread = (channel chunk, row lane): the per-channel coefficients are loaded once into registers, rows are streamed.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, const float* __restrict__ a1,
                                                      const float* __restrict__ b1, const T* __restrict__ x2,
                                                      const float* __restrict__ a2, const float* __restrict__ b2,
-                                                     T* __restrict__ y, size_t nchunks, int cpr, int relu) {
+                                                     T* __restrict__ y, size_t rows, int C, int cw, int rl, int cpr, int relu) {
   constexpr int KP = DT<T>::KPACK;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < nchunks; i += stride) {
-    const int c = (int)(i % cpr) * KP;
+  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
+  const int cglob = blockIdx.y * cw + col;
+  if (cglob >= cpr) return;
+  float A1[KP], B1[KP], A2[KP], B2[KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) {
+    A1[e] = a1[cglob * KP + e];
+    B1[e] = b1[cglob * KP + e];
+    A2[e] = a2 ? a2[cglob * KP + e] : 1.f;
+    B2[e] = a2 ? b2[cglob * KP + e] : 0.f;
+  }
+  for (size_t r = (size_t)blockIdx.x * rl + rlane; r < rows; r += (size_t)gridDim.x * rl) {
+    const size_t off = r * C + cglob * KP;
     float f[KP], g[KP];
-    Chunk<T>::unpack(ld16(x1 + i * KP), f);
-    if (x2) Chunk<T>::unpack(ld16(x2 + i * KP), g);
+    Chunk<T>::unpack(ld16(x1 + off), f);
+    if (x2) Chunk<T>::unpack(ld16(x2 + off), g);
 #pragma unroll
     for (int e = 0; e < KP; ++e) {
-      float z = fmaf(f[e], a1[c + e], b1[c + e]);
-      if (x2) z += a2 ? fmaf(g[e], a2[c + e], b2[c + e]) : g[e];
+      float z = fmaf(f[e], A1[e], B1[e]);
+      if (x2) z += fmaf(g[e], A2[e], B2[e]);
       f[e] = relu ? fmaxf(z, 0.f) : z;
     }
-    st16(y + i * KP, Chunk<T>::pack(f));
+    st16(y + off, Chunk<T>::pack(f));
   }
 }
 
@@ -325,13 +389,11 @@ extern "C" int pfr_bn_act(const void* x1, const float* a1, const float* b1, cons
   PFR_CHECK_ARG(x1 && a1 && b1 && y, "pfr_bn_act: null pointer");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_act: C %% %d != 0", kp);
-  const size_t nch = (size_t)rows * (C / kp);
-  unsigned blocks = (unsigned)((nch + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
+  ColGeom g = col_geom(C, kp, (size_t)rows);
   if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x1, a1, b1, (const bf16_t*)x2, a2, b2, (bf16_t*)y, nch, C / kp, relu);
+    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)x1, a1, b1, (const bf16_t*)x2, a2, b2, (bf16_t*)y, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
   else
-    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x1, a1, b1, (const float*)x2, a2, b2, (float*)y, nch, C / kp, relu);
+    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, (const float*)x1, a1, b1, (const float*)x2, a2, b2, (float*)y, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
@@ -442,32 +504,43 @@ extern "C" int pfr_bn_bwd_finalize(const float* part, int nparts, int C, float c
   return PFR_OK;
 }
 
-// ---- backward apply: g = dout·mask ; dx = cg·g + cx·x + c0 ; optional gres (+)= g  (gradient of the residual input)
+// ---- backward apply: g = dout·mask ; dx = cg·g + cx·x + c0 ; optional gres = g  (gradient of the residual input)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                            const T* __restrict__ x, const float* __restrict__ coef,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int mask_mode, T* __restrict__ dx, T* __restrict__ gres,
-                                                           size_t nchunks, int cpr, int C) {
+                                                           size_t rows, int C, int cw, int rl, int cpr) {
   constexpr int KP = DT<T>::KPACK;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < nchunks; i += stride) {
-    const int c = (int)(i % cpr) * KP;
+  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
+  const int cglob = blockIdx.y * cw + col;
+  if (cglob >= cpr) return;
+  float cg[KP], cx[KP], c0[KP], sc[KP], sh[KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) {
+    const int c = cglob * KP + e;
+    cg[e] = coef[c];
+    cx[e] = coef[C + c];
+    c0[e] = coef[2 * C + c];
+    sc[e] = mask_mode == 2 ? scale[c] : 0.f;
+    sh[e] = mask_mode == 2 ? shift[c] : 0.f;
+  }
+  for (size_t r = (size_t)blockIdx.x * rl + rlane; r < rows; r += (size_t)gridDim.x * rl) {
+    const size_t off = r * C + cglob * KP;
     float g[KP], xv[KP], o[KP];
-    Chunk<T>::unpack(ld16(dout + i * KP), g);
-    Chunk<T>::unpack(ld16(x + i * KP), xv);
-    if (mask_mode == 1) Chunk<T>::unpack(ld16(out + i * KP), o);
+    Chunk<T>::unpack(ld16(dout + off), g);
+    Chunk<T>::unpack(ld16(x + off), xv);
+    if (mask_mode == 1) Chunk<T>::unpack(ld16(out + off), o);
 #pragma unroll
     for (int e = 0; e < KP; ++e) {
       float gg = g[e];
       if (mask_mode == 1) gg = o[e] > 0.f ? gg : 0.f;
-      if (mask_mode == 2) gg = fmaf(xv[e], scale[c + e], shift[c + e]) > 0.f ? gg : 0.f;
+      if (mask_mode == 2) gg = fmaf(xv[e], sc[e], sh[e]) > 0.f ? gg : 0.f;
       g[e] = gg;
-      xv[e] = fmaf(coef[c + e], gg, fmaf(coef[C + c + e], xv[e], coef[2 * C + c + e]));
+      xv[e] = fmaf(cg[e], gg, fmaf(cx[e], xv[e], c0[e]));
     }
-    st16(dx + i * KP, Chunk<T>::pack(xv));
-    if (gres) st16(gres + i * KP, Chunk<T>::pack(g));
+    st16(dx + off, Chunk<T>::pack(xv));
+    if (gres) st16(gres + off, Chunk<T>::pack(g));
   }
 }
 
@@ -477,13 +550,11 @@ extern "C" int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x
   PFR_CHECK_ARG(dout && x && coef && dx, "pfr_bn_bwd_apply: null pointer");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_apply: C %% %d != 0", kp);
-  const size_t nch = (size_t)rows * (C / kp);
-  unsigned blocks = (unsigned)((nch + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
+  ColGeom g = col_geom(C, kp, (size_t)rows);
   if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, coef, scale, shift, mask_mode, (bf16_t*)dx, (bf16_t*)gres, nch, C / kp, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, coef, scale, shift, mask_mode, (bf16_t*)dx, (bf16_t*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, coef, scale, shift, mask_mode, (float*)dx, (float*)gres, nch, C / kp, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, coef, scale, shift, mask_mode, (float*)dx, (float*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

@@ -1,0 +1,109 @@
+"""Data-parallel gradient exchange for the FE train step: one process per GPU, RCCL all-reduce over xGMI.
+
+Reference behaviour (/root/reference/utils/__init__.py:114-119 → PL DDPPlugin(find_unused_parameters=False,
+gradient_as_bucket_view=True); engine/trainer.py:105 sync_batchnorm=False): the whole model + ArcFace head is
+replicated, every rank keeps private BN statistics, gradients are averaged across ranks in ~25 MB buckets
+overlapped with backward.
+
+MI355X design: gradients already live in ONE flat fp32 buffer in forward-parameter order (FEEngine), and backward
+finishes it from the end towards the front.  `BucketReducer.ready(off)` is called by the engine each time the suffix
+[off, end) became final; full buckets of that suffix are all-reduced (AVG) in place on a dedicated communication
+stream while the remaining dgrad/wgrad kernels run.  No gradient copies, no per-parameter hooks, 5 large
+collectives per step for ResNet-50 (xGMI is point-to-point: few, large messages).
+"""
+import torch
+import torch.distributed as dist
+
+
+class BucketReducer:
+    def __init__(self, flat, bucket_elems=6 * 1024 * 1024, group=None, average=True):
+        self.flat = flat
+        self.n = flat.numel()
+        self.bucket = int(bucket_elems)
+        self.group = group
+        self.average = average
+        self.hi = self.n
+        self.handles = []
+        self.launched = []   # (lo, hi) ranges, for tests / introspection
+        self.cuda = flat.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+
+    def reset(self):
+        self.hi = self.n
+        self.handles = []
+        self.launched = []
+
+    def _reduce(self, lo, hi):
+        view = self.flat[lo:hi]
+        op = dist.ReduceOp.AVG if (self.average and self.cuda) else dist.ReduceOp.SUM
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+        self.handles.append((h, lo, hi))
+        self.launched.append((lo, hi))
+
+    def ready(self, off):
+        """flat[off:] is final.  Launch every full bucket of the not-yet-reduced part (everything when off == 0)."""
+        while self.hi - off >= self.bucket:
+            self._reduce(self.hi - self.bucket, self.hi)
+            self.hi -= self.bucket
+        if off == 0 and self.hi > 0:
+            self._reduce(0, self.hi)
+            self.hi = 0
+
+    def finish(self):
+        """Make the compute stream wait for all outstanding reductions."""
+        if self.hi > 0:
+            self.ready(0)
+        for h, lo, hi in self.handles:
+            if self.cuda:
+                with torch.cuda.stream(self.comm_stream):
+                    h.wait()
+            else:
+                h.wait()
+                if self.average:
+                    self.flat[lo:hi].div_(dist.get_world_size(self.group))
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.reset()
+
+
+class FlatDDP:
+    """Wraps a `SoftmaxBasedMetricLearning` (HIP backbone + margin head) for data-parallel training."""
+
+    def __init__(self, model_loss, bucket_mb=25, group=None):
+        self.model_loss = model_loss
+        self.group = group
+        eng = model_loss.module.hip_engine()
+        self.eng = eng
+        # replicate rank 0's parameters / BN buffers
+        dist.broadcast(eng.master, 0, group=group)
+        dist.broadcast(eng.stats, 0, group=group)
+        self.extra = [p for n, p in model_loss.named_parameters() if not n.startswith("module.")]
+        for p in self.extra:
+            dist.broadcast(p.data, 0, group=group)
+        self.reducer = BucketReducer(eng.grad, bucket_elems=bucket_mb * 1024 * 1024 // 4, group=group)
+        eng.grad_ready_hook = self.reducer.ready
+        self.extra_handles = []
+
+    def reduce_extra(self):
+        """all-reduce gradients that do not live in the engine's flat buffer (the ArcFace weight)"""
+        r = self.reducer
+        for p in self.extra:
+            if p.grad is None:
+                continue
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            r.comm_stream.wait_event(ev)
+            with torch.cuda.stream(r.comm_stream):
+                h = dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            r.handles.append((h, 0, 0))
+
+    def finish_backward(self):
+        self.reduce_extra()
+        self.reducer.finish()

@@ -134,6 +134,8 @@ class FEEngine:
             b.bcoef = torch.zeros((3, C), dtype=torch.float32, device=dev)  # backward coefficients
             self._bn_of[id(m)] = b
         self.bn_list = [self._bn_of[id(m)] for _, m in bns]
+        maxc = max(m.num_features for _, m in bns)
+        self.bn_ws = torch.empty(max(1, lib.pfr_bn_finalize_ws_floats(1 << 20, maxc)), dtype=torch.float32, device=dev)
 
         # conv / fc records
         def conv_rec(name, m):
@@ -270,10 +272,13 @@ class FEEngine:
 
     def _bn_fwd(self, ops, bn, part, nparts, count, train):
         if train:
-            ops.append((lib.pfr_bn_finalize, (part.data_ptr(), nparts, lib.pfr_conv2d_mtile(int(count), bn.C), bn.C, float(count), bn.gamma.data_ptr(),
-                                              bn.beta.data_ptr(), float(bn.eps), float(bn.momentum), bn.rm.data_ptr(),
-                                              bn.rv.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
-                                              bn.coef[2].data_ptr(), bn.coef[3].data_ptr())))
+            nws = lib.pfr_bn_finalize_ws_floats(nparts, bn.C)
+            assert nws <= self.bn_ws.numel()
+            ops.append((lib.pfr_bn_finalize, (part.data_ptr(), nparts, lib.pfr_conv2d_mtile(int(count), bn.C), bn.C,
+                                              float(count), bn.gamma.data_ptr(), bn.beta.data_ptr(), float(bn.eps),
+                                              float(bn.momentum), bn.rm.data_ptr(), bn.rv.data_ptr(), bn.coef[0].data_ptr(),
+                                              bn.coef[1].data_ptr(), bn.coef[2].data_ptr(), bn.coef[3].data_ptr(),
+                                              self.bn_ws.data_ptr() if nws else 0)))
         else:
             ops.append((lib.pfr_bn_eval_coeff, (bn.C, bn.gamma.data_ptr(), bn.beta.data_ptr(), bn.rm.data_ptr(),
                                                 bn.rv.data_ptr(), float(bn.eps), bn.coef[2].data_ptr(),
