@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--detail", default=None, help="write per-launch timings grouped by geometry to this JSON file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,6 +173,24 @@ def main():
             opt.step()
         set_tracer(None)
         summ = tr.summary()
+        if args.detail:
+            det = {}
+            for name, a, e0, e1 in tr.records:
+                if name == "pfr_conv2d_fwd":
+                    key = "fwd N%d H%d W%d C%d Co%d R%d s%d dil%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], a[15], 1 if a[21] else 0)
+                    fl = 2.0 * a[5] * a[15] * a[16] * a[9] * a[10] * a[11] * a[8] / (4 ** a[14])
+                elif name == "pfr_conv2d_wgrad":
+                    key = "wgrad N%d H%d W%d C%d Co%d R%d s%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], 1 if a[17] else 0)
+                    fl = 2.0 * a[5] * a[14] * a[15] * a[9] * a[10] * a[11] * a[8]
+                else:
+                    key, fl = name, 0.0
+                d = det.setdefault(key, [0, 0.0, fl])
+                d[0] += 1
+                d[1] += e0.elapsed_time(e1)
+            rows = sorted(((k, v[0] // nprof, v[1] / nprof, v[2]) for k, v in det.items()), key=lambda r: -r[2])
+            with open(args.detail, "w") as f:
+                json.dump([{"op": k, "launches_per_step": n, "ms_per_step": round(ms_, 4),
+                            "tflops": round(fl * n / (ms_ * 1e-3) / 1e12, 1) if fl else None} for k, n, ms_, fl in rows], f, indent=1)
         conv_ms = sum(v[1] for k, v in summ.items() if k in ("pfr_conv2d_fwd", "pfr_conv2d_wgrad")) / nprof
         total_ms = sum(v[1] for v in summ.values()) / nprof
         flops = conv_flops_per_img(args.arch) * args.batch
