@@ -127,6 +127,23 @@ int pfr_sgd_step(float* p, const float* g, float* mom, void* shadow, int shadow_
 int pfr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, size_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, pfr_stream_t stream);
 
+/* ---- embedding match: running top-K over gallery chunks (engine/controller.py:77-90,143-160; generate_tsv.py:91-125;
+ * similarity_f = (cos+1)/2 at configs/dog_fe/fe_dogs_config.py:89-93).  Scores of a chunk come from pfr_conv2d_fwd
+ * (plain GEMM of L2-normalised rows, fp32 out).  Order: score descending, ties → lower gallery index. */
+long pfr_topk_state_bytes(int rows, int K);
+int pfr_topk_reset(void* state, int rows, int K, pfr_stream_t stream);
+/* scores [rows][ld] fp32, n valid columns, gallery index of column j = col0 + j; chunks must come in increasing col0.
+ * self_idx [rows] int32 or NULL: gallery index to skip per query (all-vs-all evaluation excludes the query itself) */
+int pfr_topk_update(const float* scores, int rows, int ld, int n, int col0, int K, void* state, const int* self_idx,
+                    pfr_stream_t stream);
+int pfr_topk_finish(const void* state, int rows, int K, float* out_scores, int* out_idx, pfr_stream_t stream);
+/* exact fp32 re-scoring of KC candidates per query (q, g: L2-normalised fp32 rows), keeps the best K */
+int pfr_topk_rescore(const float* q, const float* g, int rows, int D, const int* cand, int KC, int K, float* out_scores,
+                     int* out_idx, pfr_stream_t stream);
+/* out[p] = (cos(emb[idx_a[p]], emb[idx_b[p]]) + 1) / 2, norms clamped at eps (F.cosine_similarity) */
+int pfr_pair_similarity(const float* emb, int D, const long* idx_a, const long* idx_b, int P, float eps, float* out,
+                        pfr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,278 @@
+// pfr_match.hip — embedding cosine match with running top-K (the candR@K / gallery-match path).
+//
+// Reference semantics replaced (file:line in /root/reference):
+//   engine/controller.py:77-90 (and 143-160)  per query: score all others with similarity_f, argsort descending, top-K
+//   configs/dog_fe/fe_dogs_config.py:89-93     similarity_f = (F.cosine_similarity + 1) / 2   (monotone in the cosine)
+//   generate_tsv.py:91-125                     query-vs-gallery ranking, top-100 answers
+// The reference builds python lists of pairs (≈8.4 µs per scored pair).  Here: rows are
+// L2-normalised once (pfr_l2norm_fwd), scores of a query block against a gallery CHUNK are one MFMA GEMM
+// (pfr_conv2d_fwd as a plain GEMM, fp32 scores), and this file keeps, per query, the running top-K list across
+// chunks: a radix-select / threshold-filter row kernel (one workgroup per query) that only ever sorts the handful of
+// scores above the current K-th best.  Ordering: score descending, ties → lower gallery index (the reference's
+// argsort is unstable, so its own order under ties is undefined).
+#include "pfr_common.h"
+
+#define SEL_LIST 2048   // max entries sorted per query per chunk (current list + new candidates)
+#define SEL_CAP 1536    // direct-collect capacity; above it the K-th value of the chunk is found by radix select
+#define SEL_EQCAP 1024  // capacity for entries tied with the K-th value
+
+__device__ __forceinline__ uint32_t fkey(float s) {
+  const uint32_t u = __float_as_uint(s);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// descending bitonic sort of n (power of two) u64 keys in LDS by a 256-thread block
+__device__ void bitonic_desc(unsigned long long* a, int n) {
+  for (int k = 2; k <= n; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long x = a[i], y = a[l];
+          const bool desc = ((i & k) == 0);
+          if ((x < y) == desc) { a[i] = y; a[l] = x; }
+        }
+      }
+    }
+  __syncthreads();
+}
+
+// scores: [rows][ld] fp32 of this gallery chunk (n valid columns, global gallery index = col0 + column).
+// cur: running list [rows][K] of u64 entries (key<<32 | ~idx), sorted descending; cur_n[rows] valid counts.
+__global__ __launch_bounds__(256) void rowselect_kernel(const float* __restrict__ scores, int ld, int n, int col0, int K,
+                                                        unsigned long long* __restrict__ cur, int* __restrict__ cur_n,
+                                                        const int* __restrict__ self_idx, int* __restrict__ flags) {
+  __shared__ unsigned long long list[SEL_LIST];
+  __shared__ unsigned int hist[2048];
+  __shared__ int s_cnt, s_eq, s_bin, s_need;
+  const int row = blockIdx.x;
+  const float* sr = scores + (size_t)row * ld;
+  unsigned long long* cl = cur + (size_t)row * K;
+  const int have = cur_n[row];
+  const int self = self_idx ? self_idx[row] : -1;
+  // threshold: only scores strictly above the current K-th best can enter (later chunks have higher indices → lose ties)
+  uint32_t tkey = 0;
+  if (have == K) tkey = (uint32_t)(cl[K - 1] >> 32);
+  if (threadIdx.x == 0) { s_cnt = 0; s_eq = 0; }
+  __syncthreads();
+  int mine = 0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    if (col0 + j == self) continue;
+    if (fkey(sr[j]) > tkey || have < K) ++mine;
+  }
+  atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  const int cnt = s_cnt;
+  __syncthreads();
+  uint32_t lo_key = tkey;      // collect keys > lo_key ...
+  bool strict = (have == K);   // ... (or all when the list is not full yet and no radix bound was needed)
+  uint32_t eq_key = 0;
+  int need_eq = 0;
+  if (cnt > SEL_CAP) {
+    // ---- radix select (11+11+10 bits) of the K-th largest key of this chunk
+    int need = K;
+    uint32_t prefix = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+      const int bits = pass == 2 ? 10 : 11;
+      for (int i = threadIdx.x; i < 2048; i += 256) hist[i] = 0;
+      __syncthreads();
+      for (int j = threadIdx.x; j < n; j += 256) {
+        if (col0 + j == self) continue;
+        const uint32_t k = fkey(sr[j]);
+        const bool match = pass == 0 ? true : (pass == 1 ? (k >> 21) == prefix : (k >> 10) == prefix);
+        if (match) atomicAdd(&hist[(k >> shift) & ((1u << bits) - 1)], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int acc = 0, b = (1 << bits) - 1;
+        for (; b > 0; --b) {
+          if (acc + (int)hist[b] >= need) break;
+          acc += hist[b];
+        }
+        s_bin = b;
+        s_need = need - acc;
+      }
+      __syncthreads();
+      prefix = (prefix << bits) | (uint32_t)s_bin;
+      need = s_need;
+      __syncthreads();
+    }
+    eq_key = prefix;          // exact K-th largest key of the chunk
+    need_eq = need;           // how many entries equal to it are still needed
+    lo_key = eq_key;
+    strict = true;
+  }
+  // ---- collect
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) {
+    if (col0 + j == self) continue;
+    const uint32_t k = fkey(sr[j]);
+    const bool take = strict ? (k > lo_key) : true;
+    const unsigned long long e = ((unsigned long long)k << 32) | (uint32_t)(~(uint32_t)(col0 + j));
+    if (take) {
+      const int p = atomicAdd(&s_cnt, 1);
+      if (p < SEL_CAP) list[p] = e;
+    } else if (need_eq > 0 && k == eq_key) {
+      const int p = atomicAdd(&s_eq, 1);
+      if (p < SEL_EQCAP) reinterpret_cast<unsigned long long*>(hist)[p] = e;  // hist (8 KB) reused as the tie buffer
+    }
+  }
+  __syncthreads();
+  int total = min(s_cnt, SEL_CAP);
+  if (need_eq > 0) {
+    const int neq = min(s_eq, SEL_EQCAP);
+    if (s_eq > SEL_EQCAP && threadIdx.x == 0 && flags) atomicOr(flags, 1);  // more ties than the buffer holds
+    int p2 = 1;
+    while (p2 < neq) p2 <<= 1;
+    unsigned long long* eqb = reinterpret_cast<unsigned long long*>(hist);
+    for (int i = neq + threadIdx.x; i < p2; i += 256) eqb[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(eqb, p2);  // equal keys → descending ~idx = ascending index
+    const int take = min(need_eq, neq);
+    for (int i = threadIdx.x; i < take; i += 256)
+      if (total + i < SEL_LIST) list[total + i] = eqb[i];
+    total = min(SEL_LIST, total + take);
+    __syncthreads();
+  }
+  // ---- append the current list, sort, keep the best K
+  for (int i = threadIdx.x; i < have; i += 256)
+    if (total + i < SEL_LIST) list[total + i] = cl[i];
+  total = min(SEL_LIST, total + have);
+  int p2 = 1;
+  while (p2 < total) p2 <<= 1;
+  for (int i = total + threadIdx.x; i < p2; i += 256) list[i] = 0ull;
+  __syncthreads();
+  bitonic_desc(list, p2);
+  const int keep = min(K, total);
+  for (int i = threadIdx.x; i < keep; i += 256) cl[i] = list[i];
+  if (threadIdx.x == 0) cur_n[row] = keep;
+}
+
+__global__ void topk_unpack_kernel(const unsigned long long* __restrict__ cur, const int* __restrict__ cur_n, int rows, int K,
+                                   float* __restrict__ out_scores, int* __restrict__ out_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  const int r = i / K, j = i % K;
+  if (j < cur_n[r]) {
+    const unsigned long long e = cur[i];
+    out_scores[i] = fkey_inv((uint32_t)(e >> 32));
+    out_idx[i] = (int)(~(uint32_t)e);
+  } else {
+    out_scores[i] = -INFINITY;
+    out_idx[i] = -1;
+  }
+}
+
+extern "C" long pfr_topk_state_bytes(int rows, int K) { return (long)rows * K * 8 + (long)rows * 4 + 64; }
+
+// state: pfr_topk_state_bytes(rows, K) bytes, zeroed by pfr_topk_reset before the first chunk
+extern "C" int pfr_topk_reset(void* state, int rows, int K, hipStream_t st) {
+  PFR_CHECK_ARG(state, "pfr_topk_reset: null state");
+  if (hipMemsetAsync(state, 0, (size_t)pfr_topk_state_bytes(rows, K), st) != hipSuccess) {
+    pfr_set_error("pfr_topk_reset: hipMemsetAsync failed");
+    return PFR_ERR_HIP;
+  }
+  return PFR_OK;
+}
+
+// merge one gallery chunk of fp32 scores [rows][ld] (n valid columns; gallery index of column j = col0 + j)
+extern "C" int pfr_topk_update(const float* scores, int rows, int ld, int n, int col0, int K, void* state, const int* self_idx,
+                               hipStream_t st) {
+  PFR_CHECK_ARG(scores && state && rows > 0 && n > 0, "pfr_topk_update: bad args");
+  PFR_CHECK_ARG(K >= 1 && K <= 512, "pfr_topk_update: K must be in [1,512]");
+  unsigned long long* cur = reinterpret_cast<unsigned long long*>(state);
+  int* cur_n = reinterpret_cast<int*>(reinterpret_cast<char*>(state) + (size_t)rows * K * 8);
+  int* flags = cur_n + rows;
+  hipLaunchKernelGGL(rowselect_kernel, dim3(rows), dim3(256), 0, st, scores, ld, n, col0, K, cur, cur_n, self_idx, flags);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+extern "C" int pfr_topk_finish(const void* state, int rows, int K, float* out_scores, int* out_idx, hipStream_t st) {
+  PFR_CHECK_ARG(state && out_scores && out_idx, "pfr_topk_finish: null pointer");
+  const unsigned long long* cur = reinterpret_cast<const unsigned long long*>(state);
+  const int* cur_n = reinterpret_cast<const int*>(reinterpret_cast<const char*>(state) + (size_t)rows * K * 8);
+  hipLaunchKernelGGL(topk_unpack_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, st, cur, cur_n, rows, K, out_scores, out_idx);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// exact fp32 re-scoring of candidate lists: score = <q[r], g[idx]> on the fp32 (normalised) rows, then re-sort and keep K.
+// one workgroup per query; a wave computes one dot product at a time.
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q, const float* __restrict__ g, int D,
+                                                      const int* __restrict__ cand, int KC, int K,
+                                                      float* __restrict__ out_scores, int* __restrict__ out_idx) {
+  __shared__ unsigned long long list[512];
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* qr = q + (size_t)row * D;
+  int p2 = 1;
+  while (p2 < KC) p2 <<= 1;
+  for (int i = threadIdx.x; i < p2; i += 256) list[i] = 0ull;
+  __syncthreads();
+  for (int c = wave; c < KC; c += 4) {
+    const int gi = cand[(size_t)row * KC + c];
+    if (gi < 0) continue;
+    const float* gr = g + (size_t)gi * D;
+    float a = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(qr + d);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(gr + d);
+      a = fmaf(x[0], y[0], a); a = fmaf(x[1], y[1], a); a = fmaf(x[2], y[2], a); a = fmaf(x[3], y[3], a);
+    }
+    a = wave_sum(a);
+    if (lane == 0) list[c] = ((unsigned long long)fkey(a) << 32) | (uint32_t)(~(uint32_t)gi);
+  }
+  __syncthreads();
+  bitonic_desc(list, p2);
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const unsigned long long e = list[i];
+    if (e != 0ull) {
+      out_scores[(size_t)row * K + i] = fkey_inv((uint32_t)(e >> 32));
+      out_idx[(size_t)row * K + i] = (int)(~(uint32_t)e);
+    } else {
+      out_scores[(size_t)row * K + i] = -INFINITY;
+      out_idx[(size_t)row * K + i] = -1;
+    }
+  }
+}
+
+extern "C" int pfr_topk_rescore(const float* q, const float* g, int rows, int D, const int* cand, int KC, int K,
+                                float* out_scores, int* out_idx, hipStream_t st) {
+  PFR_CHECK_ARG(q && g && cand && out_scores && out_idx, "pfr_topk_rescore: null pointer");
+  PFR_CHECK_ARG(D % 4 == 0 && KC <= 512 && K <= KC, "pfr_topk_rescore: need D %% 4 == 0, K <= KC <= 512");
+  hipLaunchKernelGGL(rescore_kernel, dim3(rows), dim3(256), 0, st, q, g, D, cand, KC, K, out_scores, out_idx);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// pair scores of the validation protocol: out[p] = (cos(a_p, b_p) + 1) / 2 with F.cosine_similarity's eps clamp
+__global__ __launch_bounds__(256) void pair_sim_kernel(const float* __restrict__ emb, int D, const long* __restrict__ ia,
+                                                       const long* __restrict__ ib, int P, float eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const float* a = emb + (size_t)ia[p] * D;
+  const float* b = emb + (size_t)ib[p] * D;
+  float ab = 0.f, aa = 0.f, bb = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float x = a[d], y = b[d];
+    ab = fmaf(x, y, ab); aa = fmaf(x, x, aa); bb = fmaf(y, y, bb);
+  }
+  ab = wave_sum(ab); aa = wave_sum(aa); bb = wave_sum(bb);
+  if (lane == 0) out[p] = (ab / (fmaxf(sqrtf(aa), eps) * fmaxf(sqrtf(bb), eps)) + 1.f) * 0.5f;
+}
+extern "C" int pfr_pair_similarity(const float* emb, int D, const long* idx_a, const long* idx_b, int P, float eps, float* out,
+                                   hipStream_t st) {
+  PFR_CHECK_ARG(emb && idx_a && idx_b && out, "pfr_pair_similarity: null pointer");
+  if (P == 0) return PFR_OK;
+  hipLaunchKernelGGL(pair_sim_kernel, dim3((P + 3) / 4), dim3(256), 0, st, emb, D, idx_a, idx_b, P, eps, out);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}

@@ -256,9 +256,13 @@ extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   int bp, bq;
   wgrad_tiles(Cout, KK, &bp, &bq);
   const long tiles = (long)((Cout + bp - 1) / bp) * ((KK + bq - 1) / bq);
-  long want = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU in flight
+  long want = (768 + tiles - 1) / tiles;   // ~3 workgroups per CU in flight
   const long maxs = (M + 255) / 256;       // at least 256 reduction rows per split
   if (want > maxs) want = maxs;
+  // the fp32 partial slabs are written and re-read once: keep them well below the activation traffic of the layer
+  const long slab = (long)Cout * KK * 4;
+  const long cap = (24L << 20) / slab;
+  if (want > cap) want = cap;
   if (want < 1) want = 1;
   return (int)want;
 }

@@ -1,0 +1,106 @@
+"""Embedding match: cosine scores, running top-K, candR@K (Recall@K) — the evaluation half of the FE hot path.
+
+Reference call sites: /root/reference/engine/controller.py:60-65,77-90,143-160 (pair scores + per-query ranking),
+configs/dog_fe/fe_dogs_config.py:89-93 (`similarity_f`), generate_tsv.py:91-125 (query-vs-gallery top-100).
+
+CUDA tensors run on the gfx950 kernels (normalise → MFMA GEMM per gallery chunk → radix-select/threshold top-K merge,
+optional exact fp32 re-scoring of the candidate lists); CPU tensors use plain torch (the reference's own device
+behaviour, used by the CPU plumbing config).  Ordering everywhere: score descending, ties → lower index.
+"""
+import torch
+
+from .._hip import lib, dtype_id
+from .._hip import ops
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self=False, rescore=None, slack=None):
+    """Top-k gallery rows per query by cosine similarity.  q [Q,D], g [G,D] (any scale; rows are L2-normalised here).
+    → (scores [Q,k] fp32 cosine, idx [Q,k] int32, −1 / −inf padded when fewer than k exist).
+    exclude_self: q and g are the same set, the diagonal is skipped (the reference excludes the query itself).
+    rescore (default: True for bf16): candidates are selected on bf16-input scores with `slack` extra entries, then
+    re-scored exactly in fp32 and re-sorted, so that the final order is the fp32 order."""
+    if not q.is_cuda:
+        return _cosine_topk_torch(q, g, k, exclude_self)
+    Q, D = q.shape
+    G = g.shape[0]
+    T = compute_dtype
+    if rescore is None:
+        rescore = T != torch.float32
+    kc = k
+    if rescore:
+        kc = min(512, k + (slack if slack is not None else max(28, k // 2 + k)))
+    kc = min(kc, 512)
+    q32 = q.float().contiguous()
+    g32 = g.float().contiguous()
+    qn, _, _ = ops.l2norm_fwd(q32, T)
+    gn, _, _ = ops.l2norm_fwd(g32, T)
+    if rescore:
+        qn32, _, _ = ops.l2norm_fwd(q32, torch.float32)
+        gn32, _, _ = ops.l2norm_fwd(g32, torch.float32)
+    chunk = min(chunk, G)
+    ld = (chunk + 3) // 4 * 4
+    sbuf = torch.empty((Q, 1, 1, ld), dtype=torch.float32, device=q.device)
+    state = torch.empty(lib.pfr_topk_state_bytes(Q, kc), dtype=torch.uint8, device=q.device)
+    lib.pfr_topk_reset(state.data_ptr(), Q, kc, _stream())
+    self_idx = torch.arange(Q, dtype=torch.int32, device=q.device) if exclude_self else None
+    for c0 in range(0, G, chunk):
+        n = min(chunk, G - c0)
+        ops.conv2d_fwd(qn.view(Q, 1, 1, D), gn[c0:c0 + n].view(n, 1, 1, D), out=sbuf)
+        lib.pfr_topk_update(sbuf.data_ptr(), Q, ld, n, c0, kc, state.data_ptr(), 0 if self_idx is None else self_idx.data_ptr(),
+                            _stream())
+    sc = torch.empty((Q, kc), dtype=torch.float32, device=q.device)
+    idx = torch.empty((Q, kc), dtype=torch.int32, device=q.device)
+    lib.pfr_topk_finish(state.data_ptr(), Q, kc, sc.data_ptr(), idx.data_ptr(), _stream())
+    if rescore:
+        sc2 = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+        idx2 = torch.empty((Q, k), dtype=torch.int32, device=q.device)
+        lib.pfr_topk_rescore(qn32.data_ptr(), gn32.data_ptr(), Q, D, idx.data_ptr(), kc, k, sc2.data_ptr(), idx2.data_ptr(),
+                             _stream())
+        return sc2, idx2
+    return sc[:, :k].contiguous(), idx[:, :k].contiguous()
+
+
+def _cosine_topk_torch(q, g, k, exclude_self):
+    qn = q / q.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    gn = g / g.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    sc = qn @ gn.t()
+    if exclude_self:
+        sc.fill_diagonal_(-float("inf"))
+    kk = min(k, sc.shape[1] - (1 if exclude_self else 0))
+    order = torch.argsort(sc, dim=1, descending=True, stable=True)[:, :kk]
+    return torch.gather(sc, 1, order), order.int()
+
+
+def recall_at_k(emb, classes, ks=(10, 100), compute_dtype=torch.float32):
+    """candR@K of the reference's validation protocol (controller.py:77-90): every embedding queries all the OTHERS;
+    a hit at K = some same-class item among the K best; denominator = queries that have a same-class other.
+    → {k: [hits, denom]}"""
+    kmax = min(max(ks), emb.shape[0] - 1)
+    _, idx = cosine_topk(emb, emb, kmax, compute_dtype=compute_dtype, exclude_self=True)
+    idx = idx.long()
+    cls = classes.to(idx.device)
+    valid = idx >= 0
+    same = (cls[idx.clamp_min(0)] == cls[:, None]) & valid
+    counts = torch.bincount(cls - cls.min())
+    has = counts[cls - cls.min()] > 1
+    out = {}
+    for k in ks:
+        out[k] = [int((same[:, :k].any(dim=1) & has).sum().item()), int(has.sum().item())]
+    return out
+
+
+def pair_similarity(emb, idx_a, idx_b, eps=1e-8):
+    """(cos(emb[a], emb[b]) + 1) / 2 for index pairs — `similarity_f` over `pair_generator.corrected_indices`."""
+    ia = torch.as_tensor(idx_a, dtype=torch.int64, device=emb.device).contiguous()
+    ib = torch.as_tensor(idx_b, dtype=torch.int64, device=emb.device).contiguous()
+    if not emb.is_cuda:
+        a, b = emb[ia], emb[ib]
+        return ((a * b).sum(1) / (a.norm(dim=1).clamp_min(eps) * b.norm(dim=1).clamp_min(eps)) + 1) / 2
+    e = emb.float().contiguous()
+    out = torch.empty(ia.numel(), dtype=torch.float32, device=emb.device)
+    lib.pfr_pair_similarity(e.data_ptr(), e.shape[1], ia.data_ptr(), ib.data_ptr(), ia.numel(), float(eps), out.data_ptr(), _stream())
+    return out

@@ -1,0 +1,65 @@
+"""Embedding match / candR@K on the HIP path vs the CPU oracle and the fixtures produced by the reference's own
+Controller.test_epoch_end (tests/golden/recall.npz, see oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("name", ["n256", "n400", "ties"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_recall_at_k_identical_to_reference(name, dtype):
+    from pets_face_recognition_amd.match import recall_at_k
+    G = np.load(os.path.join(GOLD, "recall.npz"))
+    emb = torch.tensor(G[f"{name}_emb"]).to(DEV)
+    cls = torch.tensor(G[f"{name}_classes"]).to(DEV)
+    got = recall_at_k(emb, cls, (10, 100), compute_dtype=dtype)
+    for k in (10, 100):
+        assert got[k] == G[f"{name}_recall{k}_counts"].tolist(), (k, got[k])
+        if name != "ties":   # the reference's own ratio (its unstable argsort makes it undefined under ties)
+            assert abs(got[k][0] / got[k][1] - float(G[f"{name}_recall{k}_ref"])) < 1e-12
+
+
+def test_pair_similarity_vs_reference():
+    from pets_face_recognition_amd.match import pair_similarity
+    G = np.load(os.path.join(GOLD, "recall.npz"))
+    emb = torch.tensor(G["n256_emb"]).to(DEV)
+    pairs = G["n256_pairs"]
+    sc = pair_similarity(emb, pairs[:, 0], pairs[:, 1])
+    torch.cuda.synchronize()
+    assert torch.allclose(sc.cpu(), torch.tensor(G["n256_pair_scores"]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_query_gallery_topk_chunked(dtype):
+    """multi-chunk running top-K (radix-select first chunk, threshold-filter later chunks) == oracle full sort"""
+    from oracle import match_ref
+    from pets_face_recognition_amd.match import cosine_topk
+    g = torch.Generator().manual_seed(5)
+    Q, Gn, D, K = 300, 20000, 512, 100
+    centers = torch.randn(500, D, generator=g)
+    gcls = torch.randint(0, 500, (Gn,), generator=g)
+    gal = centers[gcls] + 2.5 * torch.randn(Gn, D, generator=g)
+    qcls = torch.randint(0, 500, (Q,), generator=g)
+    qry = centers[qcls] + 2.5 * torch.randn(Q, D, generator=g)
+    gal[777] = gal[123]           # exact duplicate rows: tie → lower index first
+    rs, ri = match_ref.topk_query_gallery(qry, gal, K)
+    sc, idx = cosine_topk(qry.to(DEV), gal.to(DEV), K, compute_dtype=dtype, chunk=4096)
+    torch.cuda.synchronize()
+    idx = idx.cpu().long()
+    # identical candidate sets; order may differ only where fp32 scores differ by rounding of the summation order
+    same_set = [(set(idx[i].tolist()) == set(ri[i].tolist())) for i in range(Q)]
+    assert sum(same_set) >= Q - 2, f"{Q - sum(same_set)} queries with a different top-{K} set"
+    assert torch.allclose(sc.cpu(), rs, rtol=1e-4, atol=1e-5)
+    a = match_ref.cand_recall_query_gallery(idx, qcls, gcls, (10, 100))
+    b = match_ref.cand_recall_query_gallery(ri, qcls, gcls, (10, 100))
+    assert a == b
+    # small-gallery edge: fewer rows than K
+    sc2, idx2 = cosine_topk(qry[:5].to(DEV), gal[:40].to(DEV), K, compute_dtype=dtype)
+    torch.cuda.synchronize()
+    assert (idx2[:, 40:] == -1).all() and (idx2[:, :40] >= 0).all()
