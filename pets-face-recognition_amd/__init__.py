@@ -10,3 +10,13 @@ Layout
   optim/     flat-buffer fused SGD / AdamW
 """
 __version__ = "0.1.0"
+
+
+def install_reference_aliases():
+    """Expose the sub-packages under the reference's top-level names (`losses`, `models`, `engine`, `utils`,
+    `data_loading`) so that reference-style config files (`from losses import SoftmaxBasedMetricLearning`, …) run
+    unchanged.  Called by main.py / eval scripts."""
+    import importlib
+    import sys
+    for name in ("utils", "models", "losses", "data_loading", "engine", "match", "optim"):
+        sys.modules.setdefault(name, importlib.import_module(__name__ + "." + name))

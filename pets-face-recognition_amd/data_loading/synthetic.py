@@ -1,0 +1,45 @@
+"""Synthetic stand-in for the reference's folder-per-identity `RecDataset` (/root/reference/data_loading/dataset.py:
+67-201): same item contract `{'x': float 3xHxW in [0,1], 'label': int64, 'index': int64}` (dataset.py:125), same
+`get_users()/get_labels()` surface used by the configs, but images are generated (datasets need network downloads).
+Each identity has a fixed random low-frequency pattern; photos are the pattern plus noise, so that embeddings can
+actually separate identities."""
+import torch
+from torch.utils.data import Dataset
+
+
+class SyntheticRecDataset(Dataset):
+    def __init__(self, n_identities, photos_per_identity, image_size=224, seed=0, noise=0.15):
+        self.n_id, self.ppi, self.size, self.seed, self.noise = n_identities, photos_per_identity, image_size, seed, noise
+        self.labels = torch.arange(n_identities).repeat_interleave(photos_per_identity)
+        self.label_map = {u: u for u in range(n_identities)}
+
+    def __len__(self):
+        return self.n_id * self.ppi
+
+    def get_users(self):
+        return list(range(self.n_id))
+
+    def get_labels(self):
+        return self.labels.tolist()
+
+    def _pattern(self, ident):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + ident)
+        low = torch.rand(3, 7, 7, generator=g)
+        return torch.nn.functional.interpolate(low[None], size=(self.size, self.size), mode='bilinear', align_corners=False)[0]
+
+    def __getitem__(self, i):
+        ident = int(self.labels[i])
+        g = torch.Generator().manual_seed(self.seed * 7919 + i)
+        x = (self._pattern(ident) + self.noise * torch.randn(3, self.size, self.size, generator=g)).clamp_(0, 1)
+        return {'x': x, 'label': torch.tensor(self.label_map[ident], dtype=torch.int64), 'index': torch.tensor(i, dtype=torch.int64)}
+
+
+class RecSubset(Dataset):
+    def __init__(self, dataset, indices):
+        self.dataset, self.indices = dataset, list(indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, i):
+        return self.dataset[self.indices[i]]

@@ -1,1 +1,3 @@
-from .ddp import BucketReducer, FlatDDP  # noqa: F401
+from .controller import Controller  # noqa: F401
+from .trainer import Trainer  # noqa: F401
+from .ddp import BucketReducer, FlatDDP, GenericDDP  # noqa: F401

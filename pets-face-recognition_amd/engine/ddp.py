@@ -107,3 +107,31 @@ class FlatDDP:
     def finish_backward(self):
         self.reduce_extra()
         self.reducer.finish()
+
+
+class GenericDDP:
+    """Gradient averaging for the torch (CPU) execution path: the same replicate-all / mean-reduce semantics on
+    ordinary parameter tensors (used by the CPU plumbing configs and the gloo tests)."""
+
+    def __init__(self, module, group=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.group = group
+        for p in self.params:
+            dist.broadcast(p.data, 0, group=group)
+        for b in module.buffers():
+            if b.dtype.is_floating_point:
+                dist.broadcast(b.data, 0, group=group)
+
+    def finish_backward(self):
+        world = dist.get_world_size(self.group)
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, group=self.group)
+        flat.div_(world)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n

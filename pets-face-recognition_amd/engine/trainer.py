@@ -1,0 +1,146 @@
+"""`Trainer` — a plain training / evaluation driver with the call surface the reference uses
+(`Trainer(gpus=…, max_epochs=…, strategy=…, default_root_dir=…, logger=…, enable_checkpointing=…, callbacks=…,
+**trainer_kwargs)`, `.fit(controller)`, `.test(controller)`), replacing the copy of PyTorch-Lightning's Trainer in
+/root/reference/engine/trainer.py:66-652 and the custom loops of engine/loops/*.py.  Order of operations kept from the
+reference: per batch zero_grad → training_step → backward → optimizer.step (PL automatic optimisation,
+trainer.py:403-413); validation at the end of every epoch, then a barrier when distributed, then the LR-scheduler
+step (loops/train_loop.py:13-38); evaluation outputs are handed over as List[dataloader][batch]
+(loops/eval_loop.py:30-51); no sanity-validation steps, no sampler replacement, private BN statistics per rank
+(trainer.py:105,110,118); one checkpoint (bare state_dict, reference key names) per epoch.
+
+Distributed = one process per GPU started by torchrun (RANK / LOCAL_RANK / WORLD_SIZE), RCCL all-reduce of the flat
+gradient buffer in buckets overlapped with backward (engine/ddp.py)."""
+import os
+from pathlib import Path
+
+import torch
+
+
+def _to_device(batch, device):
+    if isinstance(batch, dict):
+        return {k: _to_device(v, device) for k, v in batch.items()}
+    if isinstance(batch, (list, tuple)):
+        return type(batch)(_to_device(v, device) for v in batch)
+    if torch.is_tensor(batch):
+        return batch.to(device, non_blocking=True)
+    return batch
+
+
+class Trainer:
+    def __init__(self, gpus=0, default_root_dir=None, strategy=None, max_epochs=1, logger=False, enable_checkpointing=False,
+                 callbacks=None, num_sanity_val_steps=0, limit_train_batches=None, limit_val_batches=None,
+                 check_val_every_n_epoch=1, log_every_n_steps=50, benchmark=None, fast_dev_run=False, **_ignored):
+        self.gpus, self.root, self.strategy = gpus, default_root_dir, strategy
+        self.max_epochs = 1 if fast_dev_run else max_epochs
+        self.logger = logger if logger else None
+        self.enable_checkpointing = enable_checkpointing
+        self.callbacks = callbacks or []
+        self.limit_train_batches = 1 if fast_dev_run else limit_train_batches
+        self.limit_val_batches = 1 if fast_dev_run else limit_val_batches
+        self.check_val_every_n_epoch = check_val_every_n_epoch
+        self.log_every_n_steps = log_every_n_steps
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.global_step = 0
+        self.ddp = None
+
+    # ------------------------------------------------------------------
+    @property
+    def is_distributed_run(self):
+        return self.strategy is not None and self.world > 1
+
+    def _device(self):
+        if not self.gpus:
+            return torch.device('cpu')
+        if self.is_distributed_run:
+            return torch.device('cuda', self.local_rank)
+        return torch.device('cuda', self.gpus[0] if isinstance(self.gpus, (list, tuple)) else 0)
+
+    def _setup(self, controller):
+        device = self._device()
+        if device.type == 'cuda':
+            torch.cuda.set_device(device)
+        controller.to(device)
+        controller.logger = self.logger
+        if self.is_distributed_run and self.ddp is None:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                dist.init_process_group('nccl' if device.type == 'cuda' else 'gloo')
+            if device.type == 'cuda':
+                from .ddp import FlatDDP
+                controller.model_loss.module.hip_engine(device)
+                self.ddp = FlatDDP(controller.model_loss, bucket_mb=self.strategy.get('bucket_mb', 25))
+            else:
+                from .ddp import GenericDDP
+                self.ddp = GenericDDP(controller.model_loss)
+        return device
+
+    # ------------------------------------------------------------------
+    def fit(self, controller):
+        device = self._setup(controller)
+        opt = controller.configure_optimizers()
+        optims, scheds = (opt if isinstance(opt, (tuple, list)) and len(opt) == 2 and isinstance(opt[0], (list, tuple))
+                          else ([opt], []))
+        optim = optims[0]
+        history = []
+        for epoch in range(self.max_epochs):
+            controller.current_epoch = epoch
+            controller.train()
+            for bi, batch in enumerate(controller.train_dataloader()):
+                if self.limit_train_batches is not None and bi >= self.limit_train_batches:
+                    break
+                batch = _to_device(batch, device)
+                optim.zero_grad()
+                loss = controller.training_step(batch, bi)
+                loss.backward()
+                if self.ddp is not None:
+                    self.ddp.finish_backward()
+                optim.step()
+                self.global_step += 1
+                if self.global_step % self.log_every_n_steps == 0 or bi == 0:
+                    lv = float(loss.detach())
+                    history.append(lv)
+                    if self.rank == 0:
+                        print(f'epoch {epoch} step {self.global_step} loss {lv:.5f}')
+            if (epoch + 1) % self.check_val_every_n_epoch == 0:
+                self._run_eval(controller, device, 'val')
+            if self.is_distributed_run:
+                import torch.distributed as dist
+                dist.barrier()
+            for s in scheds:
+                s.step()
+            if self.enable_checkpointing and self.root is not None and self.rank == 0:
+                Path(self.root).mkdir(parents=True, exist_ok=True)
+                torch.save(controller.state_dict(), Path(self.root) / f'epoch={epoch}.ckpt')
+        self.loss_history = history
+        return controller
+
+    def _run_eval(self, controller, device, kind):
+        controller.eval()
+        loaders = controller.val_dataloader() if kind == 'val' else controller.test_dataloader()
+        if not isinstance(loaders, (list, tuple)):
+            loaders = [loaders]
+        outputs = []
+        with torch.no_grad():
+            for di, loader in enumerate(loaders):
+                outs = []
+                for bi, batch in enumerate(loader):
+                    if self.limit_val_batches is not None and bi >= self.limit_val_batches:
+                        break
+                    batch = _to_device(batch, device)
+                    step = controller.validation_step if kind == 'val' else controller.test_step
+                    outs.append(step(batch, bi, di))
+                outputs.append(outs)
+            res = controller.validation_epoch_end(outputs) if kind == 'val' else controller.test_epoch_end(outputs)
+        controller.train()
+        return res
+
+    def test(self, controller):
+        device = self._setup(controller)
+        return self._run_eval(controller, device, 'test')
+
+    def validate(self, controller):
+        device = self._setup(controller)
+        return self._run_eval(controller, device, 'val')

@@ -1,0 +1,115 @@
+"""The CPU oracle (oracle/) against the golden vectors generated from the reference's own modules
+(oracle/make_golden.py) — and the product's CPU (torch) execution path against the same vectors."""
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _arc_cases():
+    G = np.load(os.path.join(GOLD, "arcface.npz"))
+    for name, arc, easy in [("arc_hard", True, False), ("arc_easy", True, True), ("cosface", False, False),
+                            ("arc_hard_400", True, False)]:
+        for gamma in (0, 2):
+            key = f"{name}_g{gamma}"
+            if key + "_x" in G:
+                yield G, key, arc, easy, gamma
+
+
+def test_oracle_arcface_matches_reference_vectors():
+    from oracle import arcface_ref
+    n = 0
+    for G, key, arc, easy, gamma in _arc_cases():
+        x = torch.tensor(G[key + "_x"]).requires_grad_(True)
+        w = torch.tensor(G[key + "_w"]).requires_grad_(True)
+        y = torch.tensor(G[key + "_label"])
+        s, m = float(G[key + "_s"]), float(G[key + "_m"])
+        lo = arcface_ref.arc_margin_logits(x, w, y, s, m, easy) if arc else arcface_ref.add_margin_logits(x, w, y, s, m)
+        loss = arcface_ref.focal_loss(lo, y, gamma)
+        loss.backward()
+        assert torch.allclose(lo, torch.tensor(G[key + "_logits"]), rtol=1e-6, atol=1e-5), key
+        assert abs(loss.item() - float(G[key + "_loss"])) < 1e-5
+        assert torch.allclose(x.grad, torch.tensor(G[key + "_dx"]), rtol=1e-4, atol=1e-6)
+        assert torch.allclose(w.grad, torch.tensor(G[key + "_dw"]), rtol=1e-4, atol=1e-6)
+        n += 1
+    assert n == 7
+
+
+def test_product_cpu_path_losses_match_reference_vectors():
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    for G, key, arc, easy, gamma in _arc_cases():
+        C = G[key + "_w"].shape[0]
+        wrap = SoftmaxBasedMetricLearning(torch.nn.Identity(), C, 512, is_focal=True, loss_kwargs=dict(gamma=gamma),
+                                          arc_margin=arc, easy_margin=easy)
+        with torch.no_grad():
+            wrap.add_margin.weight.copy_(torch.tensor(G[key + "_w"]))
+        x = torch.tensor(G[key + "_x"]).requires_grad_(True)
+        r = wrap(x, torch.tensor(G[key + "_label"]))
+        r["loss"].backward()
+        assert torch.allclose(r["logits"], torch.tensor(G[key + "_logits"]), rtol=1e-6, atol=1e-5), key
+        assert abs(r["loss"].item() - float(G[key + "_loss"])) < 1e-5
+        assert torch.allclose(x.grad, torch.tensor(G[key + "_dx"]), rtol=1e-4, atol=1e-6)
+        assert set(r.keys()) == {"loss", "emb", "logits"}
+    # label=None returns the bare embedding; list input is embedded item by item
+    assert torch.equal(wrap(x.detach()), x.detach())
+    assert wrap([x.detach()[:3], x.detach()[3:5]]).shape[0] == 5
+
+
+def test_oracle_recall_matches_reference_controller():
+    from oracle import match_ref
+    G = np.load(os.path.join(GOLD, "recall.npz"))
+    for name in ("n256", "n400"):
+        emb, cls = torch.tensor(G[f"{name}_emb"]), torch.tensor(G[f"{name}_classes"])
+        loop = match_ref.recall_at_k_loop(emb[:128], cls[:128], (10, 100))      # literal loop on a prefix (speed)
+        mat = match_ref.recall_at_k_matrix(emb[:128], cls[:128], (10, 100))
+        assert loop == mat
+        full = match_ref.recall_at_k_matrix(emb, cls, (10, 100))
+        for k in (10, 100):
+            assert full[k] == G[f"{name}_recall{k}_counts"].tolist()
+            assert abs(full[k][0] / full[k][1] - float(G[f"{name}_recall{k}_ref"])) < 1e-12
+    # product CPU path
+    from pets_face_recognition_amd.match import recall_at_k, pair_similarity
+    emb, cls = torch.tensor(G["n256_emb"]), torch.tensor(G["n256_classes"])
+    got = recall_at_k(emb, cls, (10, 100))
+    assert [got[10], got[100]] == [G["n256_recall10_counts"].tolist(), G["n256_recall100_counts"].tolist()]
+    pairs = G["n256_pairs"]
+    assert torch.allclose(pair_similarity(emb, pairs[:, 0], pairs[:, 1]), torch.tensor(G["n256_pair_scores"]), atol=1e-6)
+
+
+def test_swin_restatement_matches_reference_vectors():
+    import pets_face_recognition_amd.models as M
+    G = np.load(os.path.join(GOLD, "swin_t.npz"))
+    torch.manual_seed(int(G["seed"]))
+    m = M.swin_t(num_classes=512)
+    assert sum(p.numel() for p in m.parameters()) == int(G["n_params"])
+    assert sorted(m.state_dict().keys()) == list(G["keys"])
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(G["x_seed"])))
+    with torch.no_grad():
+        y = m(x)
+        s1 = m.stage1(x)
+    assert torch.allclose(y, torch.tensor(G["emb"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(s1[:, :8, :6, :6], torch.tensor(G["stage1_sample"]), rtol=1e-4, atol=1e-5)
+
+
+def test_resnet_restatement_self_checks():
+    """torchvision is absent: the ResNet oracle is 'parity unpinned' at that boundary; self-checks per SURVEY §8c"""
+    from oracle import resnet_ref
+    import pets_face_recognition_amd.models as M
+    for arch, nparam, nkeys in (("resnet50", 24557120, 320), ("resnet18", 11439168, 122)):
+        sd = resnet_ref.init_state_dict(arch, 512, seed=0)
+        assert len(sd) == nkeys
+        assert sum(v.numel() for k, v in sd.items() if k in resnet_ref.param_names(sd)) == nparam
+        m = getattr(M, arch)()
+        m.fc = torch.nn.Linear(m.fc.in_features, 512)
+        assert list(m.state_dict().keys()) == list(sd.keys())          # torchvision key names and order
+        m.load_state_dict(sd)
+    # product CPU path (plain torch.nn layers) == functional oracle
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    m.train()
+    new = {}
+    ref = resnet_ref.forward(sd, x, "resnet18", train=True, new_stats=new)
+    got = m(x)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(m.bn1.running_mean, new["bn1.running_mean"], atol=1e-6)
