@@ -111,7 +111,7 @@ static ColGeom col_geom(int C, int kp, size_t rows) {
   g.cw = cw;
   g.rl = 256 / cw;
   g.gy = (g.cpr + cw - 1) / cw;
-  size_t want = 2048 / g.gy;
+  size_t want = 1024 / g.gy;
   size_t maxb = (rows + g.rl * 4 - 1) / (g.rl * 4);  // at least 4 rows per lane
   if (want > maxb) want = maxb;
   if (want < 1) want = 1;
@@ -467,12 +467,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ coef,
                                                               int accumulate) {
-  __shared__ float l1[16][17], l2[16][17];
-  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  // block: 4 channels x 64 part-lanes (the partial rows are summed by many short strided loops in parallel)
+  __shared__ float l1[64][5], l2[64][5];
+  const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   float a = 0.f, b = 0.f;
   if (c < C)
-    for (int i = pl; i < nparts; i += 16) {
+    for (int i = pl; i < nparts; i += 64) {
       a += part[((size_t)i * 2 + 0) * C + c];
       b += part[((size_t)i * 2 + 1) * C + c];
     }
@@ -481,8 +482,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   __syncthreads();
   if (pl == 0 && c < C) {
     float sg = 0.f, sgx = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sg += l1[i][cl]; sgx += l2[i][cl]; }
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) { sg += l1[i][cl]; sgx += l2[i][cl]; }
     const float g = gamma ? gamma[c] : 1.f, is = invstd[c], mu = mean[c];
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sgx : sgx;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sg : sg;
@@ -499,7 +500,7 @@ extern "C" int pfr_bn_bwd_finalize(const float* part, int nparts, int C, float c
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                                    int accumulate, hipStream_t st) {
   PFR_CHECK_ARG(part && mean && invstd && coef, "pfr_bn_bwd_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, nparts, C, count, gamma, mean, invstd, dgamma, dbeta, coef, accumulate);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nparts, C, count, gamma, mean, invstd, dgamma, dbeta, coef, accumulate);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

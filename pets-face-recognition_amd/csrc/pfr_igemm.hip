@@ -37,34 +37,52 @@ struct IgemmParams {
   int tilesM, tilesN;
 };
 
-template <typename T, typename TO, int BQ, int BP, bool PRO>
+// tile geometry knobs: chunks of 16 B per LDS row per k-step, and LDS ring depth
+#ifndef PFR_IGEMM_KCH
+#define PFR_IGEMM_KCH 4
+#endif
+#ifndef PFR_IGEMM_NST
+#define PFR_IGEMM_NST 3
+#endif
+
+template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr int KP = DT<T>::KPACK;
-  constexpr int BK = KStep<T>::BK;
+  constexpr int KCH = PFR_IGEMM_KCH;           // 16-byte chunks per LDS row per k-step
+  constexpr int ROWB = KCH * 16;
+  constexpr int BK = KCH * KP;                 // k elements per k-step
+  constexpr int RPI = 64 / KCH;                // tile rows covered by one wave-wide DMA instruction
   constexpr int TP = BP / 64, TQ = BQ / 64;
-  constexpr int QCH = BQ / 64, PCH = BP / 64;  // 16-byte chunks per thread per k-step
-  constexpr int STAGE = (BP + BQ) * PFR_ROWB;
+  constexpr int QCH = BQ / (4 * RPI), PCH = BP / (4 * RPI);  // DMA instructions per thread per operand per k-step
+  constexpr int NLD = QCH + PCH;
+  constexpr int NST = PFR_IGEMM_NST;           // LDS ring depth: loads are issued NST-1 k-steps ahead of their use
+  constexpr int STAGE = (BP + BQ) * ROWB;
   constexpr int KPO = 16 / (int)sizeof(TO);
   constexpr int OROWB = BP * (int)sizeof(TO) + 16;
   constexpr int EPI = BQ * OROWB;
   constexpr int RED = 4 * BP * 2 * 4;
-  constexpr int SMEM = (2 * STAGE > EPI + RED) ? 2 * STAGE : EPI + RED;
+  constexpr int PROB = PRO ? 2 * 2048 * 4 : 0;  // fused-prologue coefficients (scale, shift) of up to 2048 channels
+  constexpr int SMEM = (NST * STAGE + PROB > EPI + RED) ? NST * STAGE + PROB : EPI + RED;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave >> 1, wq = wave & 1;
 
   const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = t % p.tilesN, tm = t / p.tilesN;
   const int m0 = tm * BQ, n0 = tn * BP;
 
-  const int cc = tid & 3, r0 = tid >> 2;
+  // staging geometry: wave w, pass j covers tile rows (j*4 + w)*RPI .. +RPI, lane l -> row l/KCH, physical chunk l%KCH;
+  // the logical (k) chunk it must fetch is phys ^ swizzle(row), which is the same for every pass j.
+  const int rsub = lane / KCH;
+  const int lc = (lane % KCH) ^ row_swizzle<KCH>(wave * RPI + rsub);
 
   // ---- per-row gather state for the activation (Q) operand
   int ihb[QCH], iwb[QCH], pixb[QCH];
 #pragma unroll
   for (int j = 0; j < QCH; ++j) {
-    const int m = m0 + r0 + 64 * j;
+    const int m = m0 + (j * 4 + wave) * RPI + rsub;
     if (m < p.M) {
       const uint32_t n_img = fdiv((uint32_t)m, p.div_ohow);
       const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
@@ -79,24 +97,94 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       pixb[j] = 0;
     }
   }
-  // ---- k-chunk -> (tap r, tap s, channel c) of this thread's chunk column
-  int kel = cc * KP;
+  // ---- k-chunk -> (tap r, tap s, channel c) walker of this thread's logical chunk column
+  int kel = lc * KP;
   int tap = kel / p.C;
   int c = kel - tap * p.C;
   int tr = tap / p.S;
   int ts = tap - tr * p.S;
 
-  const char* xb = reinterpret_cast<const char*>(p.x);
-  const char* wb = reinterpret_cast<const char*>(p.w);
   const int dmask = (1 << p.idil_log2) - 1;
+  const uint32_t OOB = 0xFFFFFF00u;  // beyond num_records: the buffer load returns (and the LDS-DMA writes) zeros
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.C * sizeof(T)), 0x00020000);
+  __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)((size_t)p.Cout * p.K * sizeof(T)), 0x00020000);
 
-  u32x4 qreg[QCH], preg[PCH];
-  float psc[PRO ? KP : 1], psh[PRO ? KP : 1];
-  uint32_t qok = 0;
+  float* pcoef = reinterpret_cast<float*>(smem + NST * STAGE);  // [2][C] scale, shift (PRO only)
+  if constexpr (PRO) {
+    for (int i = tid; i < p.C; i += 256) {
+      pcoef[i] = p.pro_scale[i];
+      pcoef[p.C + i] = p.pro_shift[i];
+    }
+  }
 
-  auto gload = [&]() {
+  // validity masks / channel offsets of the (up to two) k-steps in flight, consumed by the prologue fix-up
+  uint32_t okA = 0, okB = 0;
+  int cA = 0, cB = 0;
+
+  // FAST path (C % BK == 0, every conv but the stem): within a k-step the tap (r,s) is uniform over the workgroup, so
+  // the per-row gather offsets are recomputed only when the tap changes (every C/BK k-steps, select-based, no divergent
+  // branches) and a k-step costs one v_add per DMA.  Invalid rows carry an offset that stays out of range.
+  const uint32_t OOBB = 0xF0000000u;
+  uint32_t qbase[QCH], wbase[PCH];
+  uint32_t okcur = 0;
+  int u_tr = 0, u_ts = 0, cbyte = 0, kbyte = 0;  // uniform (scalar) walker state
+  auto newtap = [&]() {
+    okcur = 0;
+#pragma unroll
+    for (int j = 0; j < QCH; ++j) {
+      int ih = ihb[j] + u_tr, iw = iwb[j] + u_ts;
+      bool ok = (((ih | iw) & dmask) == 0);
+      ih >>= p.idil_log2;
+      iw >>= p.idil_log2;
+      ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W) && (u_tr < p.R);
+      const uint32_t off = (uint32_t)(((pixb[j] + ih * p.W + iw) * p.C + lc * KP) * (int)sizeof(T));
+      qbase[j] = ok ? off : OOBB;
+      okcur |= ok ? (1u << j) : 0u;
+    }
+  };
+  if constexpr (FAST) {
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int row = n0 + (j * 4 + wave) * RPI + rsub;
+      wbase[j] = row < p.Cout ? (uint32_t)(((size_t)row * p.K + lc * KP) * sizeof(T)) : OOBB;
+    }
+    newtap();
+  }
+
+  // issues the LDS-DMA of one k-step into ring slot `buf` (weights + gathered activations, zero-filled when invalid)
+  auto gload = [&](int buf) {
+    char* base = smem + buf * STAGE;
+    if constexpr (FAST) {
+#pragma unroll
+      for (int j = 0; j < PCH; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * 4 + wave) * RPI * ROWB),
+                                                 16, (int)(wbase[j] + (uint32_t)kbyte), 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < QCH; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * 4 + wave) * RPI) * ROWB),
+                                                 16, (int)(qbase[j] + (uint32_t)cbyte), 0, 0, 0);
+      okA = okB; cA = cB;
+      okB = okcur; cB = cbyte / (int)sizeof(T) + lc * KP;
+      kbyte += BK * (int)sizeof(T);
+      cbyte += BK * (int)sizeof(T);
+      if (cbyte >= p.C * (int)sizeof(T)) {
+        cbyte = 0;
+        if (++u_ts == p.S) { u_ts = 0; ++u_tr; }
+        newtap();
+      }
+      return;
+    }
     const bool kok = kel < p.K;
-    qok = 0;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int row = n0 + (j * 4 + wave) * RPI + rsub;
+      const uint32_t off = (kok && row < p.Cout) ? (uint32_t)(((size_t)row * p.K + kel) * sizeof(T)) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * 4 + wave) * RPI * ROWB),
+                                               16, (int)off, 0, 0, 0);
+    }
+    uint32_t okm = 0;
 #pragma unroll
     for (int j = 0; j < QCH; ++j) {
       int ih = ihb[j] + tr, iw = iwb[j] + ts;
@@ -104,32 +192,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       ih >>= p.idil_log2;
       iw >>= p.idil_log2;
       ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) {
-        const size_t off = ((size_t)(pixb[j] + ih * p.W + iw) * p.C + c) * sizeof(T);
-        v = ld16(xb + off);
-        qok |= 1u << j;
-      }
-      qreg[j] = v;
+      const uint32_t off = ok ? (uint32_t)(((size_t)(pixb[j] + ih * p.W + iw) * p.C + c) * sizeof(T)) : OOB;
+      if (ok) okm |= 1u << j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * 4 + wave) * RPI) * ROWB),
+                                               16, (int)off, 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < PCH; ++j) {
-      const int row = n0 + r0 + 64 * j;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (kok && row < p.Cout) v = ld16(wb + ((size_t)row * p.K + kel) * sizeof(T));
-      preg[j] = v;
-    }
-    if constexpr (PRO) {
-      if (kok) {
-#pragma unroll
-        for (int e = 0; e < KP; e += 4) {
-          f32x4 a = *reinterpret_cast<const f32x4*>(p.pro_scale + c + e);
-          f32x4 b = *reinterpret_cast<const f32x4*>(p.pro_shift + c + e);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { psc[e + u] = a[u]; psh[e + u] = b[u]; }
-        }
-      }
-    }
+    okA = okB; cA = cB;
+    okB = okm; cB = c;
     // advance to the next k-step
     kel += BK;
     c += BK;
@@ -139,26 +208,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  auto lstore = [&](int buf) {
-    char* base = smem + buf * STAGE;
+  // fused prologue: BN-apply(+ReLU) IN PLACE on this thread's own (already landed) activation chunks of ring slot `buf`;
+  // padding / out-of-range chunks stay exactly zero.  (okm, cc) describe that k-step.
+  auto fixup = [&](int buf, uint32_t okm, int cc) {
+    if constexpr (PRO) {
+      char* base = smem + buf * STAGE;
+      float sc[KP], sh[KP];
 #pragma unroll
-    for (int j = 0; j < PCH; ++j) st16(base + (r0 + 64 * j) * PFR_ROWB + cc * 16, preg[j]);
+      for (int e = 0; e < KP; e += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pcoef + cc + e);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pcoef + p.C + cc + e);
 #pragma unroll
-    for (int j = 0; j < QCH; ++j) {
-      u32x4 v = qreg[j];
-      if constexpr (PRO) {
-        if (qok & (1u << j)) {
+        for (int u = 0; u < 4; ++u) { sc[e + u] = a[u]; sh[e + u] = b[u]; }
+      }
+#pragma unroll
+      for (int j = 0; j < QCH; ++j) {
+        if (okm & (1u << j)) {
+          char* ptr = base + (BP + (j * 4 + wave) * RPI + rsub) * ROWB + (lane % KCH) * 16;
           float f[KP];
-          Chunk<T>::unpack(v, f);
+          Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(ptr), f);
 #pragma unroll
           for (int e = 0; e < KP; ++e) {
-            float z = fmaf(f[e], psc[e], psh[e]);
+            const float z = fmaf(f[e], sc[e], sh[e]);
             f[e] = p.pro_relu ? fmaxf(z, 0.f) : z;
           }
-          v = Chunk<T>::pack(f);
+          st16(ptr, Chunk<T>::pack(f));
         }
       }
-      st16(base + (BP + r0 + 64 * j) * PFR_ROWB + cc * 16, v);
     }
   };
 
@@ -170,17 +246,38 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // ---- NST-slot ring with counted waits: with NST = 3 the DMA of k-step kt+2 stays in flight across the barrier that
+  //      publishes kt+1 (raw s_barrier: no implicit vmcnt(0) drain); NST = 2 is the classic double buffer.
   const int nk = (p.K + BK - 1) / BK;
-  gload();
-  lstore(0);
-  __syncthreads();
+  gload(0);
+  if (NST == 3 && nk > 1) {
+    gload(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    if constexpr (PRO) { __syncthreads(); }  // coefficients visible
+    fixup(0, okA, cA);
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PRO) { __syncthreads(); }
+    fixup(0, okB, cB);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload();
-    const char* base = smem + buf * STAGE;
-    mma_kstep<T, TP, TQ>(base + (wp * (BP / 2)) * PFR_ROWB, base + (BP + wq * (BQ / 2)) * PFR_ROWB, lane, acc);
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
+    const int slot = kt % NST;
+    if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
+    const char* base = smem + slot * STAGE;
+    mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / 2)) * ROWB, base + (BP + wq * (BQ / 2)) * ROWB, lane, acc);
+    if (kt + 1 < nk) {
+      if (NST == 3 && kt + 2 < nk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        fixup((kt + 1) % NST, okA, cA);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fixup((kt + 1) % NST, okB, cB);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- epilogue phase 1: accumulators -> LDS tile [BQ rows m][BP couts] of TO
@@ -310,10 +407,14 @@ static int launch_tile(IgemmParams& p, hipStream_t st) {
   p.tilesM = (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
   const dim3 grid((unsigned)(p.tilesM * p.tilesN));
-  if (p.pro_scale)
-    hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true>), grid, dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false>), grid, dim3(256), 0, st, p);
+  const bool fast = (p.C % (PFR_IGEMM_KCH * DT<T>::KPACK)) == 0;
+  if (p.pro_scale) {
+    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, false>), grid, dim3(256), 0, st, p);
+  }
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
@@ -350,7 +451,7 @@ extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, 
   PFR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && R > 0 && S > 0 && OH > 0 && OW > 0 && stride > 0,
                 "pfr_conv2d_fwd: bad geometry");
   PFR_CHECK_ARG((long)N * OH * OW < (1L << 31) && (long)N * H * W * C < (1L << 31), "pfr_conv2d_fwd: tensor too large");
-  PFR_CHECK_ARG(!pro_scale || (C % 4 == 0 && pro_shift), "pfr_conv2d_fwd: prologue needs scale and shift");
+  PFR_CHECK_ARG(!pro_scale || (C % 4 == 0 && pro_shift && C <= 2048), "pfr_conv2d_fwd: prologue needs scale and shift, C <= 2048");
   IgemmParams p;
   p.x = x; p.w = w; p.y = y;
   p.N = N; p.H = H; p.W = W; p.C = C;

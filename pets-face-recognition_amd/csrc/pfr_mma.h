@@ -54,3 +54,55 @@ __device__ __forceinline__ void mma_kstep(const char* ldsP, const char* ldsQ, in
 
 // accumulator element (reg r of a 32x32 tile) -> row within the tile; column is lane & 31.
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ------------------------------------------------------------------------------------------------
+// v2 operand tiles: UNPADDED rows of KCH 16-byte chunks of k-values per k-step (KCH = 8: 128 B = 64 bf16 / 32 f32;
+// KCH = 4: 64 B), chunk position XOR-swizzled with row bits:
+//     KCH = 8: phys_chunk = chunk ^ ((row >> 1) & 7)        KCH = 4: phys_chunk = chunk ^ ((row >> 2) & 3)
+// Unpadded rows are what the LDS-DMA path (buffer_load … lds: wave-uniform base + lane*16) needs; the swizzle makes the
+// 16-lane groups of ds_read_b128 (rows {0-3,12-15,20-27}+k) hit 16 distinct 4-bank slots (conflict free), and it is
+// applied on the SOURCE address of the DMA (each lane group still reads one whole contiguous row segment).
+template <int KCH> __device__ __forceinline__ int row_swizzle(int row) {
+  return KCH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
+template <typename T, int KCH, int TP, int TQ>
+__device__ __forceinline__ void mma_kstep_sw(const char* ldsP, const char* ldsQ, int lane, f32x16 (&acc)[TP][TQ]) {
+  // ldsP / ldsQ: row 0 of this wave's slice (slice bases are multiples of 16 rows, so the swizzle depends on lane only).
+  // Fragments of k-group kg+1 are read while the MFMAs of k-group kg run (explicit register double buffering).
+  constexpr int ROWB = KCH * 16;
+  constexpr int NKG = KCH / 2;
+  const int row = lane & 31, half = lane >> 5;
+  const int sw = row_swizzle<KCH>(row);
+  u32x4 fp[2][TP], fq[2][TQ];
+  auto rd = [&](int kg, int b) {
+    const int off = (((kg * 2 + half) ^ sw) << 4);
+#pragma unroll
+    for (int i = 0; i < TP; ++i) fp[b][i] = *reinterpret_cast<const u32x4*>(ldsP + (i * 32 + row) * ROWB + off);
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) fq[b][j] = *reinterpret_cast<const u32x4*>(ldsQ + (j * 32 + row) * ROWB + off);
+  };
+  rd(0, 0);
+#pragma unroll
+  for (int kg = 0; kg < NKG; ++kg) {
+    const int b = kg & 1;
+    if (kg + 1 < NKG) rd(kg + 1, b ^ 1);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fp[b][i]),
+                                                               __builtin_bit_cast(bf16x8, fq[b][j]), acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fp[b][i][e]), __uint_as_float(fq[b][j][e]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+  }
+}

@@ -67,6 +67,11 @@ class FEEngine:
         self.model_id = id(model)
         self.fc_id = id(model.fc)
         self.plans = {}
+        # Fusing BN-apply+ReLU into the CONSUMER conv's operand prologue saves one write+read of the normalised
+        # activation, but the transform is then repeated for every tap and every Cout tile (18x for a 3x3 256->256
+        # conv): measured on MI355X it costs ~2x the kernel time, far more than the single elementwise pass it saves.
+        # Default: materialise z = relu(BN(c)) once (pfr_bn_act); PFR_FUSE_PROLOGUE=1 re-enables the fused form.
+        self.fuse_prologue = os.environ.get("PFR_FUSE_PROLOGUE", "0") == "1"
         self.grad_ready_hook = None     # callable(lo, hi): flat-grad range [lo, hi) is final (DDP bucket hook)
         self.bucket_elems = 6 * 1024 * 1024
         self._adopt(model)
@@ -319,13 +324,24 @@ class FEEngine:
         for convs, down in self.blocks:
             xin, xshape = cur, cshape
             raws = []
+            acts = []      # materialised relu(BN(c)) of the inner convs (None when fused into the consumer's prologue)
             pro = None
             src, sshape = xin, xshape
-            for (c, bn) in convs:
+            for ci, (c, bn) in enumerate(convs):
                 y, yshape = self._conv_bn(plan, ops, src, sshape, c, bn, train, pro=pro)
                 raws.append((y, yshape))
-                pro = (bn.coef[2], bn.coef[3])
-                src, sshape = y, yshape
+                if ci + 1 < len(convs) and not self.fuse_prologue:
+                    z = self._A(plan, yshape)
+                    ops.append((lib.pfr_bn_act, (y.data_ptr(), bn.coef[2].data_ptr(), bn.coef[3].data_ptr(), 0, 0, 0,
+                                                 z.data_ptr(), self.did, yshape[0] * yshape[1] * yshape[2], yshape[3], 1)))
+                    acts.append(z)
+                    pro = None
+                    src, sshape = z, yshape
+                else:
+                    acts.append(None)
+                    pro = (bn.coef[2], bn.coef[3])
+                    src, sshape = y, yshape
+            src = raws[-1][0]
             lastc, lastbn = convs[-1]
             out = self._A(plan, sshape)
             rows = sshape[0] * sshape[1] * sshape[2]
@@ -339,7 +355,7 @@ class FEEngine:
             else:
                 ops.append((lib.pfr_bn_act, (src.data_ptr(), lastbn.coef[2].data_ptr(), lastbn.coef[3].data_ptr(),
                                              xin.data_ptr(), 0, 0, out.data_ptr(), self.did, rows, sshape[3], 1)))
-            bsaved.append((xin, xshape, raws, cd, out, sshape))
+            bsaved.append((xin, xshape, raws, cd, out, sshape, acts))
             cur, cshape = out, sshape
         # ---- global average pool + fc
         Nn, Hh, Ww, Cf = cshape
@@ -418,7 +434,7 @@ class FEEngine:
         ops.append((lib.pfr_avgpool_bwd, (dgap.data_ptr(), dcur.data_ptr(), self.did, N, Hh * Ww, Cf)))
         release(dgap)
         # blocks in reverse
-        for (convs, down), (xin, xshape, raws, cd, out, oshape) in zip(reversed(self.blocks), reversed(bsaved)):
+        for (convs, down), (xin, xshape, raws, cd, out, oshape, acts) in zip(reversed(self.blocks), reversed(bsaved)):
             lastc, lastbn = convs[-1]
             ylast, _ = raws[-1]
             gres = G(oshape)
@@ -429,7 +445,10 @@ class FEEngine:
                 c, bn = convs[i]
                 pc, pbn = convs[i - 1]
                 xraw, xrs = raws[i - 1]
-                wgrad(xraw, xrs, dy, dyshape, c, pro=(pbn.coef[2], pbn.coef[3]))
+                if acts[i - 1] is not None:
+                    wgrad(acts[i - 1], xrs, dy, dyshape, c)
+                else:
+                    wgrad(xraw, xrs, dy, dyshape, c, pro=(pbn.coef[2], pbn.coef[3]))
                 dz = G(xrs)
                 dgrad(dy, dyshape, c, dz, xrs)
                 release(dy)
