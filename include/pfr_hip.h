@@ -47,8 +47,8 @@ int pfr_device_arch(char* buf, int buflen);
  *   bias [Cout] fp32 or NULL; accumulate: y += result; out_relu: y = max(y,0)
  *   pro_scale/pro_shift [C] fp32 or NULL: operand is relu?(scale[c]*x + shift[c]) (fused BN-apply of the producer)
  *   stats_part or NULL: fp32 [ceil(M/mtile)][2][Cout] per-channel (mean, M2 = Σ(y-mean)²) of each m-tile of the stored y,
- *   mtile = pfr_conv2d_mtile(M, Cout)  (input of pfr_bn_finalize; deterministic, no atomics). */
-int pfr_conv2d_mtile(int M, int Cout);
+ *   mtile = pfr_conv2d_mtile(M, Cout, R*S*C, dtype, out_dtype)  (input of pfr_bn_finalize; deterministic, no atomics). */
+int pfr_conv2d_mtile(int M, int Cout, int K, int dtype, int out_dtype); /* K = R*S*C */
 int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W, int C,
                    int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int ldy,
                    const float* bias, int accumulate, int out_relu, const float* pro_scale, const float* pro_shift,

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 ARCH=gfx950
-FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast -DPFR_IGEMM_KCH=4 -DPFR_IGEMM_NST=2"
+FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast"
 mkdir -p build
 pids=()
 for f in pfr_api pfr_igemm pfr_wgrad pfr_elementwise pfr_head pfr_match; do

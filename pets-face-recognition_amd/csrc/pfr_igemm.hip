@@ -17,6 +17,7 @@
 // sum / sum-of-squares partials for the FOLLOWING train-mode BatchNorm produced from the same LDS tile
 // (deterministic: one partial row per m-tile, no atomics), XCD-aware tile order (n-tiles of one m-tile adjacent).
 #include "pfr_mma.h"
+#include <stdlib.h>
 
 struct IgemmParams {
   const void* x;
@@ -39,35 +40,39 @@ struct IgemmParams {
 
 // tile geometry knobs: chunks of 16 B per LDS row per k-step, and LDS ring depth
 #ifndef PFR_IGEMM_KCH
-#define PFR_IGEMM_KCH 4
+#define PFR_IGEMM_KCH 8
 #endif
 #ifndef PFR_IGEMM_NST
-#define PFR_IGEMM_NST 3
+#define PFR_IGEMM_NST 2
 #endif
 
-template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP>
+__global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   constexpr int KP = DT<T>::KPACK;
-  constexpr int KCH = PFR_IGEMM_KCH;           // 16-byte chunks per LDS row per k-step
+  constexpr int KCH = KCH_;                    // 16-byte chunks per LDS row per k-step (4: 64-B rows, 8: 128-B rows)
   constexpr int ROWB = KCH * 16;
   constexpr int BK = KCH * KP;                 // k elements per k-step
   constexpr int RPI = 64 / KCH;                // tile rows covered by one wave-wide DMA instruction
-  constexpr int TP = BP / 64, TQ = BQ / 64;
-  constexpr int QCH = BQ / (4 * RPI), PCH = BP / (4 * RPI);  // DMA instructions per thread per operand per k-step
+  constexpr int NT = NW * 64;                  // threads: NW waves in a WP x WQ grid over (couts, rows)
+  constexpr int WQ = NW / WP;
+  constexpr int TP = BP / (WP * 32), TQ = BQ / (WQ * 32);  // 32x32 accumulator tiles per wave
+  constexpr int QCH = BQ / (NW * RPI), PCH = BP / (NW * RPI);  // DMA instructions per thread per operand per k-step
+  static_assert(TP >= 1 && TQ >= 1 && QCH >= 1 && PCH >= 1, "tile too small for this wave grid");
   constexpr int NLD = QCH + PCH;
   constexpr int NST = PFR_IGEMM_NST;           // LDS ring depth: loads are issued NST-1 k-steps ahead of their use
   constexpr int STAGE = (BP + BQ) * ROWB;
   constexpr int KPO = 16 / (int)sizeof(TO);
   constexpr int OROWB = BP * (int)sizeof(TO) + 16;
   constexpr int EPI = BQ * OROWB;
-  constexpr int RED = 4 * BP * 2 * 4;
+  constexpr int RED = NW * BP * 2 * 4;
   constexpr int PROB = PRO ? 2 * 2048 * 4 : 0;  // fused-prologue coefficients (scale, shift) of up to 2048 channels
   constexpr int SMEM = (NST * STAGE + PROB > EPI + RED) ? NST * STAGE + PROB : EPI + RED;
+  static_assert(SMEM <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wave >> 1, wq = wave & 1;
+  const int wp = wave / WQ, wq = wave % WQ;
 
   const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = t % p.tilesN, tm = t / p.tilesN;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   int ihb[QCH], iwb[QCH], pixb[QCH];
 #pragma unroll
   for (int j = 0; j < QCH; ++j) {
-    const int m = m0 + (j * 4 + wave) * RPI + rsub;
+    const int m = m0 + (j * NW + wave) * RPI + rsub;
     if (m < p.M) {
       const uint32_t n_img = fdiv((uint32_t)m, p.div_ohow);
       const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   float* pcoef = reinterpret_cast<float*>(smem + NST * STAGE);  // [2][C] scale, shift (PRO only)
   if constexpr (PRO) {
-    for (int i = tid; i < p.C; i += 256) {
+    for (int i = tid; i < p.C; i += NT) {
       pcoef[i] = p.pro_scale[i];
       pcoef[p.C + i] = p.pro_shift[i];
     }
@@ -144,12 +149,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       okcur |= ok ? (1u << j) : 0u;
     }
   };
+  // optional k-loop rotation (-DPFR_KROT): workgroup (tm,tn) starts its reduction at a different k-step and wraps.
+  // Measured: it HURTS (c3x3 256ch 14x14: 80 → 104 µs) — lock-step workgroups sharing one L2 fetch of the same weight
+  // k-slice is a benefit, not a hot spot.  Kept only as an experiment switch.
+  const int nk_all = (p.K + BK - 1) / BK;
+  int kwrap = 0;  // k-steps until the walker wraps to k = 0
   if constexpr (FAST) {
 #pragma unroll
     for (int j = 0; j < PCH; ++j) {
-      const int row = n0 + (j * 4 + wave) * RPI + rsub;
+      const int row = n0 + (j * NW + wave) * RPI + rsub;
       wbase[j] = row < p.Cout ? (uint32_t)(((size_t)row * p.K + lc * KP) * sizeof(T)) : OOBB;
     }
+#ifdef PFR_KROT
+    const int kstart = (int)(((unsigned)tm * 5u + (unsigned)tn * 3u) % (unsigned)nk_all);
+#else
+    const int kstart = 0;
+#endif
+    const int spt = p.C / BK;          // k-steps per tap
+    const int tap0 = kstart / spt;
+    u_tr = tap0 / p.S;
+    u_ts = tap0 - u_tr * p.S;
+    cbyte = (kstart - tap0 * spt) * BK * (int)sizeof(T);
+    kbyte = kstart * BK * (int)sizeof(T);
+    kwrap = nk_all - kstart;
     newtap();
   }
 
@@ -159,17 +181,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     if constexpr (FAST) {
 #pragma unroll
       for (int j = 0; j < PCH; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * 4 + wave) * RPI * ROWB),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * NW + wave) * RPI * ROWB),
                                                  16, (int)(wbase[j] + (uint32_t)kbyte), 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < QCH; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * 4 + wave) * RPI) * ROWB),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * NW + wave) * RPI) * ROWB),
                                                  16, (int)(qbase[j] + (uint32_t)cbyte), 0, 0, 0);
       okA = okB; cA = cB;
       okB = okcur; cB = cbyte / (int)sizeof(T) + lc * KP;
       kbyte += BK * (int)sizeof(T);
       cbyte += BK * (int)sizeof(T);
-      if (cbyte >= p.C * (int)sizeof(T)) {
+      if (--kwrap == 0) {  // wrap the rotated reduction back to k = 0
+        kbyte = 0; cbyte = 0; u_tr = 0; u_ts = 0;
+        newtap();
+      } else if (cbyte >= p.C * (int)sizeof(T)) {
         cbyte = 0;
         if (++u_ts == p.S) { u_ts = 0; ++u_tr; }
         newtap();
@@ -179,9 +204,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const bool kok = kel < p.K;
 #pragma unroll
     for (int j = 0; j < PCH; ++j) {
-      const int row = n0 + (j * 4 + wave) * RPI + rsub;
+      const int row = n0 + (j * NW + wave) * RPI + rsub;
       const uint32_t off = (kok && row < p.Cout) ? (uint32_t)(((size_t)row * p.K + kel) * sizeof(T)) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * 4 + wave) * RPI * ROWB),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * NW + wave) * RPI * ROWB),
                                                16, (int)off, 0, 0, 0);
     }
     uint32_t okm = 0;
@@ -194,7 +219,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
       const uint32_t off = ok ? (uint32_t)(((size_t)(pixb[j] + ih * p.W + iw) * p.C + c) * sizeof(T)) : OOB;
       if (ok) okm |= 1u << j;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * 4 + wave) * RPI) * ROWB),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * NW + wave) * RPI) * ROWB),
                                                16, (int)off, 0, 0, 0);
     }
     okA = okB; cA = cB;
@@ -224,7 +249,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int j = 0; j < QCH; ++j) {
         if (okm & (1u << j)) {
-          char* ptr = base + (BP + (j * 4 + wave) * RPI + rsub) * ROWB + (lane % KCH) * 16;
+          char* ptr = base + (BP + (j * NW + wave) * RPI + rsub) * ROWB + (lane % KCH) * 16;
           float f[KP];
           Chunk<T>::unpack(*reinterpret_cast<const u32x4*>(ptr), f);
 #pragma unroll
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   // ---- NST-slot ring with counted waits: with NST = 3 the DMA of k-step kt+2 stays in flight across the barrier that
   //      publishes kt+1 (raw s_barrier: no implicit vmcnt(0) drain); NST = 2 is the classic double buffer.
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk = nk_all;
   gload(0);
   if (NST == 3 && nk > 1) {
     gload(1);
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const int slot = kt % NST;
     if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
     const char* base = smem + slot * STAGE;
-    mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / 2)) * ROWB, base + (BP + wq * (BQ / 2)) * ROWB, lane, acc);
+    mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc);
     if (kt + 1 < nk) {
       if (NST == 3 && kt + 2 < nk) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
@@ -285,10 +310,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   for (int i = 0; i < TP; ++i)
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
-      const int mrow = wq * (BQ / 2) + j * 32 + (lane & 31);
+      const int mrow = wq * (BQ / WQ) + j * 32 + (lane & 31);
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        const int co = wp * (BP / 2) + i * 32 + 8 * qd + 4 * (lane >> 5);
+        const int co = wp * (BP / WP) + i * 32 + 8 * qd + 4 * (lane >> 5);
         char* dst = smem + mrow * OROWB + co * (int)sizeof(TO);
         if constexpr (sizeof(TO) == 4) {
           f32x4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
@@ -307,7 +332,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   // ---- epilogue phase 2: row-major 16-byte chunks: bias / accumulate / relu / BN partial sums / store
   constexpr int CPR = BP * (int)sizeof(TO) / 16;  // chunks per output row
-  constexpr int RPP = 256 / CPR;                  // rows per pass
+  constexpr int RPP = NT / CPR;                   // rows per pass
+  static_assert(CPR <= 64, "statistics reduction assumes <= 64 chunks per row");
   const int oc = tid % CPR, rl = tid / CPR;
   const int co = n0 + oc * KPO;
   float s1[KPO], s2[KPO], bia[KPO], kshift[KPO];
@@ -376,7 +402,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         s1[e] += __shfl_xor(s1[e], o, 64);
         s2[e] += __shfl_xor(s2[e], o, 64);
       }
-    float* red = reinterpret_cast<float*>(smem + EPI);  // [4 waves][2][BP]
+    float* red = reinterpret_cast<float*>(smem + EPI);  // [NW waves][2][BP]
     if (lane < CPR) {
 #pragma unroll
       for (int e = 0; e < KPO; ++e) {
@@ -389,7 +415,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       const int ch = tid;
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < NW; ++w) {
         a += red[(w * 2 + 0) * BP + ch];
         b += red[(w * 2 + 1) * BP + ch];
       }
@@ -402,42 +428,72 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename TO, int BQ, int BP>
-static int launch_tile(IgemmParams& p, hipStream_t st) {
+template <typename T, typename TO, int BQ, int BP, int KCH, int NW, int WP>
+static int launch_tile_k(IgemmParams& p, hipStream_t st) {
   p.tilesM = (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
-  const dim3 grid((unsigned)(p.tilesM * p.tilesN));
-  const bool fast = (p.C % (PFR_IGEMM_KCH * DT<T>::KPACK)) == 0;
+  const dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(NW * 64);
+  const bool fast = (p.C % (KCH * DT<T>::KPACK)) == 0;
   if (p.pro_scale) {
-    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, false>), grid, dim3(256), 0, st, p);
+    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, true, KCH, NW, WP>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, false, KCH, NW, WP>), grid, block, 0, st, p);
   } else {
-    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, false>), grid, dim3(256), 0, st, p);
+    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true, KCH, NW, WP>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, false, KCH, NW, WP>), grid, block, 0, st, p);
   }
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
 
-// m-tile height the launcher will pick (the caller sizes stats_part with it)
-static int pick_bq(int M, int Cout) {
+// k-step width: 128-byte rows (16 MFMAs per barrier) pay off for long reductions; short / bandwidth-bound layers
+// (K = 64 … 256) run better with 64-byte rows and more resident workgroups.
+template <typename T, typename TO, int BQ, int BP>
+static int launch_tile(IgemmParams& p, hipStream_t st) {
+  if (p.K >= 512 && p.C % (8 * DT<T>::KPACK) == 0) return launch_tile_k<T, TO, BQ, BP, 8, 4, 2>(p, st);
+  return launch_tile_k<T, TO, BQ, BP, 4, 4, 2>(p, st);
+}
+
+// Tile choice.  Long reductions with many output channels use 8-wave 256-row tiles (256x256 / 256x128: twice / 1.33x
+// the FLOPs per byte staged through LDS of the 128x128 tile); everything else the 4-wave tiles.
+// Returns the m-tile height (also what the caller sizes stats_part with) and the variant id.
+enum { TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x256, TILE_256x128 };
+static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) {
+  const char* force = getenv("PFR_IGEMM_BIG");
+  const bool allow_big = !(force && force[0] == '0');
+  if (allow_big && dtype == PFR_BF16 && out_dtype == PFR_BF16 && K >= 512 && (K % 64) == 0) {
+    const long t256 = (long)((M + 255) / 256);
+    if (Cout >= 256 && t256 * ((Cout + 255) / 256) >= 160) { *bq = 256; return TILE_256x256; }
+    if (Cout >= 128 && t256 * ((Cout + 127) / 128) >= 320) { *bq = 256; return TILE_256x128; }
+  }
   const int bp = Cout >= 128 ? 128 : 64;
   const long tiles128 = (long)((M + 127) / 128) * ((Cout + bp - 1) / bp);
-  return tiles128 >= 512 ? 128 : 64;
+  const int b = tiles128 >= 512 ? 128 : 64;
+  *bq = b;
+  if (Cout >= 128) return b == 128 ? TILE_128x128 : TILE_64x128;
+  return b == 128 ? TILE_128x64 : TILE_64x64;
 }
 
 template <typename T, typename TO>
-static int launch_igemm(IgemmParams& p, hipStream_t st) {
-  const int bq = pick_bq(p.M, p.Cout);
-  if (p.Cout >= 128) {
-    if (bq == 128) return launch_tile<T, TO, 128, 128>(p, st);
-    return launch_tile<T, TO, 64, 128>(p, st);
+static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
+  int bq;
+  const int v = pick_tile(p.M, p.Cout, p.K, dtype, out_dtype, &bq);
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+    if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 8, 8, 2>(p, st);
+    if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 8, 8, 2>(p, st);
   }
-  if (bq == 128) return launch_tile<T, TO, 128, 64>(p, st);
-  return launch_tile<T, TO, 64, 64>(p, st);
+  switch (v) {
+    case TILE_128x128: return launch_tile<T, TO, 128, 128>(p, st);
+    case TILE_64x128: return launch_tile<T, TO, 64, 128>(p, st);
+    case TILE_128x64: return launch_tile<T, TO, 128, 64>(p, st);
+    default: return launch_tile<T, TO, 64, 64>(p, st);
+  }
 }
 
-extern "C" int pfr_conv2d_mtile(int M, int Cout) { return pick_bq(M, Cout); }
+extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int dtype, int out_dtype) {
+  int bq;
+  pick_tile(M, Cout, K, dtype, out_dtype, &bq);
+  return bq;
+}
 
 extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
                               int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
@@ -463,8 +519,8 @@ extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, 
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
   if (dtype == PFR_BF16) {
-    if (out_dtype == PFR_BF16) return launch_igemm<bf16_t, bf16_t>(p, stream);
-    return launch_igemm<bf16_t, float>(p, stream);
+    if (out_dtype == PFR_BF16) return launch_igemm<bf16_t, bf16_t>(p, dtype, out_dtype, stream);
+    return launch_igemm<bf16_t, float>(p, dtype, out_dtype, stream);
   }
-  return launch_igemm<float, float>(p, stream);
+  return launch_igemm<float, float>(p, dtype, out_dtype, stream);
 }

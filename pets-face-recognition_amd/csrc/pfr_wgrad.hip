@@ -212,24 +212,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n, int splits,
-                                    float scale, int accumulate) {
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 4 <= n) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) a += *reinterpret_cast<const f32x4*>(part + (size_t)s * n + i);
-    a *= scale;
-    if (accumulate) a += *reinterpret_cast<const f32x4*>(dw + i);
-    *reinterpret_cast<f32x4*>(dw + i) = a;
-  } else {
-    for (size_t k = i; k < n; ++k) {
-      float a = 0.f;
-      for (int s = 0; s < splits; ++s) a += part[(size_t)s * n + k];
-      a *= scale;
-      if (accumulate) a += dw[k];
-      dw[k] = a;
+// sums the split slabs: block = 64 columns (of 4 floats) x 4 split-lanes; every lane keeps 4 independent loads in flight
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4,
+                                                           int splits, float scale, int accumulate) {
+  __shared__ f32x4 red[4][64];
+  const int cx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + cx;  // index of a 4-float group
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (i < n4) {
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + i;
+    int s = sl;
+    for (; s + 12 < splits; s += 16) {
+      a0 += p4[(size_t)s * n4];
+      a1 += p4[(size_t)(s + 4) * n4];
+      a2 += p4[(size_t)(s + 8) * n4];
+      a3 += p4[(size_t)(s + 12) * n4];
     }
+    for (; s < splits; s += 4) a0 += p4[(size_t)s * n4];
+  }
+  red[sl][cx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    f32x4 a = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+    a *= scale;
+    f32x4* o = reinterpret_cast<f32x4*>(dw) + i;
+    if (accumulate) a += *o;
+    *o = a;
   }
 }
 
@@ -302,9 +310,9 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
 #undef PFR_WG_DISPATCH
   if (rc != PFR_OK) return rc;
   if (!direct) {
-    const size_t n = (size_t)Cout * p.KK;
-    const unsigned blocks = (unsigned)((n / 4 + 256) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, n, p.splits, scale, accumulate);
+    const size_t n4 = (size_t)Cout * p.KK / 4;  // Cout*KK is a multiple of 16 (both are multiples of the 16-byte chunk)
+    const unsigned blocks = (unsigned)((n4 + 63) / 64);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, n4, p.splits, scale, accumulate);
     PFR_CHECK_LAUNCH();
   }
   return PFR_OK;

@@ -270,16 +270,16 @@ class FEEngine:
                                          0 if bias is None else bias.data_ptr(), accumulate, 0, ps, psh, prelu,
                                          0 if part is None else part.data_ptr())))
 
-    def _stats_buf(self, plan, M, Cout):
-        mt = lib.pfr_conv2d_mtile(M, Cout)
+    def _stats_buf(self, plan, M, Cout, K):
+        mt = lib.pfr_conv2d_mtile(M, Cout, K, self.did, self.did)
         nt = (M + mt - 1) // mt
-        return self._A(plan, (nt, 2, Cout), torch.float32), nt
+        return self._A(plan, (nt, 2, Cout), torch.float32), nt, mt
 
-    def _bn_fwd(self, ops, bn, part, nparts, count, train):
+    def _bn_fwd(self, ops, bn, part, nparts, count, train, mt=0):
         if train:
             nws = lib.pfr_bn_finalize_ws_floats(nparts, bn.C)
             assert nws <= self.bn_ws.numel()
-            ops.append((lib.pfr_bn_finalize, (part.data_ptr(), nparts, lib.pfr_conv2d_mtile(int(count), bn.C), bn.C,
+            ops.append((lib.pfr_bn_finalize, (part.data_ptr(), nparts, mt, bn.C,
                                               float(count), bn.gamma.data_ptr(), bn.beta.data_ptr(), float(bn.eps),
                                               float(bn.momentum), bn.rm.data_ptr(), bn.rv.data_ptr(), bn.coef[0].data_ptr(),
                                               bn.coef[1].data_ptr(), bn.coef[2].data_ptr(), bn.coef[3].data_ptr(),
@@ -293,11 +293,11 @@ class FEEngine:
         N, H, W, C = xshape
         OH, OW = conv_out_hw(H, W, c.R, c.S, c.stride, c.pad)
         y = self._A(plan, (N, OH, OW, c.Cout))
-        part, nt = (None, 0)
+        part, nt, mt = (None, 0, 0)
         if train:
-            part, nt = self._stats_buf(plan, N * OH * OW, c.Cout)
+            part, nt, mt = self._stats_buf(plan, N * OH * OW, c.Cout, c.R * c.S * C)
         self._conv_fwd(ops, x, xshape, w if w is not None else c.w, y, c, c.stride, c.pad, OH, OW, pro=pro, part=part)
-        self._bn_fwd(ops, bn, part, nt, N * OH * OW, train)
+        self._bn_fwd(ops, bn, part, nt, N * OH * OW, train, mt)
         return y, (N, OH, OW, c.Cout)
 
     def build_plan(self, N, H, W, train, with_backward):
