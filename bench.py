@@ -196,8 +196,16 @@ def main():
         flops = conv_flops_per_img(args.arch) * args.batch
         ach = flops / (conv_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.arch == "resnet50" and args.batch == 256 and args.dtype == "bf16":
+            # HBM bytes of the conv family per step from rocprofv3 PMC passes of THIS command (FETCH_SIZE x2-corrected
+            # + WRITE_SIZE, see profiles/traffic.json); bench.py cannot run the profiler on itself.
+            with open(tpath) as f:
+                traffic = json.load(f).get("conv_family_bytes_per_step")
         roof = {"bound": "mfma", "kernel": "igemm_kernel + wgrad_kernel (all conv/linear launches of a step)",
-                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes per step of the same launches (PMC), algorithmic minimum = activations+weights once",
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(total_ms, 3),
                 "whole_step_frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
                 "by_entry_point_ms": {k: round(v[1] / nprof, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}

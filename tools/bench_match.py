@@ -1,0 +1,36 @@
+"""BASELINE config 5: query x gallery 512-d cosine match with top-100 and candR@10/100 on one MI355X.
+  python tools/bench_match.py [Q] [G]     (defaults 10000 x 1000000)
+Synthetic data per SURVEY §8d: gallery = 100k classes x 10 photos, center[class] + sigma*N(0,1), L2-normalised."""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pets_face_recognition_amd.match import cosine_topk
+
+Q = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+D, K = 512, 100
+dev = 'cuda'
+g = torch.Generator(device=dev).manual_seed(123)
+ncls = G // 10
+centers = torch.randn(ncls, D, device=dev, generator=g)
+gcls = torch.arange(ncls, device=dev).repeat_interleave(10)[:G]
+perm = torch.randperm(G, device=dev, generator=g)
+gcls = gcls[perm]
+sigma = 3.2
+gal = centers[gcls] + sigma * torch.randn(G, D, device=dev, generator=g)
+qcls = torch.randint(0, ncls, (Q,), device=dev, generator=g)
+qry = centers[qcls] + sigma * torch.randn(Q, D, device=dev, generator=g)
+res = {}
+for name, dt in (("bf16+fp32 rescore", torch.bfloat16), ("f32", torch.float32)):
+    sc, idx = cosine_topk(qry, gal, K, compute_dtype=dt)          # warm-up (allocations, first launches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sc, idx = cosine_topk(qry, gal, K, compute_dtype=dt)
+    torch.cuda.synchronize()
+    dtm = time.perf_counter() - t0
+    hit = gcls[idx.long().clamp_min(0)] == qcls[:, None]
+    r10, r100 = hit[:, :10].any(1).float().mean().item(), hit[:, :100].any(1).float().mean().item()
+    res[name] = dict(seconds=round(dtm, 4), tflops=round(2.0 * Q * G * D / dtm / 1e12, 1), pairs_per_s=round(Q * G / dtm / 1e9, 2),
+                     candR10=round(r10, 4), candR100=round(r100, 4), idx_checksum=int(idx.long().sum().item()))
+print(json.dumps({"workload": f"{Q} queries x {G} gallery x {D}-d, top-{K}", "results": res,
+                  "identical_top100_sets_bf16_vs_f32": None}))
