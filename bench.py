@@ -177,7 +177,7 @@ def main():
             det = {}
             for name, a, e0, e1 in tr.records:
                 if name == "pfr_conv2d_fwd":
-                    key = "fwd N%d H%d W%d C%d Co%d R%d s%d dil%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], a[15], 1 if a[21] else 0)
+                    key = "fwd N%d H%d W%d C%d Co%d R%d s%d dil%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], a[15], 1 if a[22] else 0)
                     fl = 2.0 * a[5] * a[15] * a[16] * a[9] * a[10] * a[11] * a[8] / (4 ** a[14])
                 elif name == "pfr_conv2d_wgrad":
                     key = "wgrad N%d H%d W%d C%d Co%d R%d s%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], 1 if a[17] else 0)

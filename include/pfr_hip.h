@@ -44,15 +44,16 @@ int pfr_device_arch(char* buf, int buflen);
  * losses/large_margin.py:71) and — run over dy with flipped/transposed weights and idil_log2 = log2(stride) —
  * the autograd input gradient of the same ops.
  *   x [N][H][W][C], w [Cout][R][S][C], y [N*OH*OW][ldy] (ldy<=0 → Cout); ih = oh*stride - pad + r.
- *   bias [Cout] fp32 or NULL; accumulate: y += result; out_relu: y = max(y,0)
+ *   bias [Cout] fp32 or NULL; residual [M][ldy] (y's dtype) or NULL: y = result + bias + residual;
+ *   accumulate: y += result; out_relu: y = max(y,0)
  *   pro_scale/pro_shift [C] fp32 or NULL: operand is relu?(scale[c]*x + shift[c]) (fused BN-apply of the producer)
  *   stats_part or NULL: fp32 [ceil(M/mtile)][2][Cout] per-channel (mean, M2 = Σ(y-mean)²) of each m-tile of the stored y,
  *   mtile = pfr_conv2d_mtile(M, Cout, R*S*C, dtype, out_dtype)  (input of pfr_bn_finalize; deterministic, no atomics). */
 int pfr_conv2d_mtile(int M, int Cout, int K, int dtype, int out_dtype); /* K = R*S*C */
 int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W, int C,
                    int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int ldy,
-                   const float* bias, int accumulate, int out_relu, const float* pro_scale, const float* pro_shift,
-                   int pro_relu, float* stats_part, pfr_stream_t stream);
+                   const float* bias, const void* residual, int accumulate, int out_relu, const float* pro_scale,
+                   const float* pro_shift, int pro_relu, float* stats_part, pfr_stream_t stream);
 
 /* pfr_conv2d_wgrad replaces the autograd weight gradient of nn.Conv2d / nn.Linear / F.linear:
  *   dw[co][r][s][c] (fp32) = scale * sum_m dy[m][co] * act(x)[...]  (+ dw if accumulate)
@@ -126,6 +127,24 @@ int pfr_sgd_step(float* p, const float* g, float* mom, void* shadow, int shadow_
                  float weight_decay, float grad_scale, int first_step, pfr_stream_t stream);
 int pfr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, size_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, pfr_stream_t stream);
+
+/* ---- Swin-T feature extractor (models/swin.py:8-241): LayerNorm (29,215), exact GELU (39-43), fused shifted-window
+ * attention (101-135).  Linear layers and the Unfold+Linear patch merging (a stride-f conv) use pfr_conv2d_*. */
+int pfr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int dtype,
+                      long rows, int C, float eps, pfr_stream_t stream);
+int pfr_layernorm_bwd_blocks(long rows); /* part is fp32 [2][blocks][C]: dgamma partial rows, then dbeta partial rows (sum each half with pfr_colsum) */
+int pfr_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                      const void* dres, void* dx, float* part, int dtype, long rows, int C, pfr_stream_t stream);
+int pfr_gelu_fwd(const void* x, void* y, int dtype, size_t n, pfr_stream_t stream);
+int pfr_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, size_t n, pfr_stream_t stream);
+/* qkv [B][H][W][3*heads*head_dim] (q|k|v, each (head, d)); pos: fp32 [(2w-1)][(2w-1)] relative-position table;
+ * shift = cyclic displacement (0 or w/2); out [B][H][W][heads*head_dim] */
+int pfr_window_attn_fwd(const void* qkv, const float* pos, void* out, int dtype, int B, int H, int W, int heads, int head_dim,
+                        int window, int shift, float scale, pfr_stream_t stream);
+/* dpos_part: fp32 [B*(H/w)*(W/w)*heads][(2w-1)^2] per-workgroup partials of the table gradient (sum with pfr_colsum) */
+int pfr_window_attn_bwd(const void* qkv, const float* pos, const void* dout, void* dqkv, float* dpos_part, int dtype, int B,
+                        int H, int W, int heads, int head_dim, int window, int shift, float scale, pfr_stream_t stream);
+int pfr_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, int Cp, int accumulate, pfr_stream_t stream);
 
 /* ---- embedding match: running top-K over gallery chunks (engine/controller.py:77-90,143-160; generate_tsv.py:91-125;
  * similarity_f = (cos+1)/2 at configs/dog_fe/fe_dogs_config.py:89-93).  Scores of a chunk come from pfr_conv2d_fwd

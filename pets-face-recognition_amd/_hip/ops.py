@@ -32,7 +32,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 
 
 def conv2d_fwd(x, w, stride=1, pad=0, idil_log2=0, out_hw=None, out=None, out_dtype=None, bias=None, accumulate=False,
-               out_relu=False, pro=None, stats=False, stats_buf=None):
+               out_relu=False, pro=None, stats=False, stats_buf=None, residual=None):
     """x [N,H,W,C] NHWC, w [Cout,R,S,C].  Returns (y [N,OH,OW,Cout], stats_part or None)."""
     _chk(x, "x"); _chk(w, "w")
     N, H, W, C = x.shape
@@ -58,7 +58,7 @@ def conv2d_fwd(x, w, stride=1, pad=0, idil_log2=0, out_hw=None, out=None, out_dt
     if pro is not None:
         ps, psh, prelu = pro
     lib.pfr_conv2d_fwd(_p(x), _p(w), _p(out), dtype_id(x.dtype), dtype_id(out.dtype), N, H, W, C, Cout, R, S, stride, pad,
-                       idil_log2, OH, OW, ldy, _p(bias), int(accumulate), int(out_relu), _p(ps), _p(psh), int(prelu),
+                       idil_log2, OH, OW, ldy, _p(bias), _p(residual), int(accumulate), int(out_relu), _p(ps), _p(psh), int(prelu),
                        _p(part), _stream())
     return out, part
 

@@ -29,6 +29,7 @@ struct IgemmParams {
   int M, K;
   float* stats_part;  // [tilesM][2][Cout] (tile mean, tile M2) or nullptr
   const float* bias;  // [Cout] or nullptr
+  const void* residual;  // [M][ldy] of TO or nullptr: y = result (+bias) + residual   (transformer residual streams)
   int accumulate;
   const float* pro_scale;  // [C] or nullptr
   const float* pro_shift;
@@ -356,8 +357,20 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
     float f[KPO];
     Chunk<TO>::unpack(v, f);
     char* dst = yb + ((size_t)m * p.ldy + co) * sizeof(TO);
-    const bool post = p.bias || p.accumulate || p.out_relu;
+    const bool post = p.bias || p.accumulate || p.out_relu || p.residual;
     if (post) {
+      if (p.residual) {
+        float g[KPO];
+        const char* rsrc = reinterpret_cast<const char*>(p.residual) + ((size_t)m * p.ldy + co) * sizeof(TO);
+        if (vec_ok) {
+          Chunk<TO>::unpack(ld16(rsrc), g);
+        } else {
+#pragma unroll
+          for (int e = 0; e < KPO; ++e) g[e] = (co + e < p.Cout) ? to_f32(reinterpret_cast<const TO*>(rsrc)[e]) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < KPO; ++e) f[e] += g[e];
+      }
       if (p.accumulate) {
         float g[KPO];
         if (vec_ok) {
@@ -497,8 +510,9 @@ extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int dtype, int out_dtype
 
 extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
                               int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
-                              int ldy, const float* bias, int accumulate, int out_relu, const float* pro_scale,
-                              const float* pro_shift, int pro_relu, float* stats_part, hipStream_t stream) {
+                              int ldy, const float* bias, const void* residual, int accumulate, int out_relu,
+                              const float* pro_scale, const float* pro_shift, int pro_relu, float* stats_part,
+                              hipStream_t stream) {
   PFR_CHECK_ARG(x && w && y, "pfr_conv2d_fwd: null pointer");
   PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_conv2d_fwd: bad dtype %d", dtype);
   PFR_CHECK_ARG(out_dtype == dtype || out_dtype == PFR_F32, "pfr_conv2d_fwd: out_dtype must be dtype or f32");
@@ -514,7 +528,7 @@ extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, 
   p.R = R; p.S = S; p.OH = OH; p.OW = OW; p.ostride = stride; p.pad = pad; p.idil_log2 = idil_log2;
   p.Cout = Cout; p.ldy = ldy > 0 ? ldy : Cout;
   p.M = N * OH * OW; p.K = R * S * C;
-  p.stats_part = stats_part; p.bias = bias; p.accumulate = accumulate; p.out_relu = out_relu;
+  p.stats_part = stats_part; p.bias = bias; p.residual = residual; p.accumulate = accumulate; p.out_relu = out_relu;
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);

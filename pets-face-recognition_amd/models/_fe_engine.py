@@ -267,7 +267,7 @@ class FEEngine:
             ps, psh, prelu = pro[0].data_ptr(), pro[1].data_ptr(), 1
         ops.append((lib.pfr_conv2d_fwd, (x.data_ptr(), w.data_ptr(), y.data_ptr(), self.did, dtype_id(y.dtype), N, H, W, C,
                                          Cout, R, S, stride, pad, idil, OH, OW, y.shape[-1],
-                                         0 if bias is None else bias.data_ptr(), accumulate, 0, ps, psh, prelu,
+                                         0 if bias is None else bias.data_ptr(), 0, accumulate, 0, ps, psh, prelu,
                                          0 if part is None else part.data_ptr())))
 
     def _stats_buf(self, plan, M, Cout, K):

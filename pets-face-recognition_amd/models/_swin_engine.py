@@ -1,0 +1,428 @@
+"""SwinEngine — executes the Swin-T/S/B/L feature extractor (forward, backward) on the gfx950 kernels.
+
+Counterpart of /root/reference/models/swin.py:196-225 (`SwinTransformer.forward`) + autograd for BASELINE config 4.
+Same design as models/_fe_engine.FEEngine: flat fp32 master / gradient buffers (the module's nn.Parameters become views,
+state-dict names unchanged), compute-dtype shadow, one pre-built plan of C-ABI calls per input shape.
+
+Mapping (tokens are kept NHWC = [B, H, W, C] end to end; the reference's NCHW↔NHWC permutes between stages vanish):
+  PatchMerging (Unfold + Linear, swin.py:155-167)  → stride-f conv on NHWC (weights re-laid out per step)
+  LayerNorm / GELU / windowed attention            → csrc/pfr_swin.hip
+  to_qkv / to_out / MLP / head Linear              → pfr_conv2d_fwd (GEMM, bias and residual-add fused in the epilogue),
+                                                     pfr_conv2d_wgrad, data gradient through pfr_conv2d_fwd
+  cyclic shift, window partition, masks            → addressing / analytic mask inside the attention kernel
+"""
+import torch
+import torch.nn as nn
+
+from .._hip import lib, dtype_id, PfrError
+from ._fe_engine import default_compute_dtype, _ALIGN
+
+
+class _Lin:
+    pass
+
+
+class _LN:
+    pass
+
+
+class SwinEngine:
+    def __init__(self, model, device, compute_dtype=None):
+        if not str(device).startswith("cuda"):
+            raise PfrError("SwinEngine runs on the HIP device only (no CPU fallback)")
+        lib.pfr_version()
+        self.device = torch.device(device)
+        self.dtype = compute_dtype or default_compute_dtype()
+        self.did = dtype_id(self.dtype)
+        self.kp = 8 if self.dtype == torch.bfloat16 else 4
+        self.model_id = id(model)
+        self.plans = {}
+        self.grad_ready_hook = None
+        self._adopt(model)
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def _adopt(self, model):
+        dev = self.device
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        offs, total = {}, 0
+        for name, p in named:
+            offs[name] = total
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.n_flat = total
+        self.master = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.shadow = self.master if self.dtype == torch.float32 else torch.zeros(total, dtype=self.dtype, device=dev)
+        self.offs = offs
+        self._views = {}
+        self.param_list = []
+        for name, p in named:
+            o, n = offs[name], p.numel()
+            mv = self.master[o:o + n].view(p.shape)
+            mv.copy_(p.data.detach().to(dev))
+            p.data = mv
+            p.grad = None
+            self._views[name] = (p, self.grad[o:o + n].view(p.shape))
+            self.param_list.append(p)
+        for n, p in model.named_parameters():          # frozen masks just move to the device
+            if not p.requires_grad:
+                p.data = p.data.to(dev)
+        self.first_param = named[0][1]
+
+        def lin(prefix, m, conv_f=None, cin=None):
+            r = _Lin()
+            r.out, r.inp = m.out_features, m.in_features
+            r.off = offs[prefix + ".weight"]
+            r.g = self.grad[r.off:r.off + r.out * r.inp]
+            if m.bias is not None:
+                bo = offs[prefix + ".bias"]
+                r.bias = self.master[bo:bo + r.out]
+                r.dbias = self.grad[bo:bo + r.out]
+            else:
+                r.bias = r.dbias = None
+            r.f = conv_f
+            if conv_f is None:
+                r.w = self.shadow[r.off:r.off + r.out * r.inp]                       # [out][in] = [out,1,1,in]
+                r.wt = torch.zeros(r.inp * r.out, dtype=self.dtype, device=dev)     # [in,1,1,out]
+                r.cin = r.cinp = r.inp
+            else:                                                                    # patch merging as a conv
+                r.cin = cin
+                r.cinp = (cin + self.kp - 1) // self.kp * self.kp
+                kk = conv_f * conv_f * r.cinp
+                r.w = torch.zeros(r.out * kk, dtype=self.dtype, device=dev)          # [out][f][f][cinp]
+                r.wt = torch.zeros(r.out * kk, dtype=self.dtype, device=dev)         # [cinp][f][f][out]
+                r.g_conv = torch.zeros(r.out * kk, dtype=torch.float32, device=dev)
+            return r
+
+        def ln(prefix, m):
+            r = _LN()
+            r.C, r.eps = m.normalized_shape[0], m.eps
+            wo, bo = offs[prefix + ".weight"], offs[prefix + ".bias"]
+            r.gamma, r.beta = self.master[wo:wo + r.C], self.master[bo:bo + r.C]
+            r.dgamma, r.dbeta = self.grad[wo:wo + r.C], self.grad[bo:bo + r.C]
+            return r
+
+        self.stages = []
+        cin = model.stage1.patch_partition.linear.in_features // (model.stage1.patch_partition.downscaling_factor ** 2)
+        self.in_channels = cin
+        for si in range(1, 5):
+            st = getattr(model, f"stage{si}")
+            pm = st.patch_partition
+            rec = {"pm": lin(f"stage{si}.patch_partition.linear", pm.linear, conv_f=pm.downscaling_factor, cin=cin),
+                   "f": pm.downscaling_factor, "blocks": [], "off": offs[f"stage{si}.patch_partition.linear.weight"]}
+            for li, pair in enumerate(st.layers):
+                for bi, blk in enumerate(pair):
+                    pre = f"stage{si}.layers.{li}.{bi}"
+                    att = blk.attention_block.fn.fn
+                    ff = blk.mlp_block.fn.fn
+                    if not att.relative_pos_embedding:
+                        raise PfrError("HIP Swin path supports relative_pos_embedding=True (the reference default)")
+                    b = {"ln1": ln(pre + ".attention_block.fn.norm", blk.attention_block.fn.norm),
+                         "qkv": lin(pre + ".attention_block.fn.fn.to_qkv", att.to_qkv),
+                         "out": lin(pre + ".attention_block.fn.fn.to_out", att.to_out),
+                         "ln2": ln(pre + ".mlp_block.fn.norm", blk.mlp_block.fn.norm),
+                         "fc1": lin(pre + ".mlp_block.fn.fn.net.0", ff.net[0]),
+                         "fc2": lin(pre + ".mlp_block.fn.fn.net.2", ff.net[2]),
+                         "heads": att.heads, "w": att.window_size, "scale": att.scale,
+                         "shift": att.window_size // 2 if att.shifted else 0}
+                    po = offs[pre + ".attention_block.fn.fn.pos_embedding"]
+                    ntab = (2 * att.window_size - 1) ** 2
+                    b["pos"] = self.master[po:po + ntab]
+                    b["dpos"] = self.grad[po:po + ntab]
+                    b["hd"] = att.to_qkv.out_features // (3 * att.heads)
+                    rec["blocks"].append(b)
+            self.stages.append(rec)
+            cin = pm.linear.out_features
+        self.head_ln = ln("mlp_head.0", model.mlp_head[0])
+        self.head_fc = lin("mlp_head.1", model.mlp_head[1])
+        self.emb_dim = self.head_fc.out
+        self.cp = self.stages[0]["pm"].cinp
+        self.ws = None
+        torch.cuda.synchronize(dev)
+
+    def matches(self, model):
+        return id(model) == self.model_id and self.first_param.data.data_ptr() == self.master.data_ptr()
+
+    def attach_grads(self):
+        for p, gv in self._views.values():
+            p.grad = gv
+
+    def _all_lins(self):
+        for st in self.stages:
+            yield st["pm"]
+            for b in st["blocks"]:
+                for k in ("qkv", "out", "fc1", "fc2"):
+                    yield b[k]
+        yield self.head_fc
+
+    def refresh_weights(self, stream, for_backward=True):
+        if self.dtype != torch.float32:
+            lib.pfr_cast(self.master.data_ptr(), 0, self.shadow.data_ptr(), self.did, self.n_flat, stream)
+        for r in self._all_lins():
+            if r.f is not None:   # Unfold order (c, kh, kw) → conv layout [out][kh][kw][c(padded)]
+                lib.pfr_nchw_to_nhwc(self.master.data_ptr() + 4 * r.off, r.w.data_ptr(), self.did, r.out, r.cin, r.f * r.f, 1,
+                                     r.cinp, stream)
+                if for_backward and r is not self.stages[0]["pm"]:
+                    lib.pfr_weight_dgrad_layout(r.w.data_ptr(), r.wt.data_ptr(), self.did, r.out, r.f, r.f, r.cinp, stream)
+            elif for_backward:
+                lib.pfr_weight_dgrad_layout(r.w.data_ptr(), r.wt.data_ptr(), self.did, r.out, 1, 1, r.inp, stream)
+
+    # ------------------------------------------------------------------------------------------ plan
+    def build_plan(self, N, H, W, with_backward):
+        T, dev, did = self.dtype, self.device, self.did
+        fwd, bwd = [], []
+        bufs = []
+
+        def A(shape, dtype=None):
+            t = torch.empty(shape, dtype=dtype or T, device=dev)
+            bufs.append(t)
+            return t
+
+        def gemm(ops, x, rows, cin, r, y, bias=True, residual=None, w=None):
+            ops.append((lib.pfr_conv2d_fwd, (x.data_ptr(), (w if w is not None else r.w).data_ptr(), y.data_ptr(), did,
+                                             dtype_id(y.dtype), rows, 1, 1, cin, r.out, 1, 1, 1, 0, 0, 1, 1, r.out,
+                                             r.bias.data_ptr() if (bias and r.bias is not None) else 0,
+                                             0 if residual is None else residual.data_ptr(), 0, 0, 0, 0, 0, 0)))
+
+        ws_need = [0]
+
+        def wgrad(ops, x, xshape, dy, dyshape, r, R, stride, out):
+            Nq, Hq, Wq, Cq = xshape
+            _, OH, OW, Co = dyshape
+            KK = R * R * Cq
+            splits = lib.pfr_conv2d_wgrad_splits(Nq * OH * OW, Co, KK)
+            ws_need[0] = max(ws_need[0], splits * Co * KK)
+            ops.append(("wgrad", (x.data_ptr(), dy.data_ptr(), out.data_ptr(), None, did, Nq, Hq, Wq, Cq, Co, R, R, stride, 0,
+                                  OH, OW, Co, 0, 0, 0, 1.0, 0)))
+
+        def dgrad_lin(ops, dy, rows, r, dx):
+            ops.append((lib.pfr_conv2d_fwd, (dy.data_ptr(), r.wt.data_ptr(), dx.data_ptr(), did, did, rows, 1, 1, r.out, r.inp, 1,
+                                             1, 1, 0, 0, 1, 1, r.inp, 0, 0, 0, 0, 0, 0, 0, 0)))
+
+        def colsum(ops, x, rows, C, out, dt=None):
+            ops.append((lib.pfr_colsum, (x.data_ptr(), dt if dt is not None else did, rows, C, out.data_ptr(), 0)))
+
+        x_nhwc = A((N, H, W, self.cp))
+        cur, cshape = x_nhwc, (N, H, W, self.cp)
+        saved = []
+        for st in self.stages:
+            f, pm = st["f"], st["pm"]
+            Nn, Hh, Ww, Cc = cshape
+            OH, OW = Hh // f, Ww // f
+            rows = N * OH * OW
+            C = pm.out
+            t = A((N, OH, OW, C))
+            fwd.append((lib.pfr_conv2d_fwd, (cur.data_ptr(), pm.w.data_ptr(), t.data_ptr(), did, did, N, Hh, Ww, Cc, C, f, f, f, 0,
+                                             0, OH, OW, C, pm.bias.data_ptr() if pm.bias is not None else 0, 0, 0, 0, 0, 0, 0, 0)))
+            srec = {"in": cur, "inshape": cshape, "t": t, "shape": (N, OH, OW, C), "blocks": []}
+            x = t
+            for b in st["blocks"]:
+                ln1 = A((rows, C)); mu1 = A((rows,), torch.float32); rs1 = A((rows,), torch.float32)
+                fwd.append((lib.pfr_layernorm_fwd, (x.data_ptr(), b["ln1"].gamma.data_ptr(), b["ln1"].beta.data_ptr(), ln1.data_ptr(),
+                                                    mu1.data_ptr(), rs1.data_ptr(), did, rows, C, float(b["ln1"].eps))))
+                qkv = A((rows, 3 * C))
+                gemm(fwd, ln1, rows, C, b["qkv"], qkv)
+                att = A((rows, C))
+                fwd.append((lib.pfr_window_attn_fwd, (qkv.data_ptr(), b["pos"].data_ptr(), att.data_ptr(), did, N, OH, OW,
+                                                      b["heads"], b["hd"], b["w"], b["shift"], float(b["scale"]))))
+                y = A((rows, C))
+                gemm(fwd, att, rows, C, b["out"], y, residual=x)
+                ln2 = A((rows, C)); mu2 = A((rows,), torch.float32); rs2 = A((rows,), torch.float32)
+                fwd.append((lib.pfr_layernorm_fwd, (y.data_ptr(), b["ln2"].gamma.data_ptr(), b["ln2"].beta.data_ptr(), ln2.data_ptr(),
+                                                    mu2.data_ptr(), rs2.data_ptr(), did, rows, C, float(b["ln2"].eps))))
+                h1 = A((rows, 4 * C))
+                gemm(fwd, ln2, rows, C, b["fc1"], h1)
+                h2 = A((rows, 4 * C))
+                fwd.append((lib.pfr_gelu_fwd, (h1.data_ptr(), h2.data_ptr(), did, rows * 4 * C)))
+                z = A((rows, C))
+                gemm(fwd, h2, rows, 4 * C, b["fc2"], z, residual=y)
+                srec["blocks"].append(dict(x=x, ln1=ln1, mu1=mu1, rs1=rs1, qkv=qkv, att=att, y=y, ln2=ln2, mu2=mu2, rs2=rs2,
+                                           h1=h1, h2=h2, z=z))
+                x = z
+            saved.append(srec)
+            cur, cshape = x, (N, OH, OW, C)
+        Nn, Hh, Ww, Cf = cshape
+        pooled = A((N, Cf))
+        fwd.append((lib.pfr_avgpool_fwd, (cur.data_ptr(), pooled.data_ptr(), did, N, Hh * Ww, Cf)))
+        hln = A((N, Cf)); hmu = A((N,), torch.float32); hrs = A((N,), torch.float32)
+        fwd.append((lib.pfr_layernorm_fwd, (pooled.data_ptr(), self.head_ln.gamma.data_ptr(), self.head_ln.beta.data_ptr(),
+                                            hln.data_ptr(), hmu.data_ptr(), hrs.data_ptr(), did, N, Cf, float(self.head_ln.eps))))
+        emb = A((N, self.emb_dim), torch.float32)
+        gemm(fwd, hln, N, Cf, self.head_fc, emb)
+        plan = {"fwd": fwd, "bufs": bufs, "x_nhwc": x_nhwc, "emb": emb}
+        if not with_backward:
+            return plan
+
+        # ================================================================= backward
+        pool = {}
+
+        def G(shape, dtype=None):
+            key = (tuple(shape), dtype or T)
+            lst = pool.setdefault(key, [])
+            return lst.pop() if lst else A(shape, dtype)
+
+        def release(t):
+            pool.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+        def ln_bwd(ops, dy, xin, mu, rs, lnrec, dres, dx, rows, C):
+            nb = lib.pfr_layernorm_bwd_blocks(rows)
+            part = G((2, nb, C), torch.float32)
+            ops.append((lib.pfr_layernorm_bwd, (dy.data_ptr(), xin.data_ptr(), mu.data_ptr(), rs.data_ptr(), lnrec.gamma.data_ptr(),
+                                                0 if dres is None else dres.data_ptr(), dx.data_ptr(), part.data_ptr(), did, rows, C)))
+            ops.append((lib.pfr_colsum, (part[0].data_ptr(), 0, nb, C, lnrec.dgamma.data_ptr(), 0)))
+            ops.append((lib.pfr_colsum, (part[1].data_ptr(), 0, nb, C, lnrec.dbeta.data_ptr(), 0)))
+            release(part)
+
+        demb = A((N, self.emb_dim))
+        plan["demb"] = demb
+        hf = self.head_fc
+        if hf.dbias is not None:
+            colsum(bwd, demb, N, hf.out, hf.dbias)
+        wgrad(bwd, hln, (N, 1, 1, Cf), demb, (N, 1, 1, hf.out), hf, 1, 1, hf.g)
+        dhln = G((N, Cf))
+        dgrad_lin(bwd, demb, N, hf, dhln)
+        dpooled = G((N, Cf))
+        ln_bwd(bwd, dhln, pooled, hmu, hrs, self.head_ln, None, dpooled, N, Cf)
+        release(dhln)
+        dz = G(cshape)
+        bwd.append((lib.pfr_avgpool_bwd, (dpooled.data_ptr(), dz.data_ptr(), did, N, Hh * Ww, Cf)))
+        release(dpooled)
+        bwd.append((None, (offs_head := self.offs["mlp_head.0.weight"],)))
+        for si in range(len(self.stages) - 1, -1, -1):
+            st, srec = self.stages[si], saved[si]
+            Nn, OH, OW, C = srec["shape"]
+            rows = N * OH * OW
+            for b, sv in zip(reversed(st["blocks"]), reversed(srec["blocks"])):
+                # ---- MLP branch: z = fc2(gelu(fc1(ln2(y)))) + y
+                colsum(bwd, dz.view(rows, C), rows, C, b["fc2"].dbias)
+                wgrad(bwd, sv["h2"], (rows, 1, 1, 4 * C), dz, (rows, 1, 1, C), b["fc2"], 1, 1, b["fc2"].g)
+                dh2 = G((rows, 4 * C))
+                dgrad_lin(bwd, dz, rows, b["fc2"], dh2)
+                bwd.append((lib.pfr_gelu_bwd, (sv["h1"].data_ptr(), dh2.data_ptr(), dh2.data_ptr(), did, rows * 4 * C)))
+                colsum(bwd, dh2, rows, 4 * C, b["fc1"].dbias)
+                wgrad(bwd, sv["ln2"], (rows, 1, 1, C), dh2, (rows, 1, 1, 4 * C), b["fc1"], 1, 1, b["fc1"].g)
+                dln2 = G((rows, C))
+                dgrad_lin(bwd, dh2, rows, b["fc1"], dln2)
+                release(dh2)
+                dy = G((rows, C))
+                ln_bwd(bwd, dln2, sv["y"], sv["mu2"], sv["rs2"], b["ln2"], dz, dy, rows, C)
+                release(dln2)
+                release(dz)
+                # ---- attention branch: y = to_out(attn(to_qkv(ln1(x)))) + x
+                colsum(bwd, dy, rows, C, b["out"].dbias)
+                wgrad(bwd, sv["att"], (rows, 1, 1, C), dy, (rows, 1, 1, C), b["out"], 1, 1, b["out"].g)
+                datt = G((rows, C))
+                dgrad_lin(bwd, dy, rows, b["out"], datt)
+                dqkv = G((rows, 3 * C))
+                nblk = N * (OH // b["w"]) * (OW // b["w"]) * b["heads"]
+                ntab = (2 * b["w"] - 1) ** 2
+                dpart = G((nblk, ntab), torch.float32)
+                bwd.append((lib.pfr_window_attn_bwd, (sv["qkv"].data_ptr(), b["pos"].data_ptr(), datt.data_ptr(), dqkv.data_ptr(),
+                                                      dpart.data_ptr(), did, N, OH, OW, b["heads"], b["hd"], b["w"], b["shift"],
+                                                      float(b["scale"]))))
+                bwd.append((lib.pfr_colsum, (dpart.data_ptr(), 0, nblk, ntab, b["dpos"].data_ptr(), 0)))
+                release(dpart)
+                release(datt)
+                wgrad(bwd, sv["ln1"], (rows, 1, 1, C), dqkv, (rows, 1, 1, 3 * C), b["qkv"], 1, 1, b["qkv"].g)
+                dln1 = G((rows, C))
+                dgrad_lin(bwd, dqkv, rows, b["qkv"], dln1)
+                release(dqkv)
+                dx = G((rows, C))
+                ln_bwd(bwd, dln1, sv["x"], sv["mu1"], sv["rs1"], b["ln1"], dy, dx, rows, C)
+                release(dln1)
+                release(dy)
+                dz = dx
+            # ---- patch merging (stride-f conv): bias, weight gradient (conv layout → Unfold layout), data gradient
+            pm, f = st["pm"], st["f"]
+            Ni, Hi, Wi, Ci = srec["inshape"]
+            if pm.dbias is not None:
+                colsum(bwd, dz, rows, C, pm.dbias)
+            g_conv = pm.g_conv
+            wgrad(bwd, srec["in"], (Ni, Hi, Wi, Ci), dz, (N, OH, OW, C), pm, f, f, g_conv)
+            bwd.append((lib.pfr_nhwc_to_nchw_f32, (g_conv.data_ptr(), pm.g.data_ptr(), pm.out, pm.cin, f * f, pm.cinp, 0)))
+            if si > 0:
+                din = G((Ni, Hi, Wi, Ci))
+                bwd.append((lib.pfr_conv2d_fwd, (dz.data_ptr(), pm.wt.data_ptr(), din.data_ptr(), did, did, N, OH, OW, C, Ci, f, f, 1,
+                                                 f - 1, {2: 1, 4: 2}[f], Hi, Wi, Ci, 0, 0, 0, 0, 0, 0, 0, 0)))
+                release(dz)
+                dz = din
+            bwd.append((None, (st["off"],)))
+        if self.ws is None or self.ws.numel() < ws_need[0]:
+            self.ws = torch.empty(ws_need[0], dtype=torch.float32, device=dev)
+        plan["bwd_sym"] = bwd
+        return plan
+
+    def _finalize(self, plan):
+        res = []
+        for fn, args in plan["bwd_sym"]:
+            if fn == "wgrad":
+                a = list(args)
+                a[3] = self.ws.data_ptr()
+                res.append((lib.pfr_conv2d_wgrad, tuple(a)))
+            else:
+                res.append((fn, args))
+        plan["bwd"] = res
+        plan["ws_ptr"] = self.ws.data_ptr()
+
+    def get_plan(self, N, H, W, with_backward):
+        key = (N, H, W, with_backward)
+        p = self.plans.get(key)
+        if p is None:
+            if len(self.plans) >= 4:
+                self.plans.pop(next(iter(self.plans)))
+            p = self.build_plan(N, H, W, with_backward)
+            if with_backward:
+                self._finalize(p)
+            self.plans[key] = p
+        elif with_backward and p["ws_ptr"] != self.ws.data_ptr():
+            self._finalize(p)
+        return p
+
+    def forward(self, x, with_backward):
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise PfrError(f"expected NCHW input with {self.in_channels} channels, got {tuple(x.shape)}")
+        x = x.float().contiguous()
+        N, _, H, W = x.shape
+        plan = self.get_plan(N, H, W, with_backward)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh_weights(stream, for_backward=with_backward)
+        lib.pfr_nchw_to_nhwc(x.data_ptr(), plan["x_nhwc"].data_ptr(), self.did, N, x.shape[1], H, W, self.cp, stream)
+        for fn, args in plan["fwd"]:
+            fn(*args, stream)
+        self._last = plan
+        return plan["emb"]
+
+    def backward(self, demb):
+        plan = self._last
+        stream = torch.cuda.current_stream().cuda_stream
+        demb = demb.contiguous()
+        lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan["demb"].data_ptr(), self.did, demb.numel(), stream)
+        hook = self.grad_ready_hook
+        for fn, args in plan["bwd"]:
+            if fn is None:
+                if hook is not None:
+                    hook(args[0])
+            else:
+                fn(*args, stream)
+        self.attach_grads()
+
+
+class _SwinFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        eng = model.hip_engine(x.device)
+        emb = eng.forward(x, True)
+        ctx.eng = eng
+        ctx.nparams = len(params)
+        return emb.clone()
+
+    @staticmethod
+    def backward(ctx, demb):
+        ctx.eng.backward(demb)
+        return (None, None) + (None,) * ctx.nparams
+
+
+def swin_forward(model, x):
+    eng = model.hip_engine(x.device)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in eng.param_list):
+        return _SwinFunction.apply(x, model, *eng.param_list)
+    return eng.forward(x, False).clone()

@@ -2,8 +2,9 @@
 Unfold+Linear patch merging, pre-norm W-MSA / SW-MSA with cyclic shift and additive −inf masks on the last window
 row / column, one shared (2w−1)² relative-position table, exact-GELU MLP, mean-pool → LayerNorm → Linear head).
 
-Restated with plain reshape/permute (no einops).  Runs with torch ops on CPU; the HIP windowed-attention path
-(BASELINE config 4) is the next row of the scope table and is not wired yet: CUDA inputs raise.
+Restated with plain reshape/permute (no einops).  CPU tensors run these torch layers; CUDA (HIP) tensors run the
+gfx950 kernels through models/_swin_engine.SwinEngine (LayerNorm, GELU, fused shifted-window attention in
+csrc/pfr_swin.hip; every Linear incl. patch merging on the MFMA GEMM kernels) — SURVEY.md §8 K14-K17, BASELINE config 4.
 """
 import torch
 import torch.nn as nn
@@ -83,8 +84,6 @@ class WindowAttention(nn.Module):
         return t.reshape(b, h, gh * gw, w * w, -1)
 
     def forward(self, x):
-        if x.is_cuda:
-            raise NotImplementedError("Swin windowed attention has no HIP path yet (SURVEY.md §8 K14-K17: next row)")
         w, h = self.window_size, self.heads
         if self.shifted:
             x = torch.roll(x, (-self.displacement, -self.displacement), (1, 2))
@@ -161,23 +160,48 @@ class SwinTransformer(nn.Module):
             setattr(self, f"stage{i + 1}", StageModule(dims[i], dims[i + 1], layers[i], downscaling_factors[i], heads[i],
                                                        head_dim, window_size, relative_pos_embedding))
         self.mlp_head = nn.Sequential(nn.LayerNorm(dims[4]), nn.Linear(dims[4], num_classes))
+        self.compute_dtype = None   # HIP compute dtype: torch.bfloat16 / torch.float32 (None → PFR_COMPUTE_DTYPE / bf16)
+        self._engine = None
 
-    def forward(self, img):
+    def _forward_torch(self, img):
         x = self.stage4(self.stage3(self.stage2(self.stage1(img))))
         return self.mlp_head(x.mean(dim=[2, 3]))
 
+    def hip_engine(self, device=None):
+        from ._swin_engine import SwinEngine
+        if self._engine is None or not self._engine.matches(self):
+            self._engine = SwinEngine(self, device or next(self.parameters()).device, self.compute_dtype)
+        return self._engine
+
+    def forward(self, img):
+        if img.is_cuda:
+            from ._swin_engine import swin_forward
+            return swin_forward(self, img)
+        return self._forward_torch(img)
+
+    def _apply(self, fn, *a, **kw):
+        self._engine = None
+        return super()._apply(fn, *a, **kw)
+
+
+def _build(hidden_dim, layers, heads, kwargs):
+    dt = kwargs.pop("compute_dtype", None)
+    m = SwinTransformer(hidden_dim=hidden_dim, layers=layers, heads=heads, **kwargs)
+    m.compute_dtype = dt
+    return m
+
 
 def swin_t(hidden_dim=96, layers=(2, 2, 6, 2), heads=(3, 6, 12, 24), **kwargs):
-    return SwinTransformer(hidden_dim=hidden_dim, layers=layers, heads=heads, **kwargs)
+    return _build(hidden_dim, layers, heads, kwargs)
 
 
 def swin_s(hidden_dim=96, layers=(2, 2, 18, 2), heads=(3, 6, 12, 24), **kwargs):
-    return SwinTransformer(hidden_dim=hidden_dim, layers=layers, heads=heads, **kwargs)
+    return _build(hidden_dim, layers, heads, kwargs)
 
 
 def swin_b(hidden_dim=128, layers=(2, 2, 18, 2), heads=(4, 8, 16, 32), **kwargs):
-    return SwinTransformer(hidden_dim=hidden_dim, layers=layers, heads=heads, **kwargs)
+    return _build(hidden_dim, layers, heads, kwargs)
 
 
 def swin_l(hidden_dim=192, layers=(2, 2, 18, 2), heads=(6, 12, 24, 48), **kwargs):
-    return SwinTransformer(hidden_dim=hidden_dim, layers=layers, heads=heads, **kwargs)
+    return _build(hidden_dim, layers, heads, kwargs)

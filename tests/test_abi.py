@@ -28,9 +28,9 @@ def test_header_symbols_exported():
 def test_argument_errors_are_reported_not_crashed():
     from pets_face_recognition_amd._hip import lib, PfrError
     with pytest.raises(PfrError, match="null pointer"):
-        lib.pfr_conv2d_fwd(0, 0, 0, 1, 1, 1, 8, 8, 8, 8, 1, 1, 1, 0, 0, 8, 8, 8, 0, 0, 0, 0, 0, 0, 0, 0)
+        lib.pfr_conv2d_fwd(0, 0, 0, 1, 1, 1, 8, 8, 8, 8, 1, 1, 1, 0, 0, 8, 8, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     with pytest.raises(PfrError, match="multiple of 8"):
-        lib.pfr_conv2d_fwd(16, 16, 16, 1, 1, 1, 8, 8, 3, 8, 1, 1, 1, 0, 0, 8, 8, 8, 0, 0, 0, 0, 0, 0, 0, 0)
+        lib.pfr_conv2d_fwd(16, 16, 16, 1, 1, 1, 8, 8, 3, 8, 1, 1, 1, 0, 0, 8, 8, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 
 
 def test_hip_path_refuses_cpu_tensors():

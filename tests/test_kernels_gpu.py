@@ -145,7 +145,7 @@ def test_gemm_f32_out_odd_cols(dtype):
     wd = w.view(C, 1, 1, D).to(DEV, dtype)
     from pets_face_recognition_amd._hip import lib, dtype_id
     lib.pfr_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), out.data_ptr(), dtype_id(dtype), 0, B, 1, 1, D, C, 1, 1, 1, 0, 0, 1, 1,
-                       ld, 0, 0, 0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+                       ld, 0, 0, 0, 0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = out.view(B, ld).cpu()
     assert rel_err(got[:, :C], ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)

@@ -1,0 +1,163 @@
+"""Swin-T on the HIP path vs the reference-pinned torch restatement (models/swin.py on CPU == /root/reference/models/
+swin.py, see tests/test_oracle_golden.py::test_swin_restatement_matches_reference_vectors) and the golden embeddings
+generated from the reference itself (tests/golden/swin_t.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shift", [0, 3])
+def test_window_attention_kernel(dtype, shift):
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    import pets_face_recognition_amd.models.swin as S
+    g = torch.Generator().manual_seed(4)
+    B, H, W, heads, hd, w = 2, 14, 14, 3, 32, 7
+    C = heads * hd
+    att = S.WindowAttention(C, heads, hd, shift > 0, w, True)
+    qkv = torch.randn(B, H, W, 3 * C, generator=g) * 0.7
+    if dtype == torch.bfloat16:
+        qkv = qkv.bfloat16().float()
+    qkv.requires_grad_(True)
+    # torch reference of the core (everything of WindowAttention.forward between to_qkv and to_out)
+    x = qkv
+    if shift:
+        x = torch.roll(x, (-shift, -shift), (1, 2))
+    gh, gw = H // w, W // w
+    q, k, v = (att._windows(t, B, gh, gw) for t in x.chunk(3, dim=-1))
+    dots = torch.matmul(q, k.transpose(-1, -2)) * att.scale
+    ri = att.relative_indices
+    dots = dots + att.pos_embedding[ri[:, :, 0], ri[:, :, 1]]
+    if shift:
+        dots[:, :, -gw:] += att.upper_lower_mask
+        dots[:, :, gw - 1::gw] += att.left_right_mask
+    out = torch.matmul(dots.softmax(dim=-1), v)
+    out = out.view(B, heads, gh, gw, w, w, -1).permute(0, 2, 4, 3, 5, 1, 6).reshape(B, H, W, -1)
+    if shift:
+        out = torch.roll(out, (shift, shift), (1, 2))
+    dout = torch.randn(out.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+    out.backward(dout)
+    # HIP
+    st = torch.cuda.current_stream().cuda_stream
+    qd = qkv.detach().to(DEV, dtype).contiguous()
+    pos = att.pos_embedding.detach().to(DEV).contiguous()
+    od = torch.empty(B, H, W, C, dtype=dtype, device=DEV)
+    lib.pfr_window_attn_fwd(qd.data_ptr(), pos.data_ptr(), od.data_ptr(), dtype_id(dtype), B, H, W, heads, hd, w, shift,
+                            float(att.scale), st)
+    dq = torch.empty_like(qd)
+    nblk = B * gh * gw * heads
+    dpart = torch.empty(nblk, 169, dtype=torch.float32, device=DEV)
+    dod = dout.to(DEV, dtype).contiguous()
+    lib.pfr_window_attn_bwd(qd.data_ptr(), pos.data_ptr(), dod.data_ptr(), dq.data_ptr(),
+                            dpart.data_ptr(), dtype_id(dtype), B, H, W, heads, hd, w, shift, float(att.scale), st)
+    torch.cuda.synchronize()
+    t = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert rel(od, out.detach()) < t
+    assert rel(dq, qkv.grad) < t
+    assert rel(dpart.sum(0), att.pos_embedding.grad.flatten()) < t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_gelu_kernels(dtype):
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    g = torch.Generator().manual_seed(6)
+    rows, C = 1000, 96
+    x = torch.randn(rows, C, generator=g) * 2 + 0.3
+    res = torch.randn(rows, C, generator=g)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    dy = torch.randn(rows, C, generator=g)
+    if dtype == torch.bfloat16:
+        x, res, dy = x.bfloat16().float(), res.bfloat16().float(), dy.bfloat16().float()
+    xr = x.clone().requires_grad_(True); gr = gam.clone().requires_grad_(True); br = bet.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    y.backward(dy)
+    st = torch.cuda.current_stream().cuda_stream
+    did = dtype_id(dtype)
+    xd = x.to(DEV, dtype); yd = torch.empty_like(xd)
+    mu = torch.empty(rows, device=DEV); rs = torch.empty(rows, device=DEV)
+    gd, bd, dyd, resd = gam.to(DEV), bet.to(DEV), dy.to(DEV, dtype), res.to(DEV, dtype)   # keep the device buffers alive
+    lib.pfr_layernorm_fwd(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), yd.data_ptr(), mu.data_ptr(), rs.data_ptr(),
+                          did, rows, C, 1e-5, st)
+    nb = lib.pfr_layernorm_bwd_blocks(rows)
+    part = torch.empty(2, nb, C, device=DEV); dx = torch.empty_like(xd)
+    lib.pfr_layernorm_bwd(dyd.data_ptr(), xd.data_ptr(), mu.data_ptr(), rs.data_ptr(), gd.data_ptr(),
+                          resd.data_ptr(), dx.data_ptr(), part.data_ptr(), did, rows, C, st)
+    torch.cuda.synchronize()
+    t = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert rel(yd, y.detach()) < t
+    assert rel(dx, xr.grad + res) < t
+    assert rel(part[0].sum(0), gr.grad) < t and rel(part[1].sum(0), br.grad) < t
+    # GELU
+    h = torch.randn(rows, 4 * C, generator=g) * 1.5
+    if dtype == torch.bfloat16:
+        h = h.bfloat16().float()
+    hr = h.clone().requires_grad_(True)
+    gy = F.gelu(hr)
+    dg = torch.randn(gy.shape, generator=g)
+    gy.backward(dg)
+    hd_ = h.to(DEV, dtype); o = torch.empty_like(hd_); dh = torch.empty_like(hd_); dgd = dg.to(DEV, dtype)
+    lib.pfr_gelu_fwd(hd_.data_ptr(), o.data_ptr(), did, h.numel(), st)
+    lib.pfr_gelu_bwd(hd_.data_ptr(), dgd.data_ptr(), dh.data_ptr(), did, h.numel(), st)
+    torch.cuda.synchronize()
+    assert rel(o, gy.detach()) < t and rel(dh, hr.grad) < t
+
+
+def test_swin_t_embeddings_match_reference_golden():
+    """fp32 HIP path reproduces the embeddings the REFERENCE's swin_t produced for the same seed / input"""
+    import pets_face_recognition_amd.models as M
+    G = np.load(os.path.join(GOLD, "swin_t.npz"))
+    torch.manual_seed(int(G["seed"]))
+    m = M.swin_t(num_classes=512, compute_dtype=torch.float32).to(DEV).eval()
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(G["x_seed"])))
+    with torch.no_grad():
+        y = m(x.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(y, torch.tensor(G["emb"])) < 1e-3
+
+
+@pytest.mark.parametrize("dtype,tol_e,tol_g", [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 5e-2, 1.5e-1)])
+def test_swin_fwd_bwd_vs_torch_restatement(dtype, tol_e, tol_g):
+    import pets_face_recognition_amd.models as M
+    torch.manual_seed(21)
+    ref = M.swin_t(num_classes=512)                     # CPU torch path == reference (pinned by golden test)
+    hip = M.swin_t(num_classes=512, compute_dtype=dtype)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3, 3, 224, 224, generator=g)
+    demb = torch.randn(3, 512, generator=g) * 0.1
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    e_ref = ref(x)
+    e_ref.backward(demb)
+    e = hip(x.to(DEV))
+    e.backward(demb.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(e, e_ref.detach()) < tol_e
+    rp = dict(ref.named_parameters())
+    worst = ("", 0.0)
+    fh, fr = [], []
+    for n, p in hip.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, n
+        r = rel(p.grad, rp[n].grad)
+        fh.append(p.grad.double().cpu().flatten()); fr.append(rp[n].grad.double().flatten())
+        if r > worst[1]:
+            worst = (n, r)
+    cos = F.cosine_similarity(torch.cat(fh), torch.cat(fr), dim=0).item()
+    assert cos > (0.99999 if dtype == torch.float32 else 0.99), cos
+    assert worst[1] < tol_g, worst
