@@ -23,12 +23,15 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work (SURVEY.md §8d / BASELINE.md §2): conv MACs per image, forward
 CONV_GMAC = {"resnet50": 4.0871, "resnet18": 1.8136}
+SWIN_GMAC = {"swin_t": 4.490}          # forward MACs per image; fwd+bwd = 3x
 CONV1_GMAC = 0.1180
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
 def conv_flops_per_img(arch):
+    if arch in SWIN_GMAC:
+        return 2.0 * 3.0 * SWIN_GMAC[arch] * 1e9
     # fwd + dgrad + wgrad of every conv; the stem has no data gradient
     return 2.0 * (3.0 * CONV_GMAC[arch] - CONV1_GMAC) * 1e9
 
@@ -40,25 +43,31 @@ def build(args, device):
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(123)
-    backbone = getattr(M, args.arch)(compute_dtype=dt)
-    backbone.fc = torch.nn.Linear(backbone.fc.in_features, 512)
+    if args.arch.startswith("swin"):
+        backbone = getattr(M, args.arch)(num_classes=512, compute_dtype=dt)
+    else:
+        backbone = getattr(M, args.arch)(compute_dtype=dt)
+        backbone.fc = torch.nn.Linear(backbone.fc.in_features, 512)
     ml = SoftmaxBasedMetricLearning(backbone, args.classes, 512, is_focal=True, arc_margin=True)
     ml.add_margin.compute_dtype = dt
     ml.return_logits = True
     ml = ml.to(device)
     ml.train()
     backbone.hip_engine(device)  # adopt parameters into the flat buffers before the optimizer captures them
-    p1 = [p for n, p in ml.module.named_parameters() if "fc" not in n]
-    p2 = [p for n, p in ml.module.named_parameters() if "fc" in n]
+    p1 = [p for n, p in ml.module.named_parameters() if "fc" not in n and p.requires_grad]
+    p2 = [p for n, p in ml.module.named_parameters() if "fc" in n and p.requires_grad]
     # optimizer groups of the reference recipe (configs/dog_fe/fe_dogs_config.py:123-133)
-    opt = FusedSGD([{"lr": 5e-3, "params": p1}, {"lr": 1e-2, "params": p2},
-                    {"lr": 1e-2, "params": ml.add_margin.parameters(), "weight_decay": 1e-4}], 0.01, momentum=0.9)
+    groups = [{"lr": 5e-3, "params": p1}] + ([{"lr": 1e-2, "params": p2}] if p2 else []) + \
+             [{"lr": 1e-2, "params": ml.add_margin.parameters(), "weight_decay": 1e-4}]
+    opt = FusedSGD(groups, 0.01, momentum=0.9)
     return ml, opt
 
 
 def cpu_baseline(args):
     """The reference path restated on PyTorch-CPU (oracle/), timed on the host cores on a bounded sample."""
     from oracle import resnet_ref, arcface_ref
+    if args.arch not in resnet_ref.ARCH:
+        return None
     nthreads = min(64, os.cpu_count() or 1)   # more threads than this only adds contention on the 2x64-core host
     torch.set_num_threads(nthreads)
     B = args.cpu_batch
@@ -191,7 +200,8 @@ def main():
             with open(args.detail, "w") as f:
                 json.dump([{"op": k, "launches_per_step": n, "ms_per_step": round(ms_, 4),
                             "tflops": round(fl * n / (ms_ * 1e-3) / 1e12, 1) if fl else None} for k, n, ms_, fl in rows], f, indent=1)
-        conv_ms = sum(v[1] for k, v in summ.items() if k in ("pfr_conv2d_fwd", "pfr_conv2d_wgrad")) / nprof
+        conv_ms = sum(v[1] for k, v in summ.items() if k in ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_window_attn_fwd",
+                                                             "pfr_window_attn_bwd")) / nprof
         total_ms = sum(v[1] for v in summ.values()) / nprof
         flops = conv_flops_per_img(args.arch) * args.batch
         ach = flops / (conv_ms * 1e-3) / 1e12
@@ -217,11 +227,12 @@ def main():
         cpu = cpu_baseline(args)
 
     if rank == 0:
-        line = {"metric": "FE train images/sec @224^2 bs=256/GPU", "value": round(value, 1), "unit": "images/sec",
+        line = {"metric": f"FE train images/sec @224^2 bs={args.batch}/GPU", "value": round(value, 1), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"{args.arch} FE + ArcFace(s=64,m=0.5) + CE, {args.classes} ids, 224x224x3, "
-                                       f"fwd+bwd+SGD(momentum 0.9, 3 param groups)", "global_batch": args.batch * world,
+                                       f"fwd+bwd+SGD(momentum 0.9, param groups of the reference recipe)",
+                           "global_batch": args.batch * world,
                            "per_gpu_batch": args.batch, "parallelism": f"dp{world}", "loss": round(final_loss, 4)},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line))

@@ -70,7 +70,8 @@ int pfr_cast(const void* x, int src_dtype, void* y, int dst_dtype, size_t n, pfr
 /* w [O][R][S][I] → wt [I][R][S][O], taps flipped: the weights pfr_conv2d_fwd needs to compute the data gradient */
 int pfr_weight_dgrad_layout(const void* w, void* wt, int dtype, int O, int R, int S, int I, pfr_stream_t stream);
 int pfr_add(const void* a, const void* b, void* y, int dtype, size_t n, pfr_stream_t stream);
-int pfr_colsum(const void* x, int dtype, int rows, int C, float* out, int accumulate, pfr_stream_t stream);
+long pfr_colsum_ws_floats(long rows, int C); /* 0 for small row counts */
+int pfr_colsum(const void* x, int dtype, long rows, int C, float* out, int accumulate, float* workspace, pfr_stream_t stream);
 int pfr_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long rows, int cols, float scale, int accumulate,
                    pfr_stream_t stream);
 

@@ -134,7 +134,9 @@ def colsum(x, out=None, accumulate=False):
     rows, C = x.shape
     if out is None:
         out = torch.empty(C, dtype=torch.float32, device=x.device)
-    lib.pfr_colsum(_p(x), dtype_id(x.dtype), rows, C, _p(out), int(accumulate), _stream())
+    nws = lib.pfr_colsum_ws_floats(rows, C)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    lib.pfr_colsum(_p(x), dtype_id(x.dtype), rows, C, _p(out), int(accumulate), _p(ws), _stream())
     return out
 
 

@@ -812,12 +812,59 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     out[c] = accumulate ? out[c] + a : a;
   }
 }
-extern "C" int pfr_colsum(const void* x, int dtype, int rows, int C, float* out, int accumulate, hipStream_t st) {
+// partial column sums of row block blockIdx.y: grid (ceil(C/64), nblk) → part [nblk][C]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, float* __restrict__ part, long rows, int C,
+                                                          long rows_per_block) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  __shared__ float l[4][64];
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    long r = r0 + rl;
+    for (; r + 4 < r1; r += 8) {
+      a0 += to_f32(x[(size_t)r * C + c]);
+      a1 += to_f32(x[(size_t)(r + 4) * C + c]);
+    }
+    for (; r < r1; r += 4) a0 += to_f32(x[(size_t)r * C + c]);
+  }
+  l[rl][threadIdx.x & 63] = a0 + a1;
+  __syncthreads();
+  if (rl == 0 && c < C) part[(size_t)blockIdx.y * C + c] = l[0][threadIdx.x] + l[1][threadIdx.x] + l[2][threadIdx.x] + l[3][threadIdx.x];
+}
+
+static long colsum_blocks(long rows, int C) {
+  if (rows <= 2048) return 0;  // single-kernel path
+  long want = 2048 / ((C + 63) / 64);
+  if (want < 8) want = 8;
+  const long maxb = (rows + 255) / 256;
+  return want < maxb ? want : maxb;
+}
+extern "C" long pfr_colsum_ws_floats(long rows, int C) { return colsum_blocks(rows, C) * C; }
+
+extern "C" int pfr_colsum(const void* x, int dtype, long rows, int C, float* out, int accumulate, float* workspace,
+                          hipStream_t st) {
   PFR_CHECK_ARG(x && out, "pfr_colsum: null pointer");
+  const long nblk = colsum_blocks(rows, C);
+  if (nblk > 0) {
+    PFR_CHECK_ARG(workspace, "pfr_colsum: workspace of pfr_colsum_ws_floats(rows, C) floats required for %ld rows", rows);
+    const long rpb = (rows + nblk - 1) / nblk;
+    const dim3 grid((C + 63) / 64, (unsigned)nblk);
+    if (dtype == PFR_BF16)
+      hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, workspace, rows, C, rpb);
+    else
+      hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(256), 0, st, (const float*)x, workspace, rows, C, rpb);
+    PFR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)workspace, out, (int)nblk, C, accumulate);
+    PFR_CHECK_LAUNCH();
+    return PFR_OK;
+  }
   if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, out, rows, C, accumulate);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, out, (int)rows, C, accumulate);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)x, out, rows, C, accumulate);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)x, out, (int)rows, C, accumulate);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

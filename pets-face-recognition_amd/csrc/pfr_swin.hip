@@ -57,51 +57,97 @@ extern "C" int pfr_layernorm_fwd(const void* x, const float* gamma, const float*
 
 // dx = rstd·(g − mean(g) − x̂·mean(g·x̂)),  g = dy·γ ;  per-block partials of dγ = Σ dy·x̂, dβ = Σ dy  → part [2][nblk][C]
 // `dres` (optional) is added to dx: the residual branch gradient that joins at the LayerNorm input.
-template <typename T>
+// NKC = channels per lane = ceil(C/64) (compile-time so that the per-lane partial sums live in registers)
+template <typename T, int LN_MAXK>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const T* __restrict__ dres,
                                                             T* __restrict__ dx, float* __restrict__ part, long rows, int C,
                                                             int rows_per_block) {
-  extern __shared__ float sh[];  // [2][C] block partials
+  extern __shared__ float sh[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < 2 * C; c += 256) sh[c] = 0.f;
-  __syncthreads();
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  // lane owns channels lane, lane+64, ...: dγ / dβ partials stay in registers over all rows of this wave
+  float ag[LN_MAXK], ab[LN_MAXK], gm[LN_MAXK];
+  constexpr int nkc = LN_MAXK;
+#pragma unroll
+  for (int k = 0; k < LN_MAXK; ++k) {
+    ag[k] = 0.f; ab[k] = 0.f;
+    gm[k] = (k < nkc && lane + 64 * k < C) ? gamma[lane + 64 * k] : 0.f;
+  }
   for (long row = r0 + wave; row < r1; row += 4) {
     const T* xr = x + row * C;
     const T* gr = dy + row * C;
     const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAXK], dv[LN_MAXK];
     float a = 0.f, b = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float xh = (to_f32(xr[c]) - mu) * rs;
-      const float g = to_f32(gr[c]) * gamma[c];
-      a += g;
-      b = fmaf(g, xh, b);
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) {
+      if (k < nkc) {
+        const int c = lane + 64 * k;
+        const bool ok = c < C;
+        xh[k] = ok ? (to_f32(xr[c]) - mu) * rs : 0.f;
+        dv[k] = ok ? to_f32(gr[c]) : 0.f;
+        const float g = dv[k] * gm[k];
+        a += g;
+        b = fmaf(g, xh[k], b);
+      }
     }
     a = wave_sum(a) / C;
     b = wave_sum(b) / C;
-    for (int c = lane; c < C; c += 64) {
-      const float xh = (to_f32(xr[c]) - mu) * rs;
-      const float d = to_f32(gr[c]);
-      float v = rs * (d * gamma[c] - a - xh * b);
-      if (dres) v += to_f32(dres[row * C + c]);
-      dx[row * C + c] = from_f32<T>(v);
-      atomicAdd(&sh[c], d * xh);       // LDS atomics, 4 waves per block
-      atomicAdd(&sh[C + c], d);
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) {
+      if (k < nkc) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+          float v = rs * (dv[k] * gm[k] - a - xh[k] * b);
+          if (dres) v += to_f32(dres[row * C + c]);
+          dx[row * C + c] = from_f32<T>(v);
+          ag[k] = fmaf(dv[k], xh[k], ag[k]);
+          ab[k] += dv[k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LN_MAXK; ++k) {
+    if (k < nkc && lane + 64 * k < C) {
+      sh[(wave * 2 + 0) * C + lane + 64 * k] = ag[k];
+      sh[(wave * 2 + 1) * C + lane + 64 * k] = ab[k];
     }
   }
   __syncthreads();
   // layout [2][nblk][C]: all dgamma partial rows, then all dbeta partial rows (each half is a plain [nblk][C] matrix)
-  for (int c = threadIdx.x; c < 2 * C; c += 256)
-    part[((size_t)(c / C) * gridDim.x + blockIdx.x) * C + (c % C)] = sh[c];
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int q = c / C, cc = c % C;
+    const float v = sh[(0 * 2 + q) * C + cc] + sh[(1 * 2 + q) * C + cc] + sh[(2 * 2 + q) * C + cc] + sh[(3 * 2 + q) * C + cc];
+    part[((size_t)q * gridDim.x + blockIdx.x) * C + cc] = v;
+  }
 }
 
 extern "C" int pfr_layernorm_bwd_blocks(long rows) {
-  long nb = (rows + 255) / 256;
-  if (nb > 1024) nb = 1024;
+  long nb = (rows + 15) / 16;   // >= 4 rows per wave: the row loop is latency-bound, so favour many resident waves
+  if (nb > 16384) nb = 16384;
   return (int)(nb < 1 ? 1 : nb);
+}
+
+template <typename T>
+static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                         const void* dres, void* dx, float* part, long rows, int C, int nb, int rpb, hipStream_t st) {
+  const size_t shb = (size_t)8 * C * sizeof(float);
+  const int nkc = (C + 63) / 64;
+#define PFR_LN_CASE(K)                                                                                                  \
+  if (nkc <= K) {                                                                                                       \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, K>), dim3(nb), dim3(256), shb, st, (const T*)dy, (const T*)x, mean, rstd, gamma, \
+                       (const T*)dres, (T*)dx, part, rows, C, rpb);                                                    \
+    return PFR_OK;                                                                                                      \
+  }
+  PFR_LN_CASE(2) PFR_LN_CASE(3) PFR_LN_CASE(4) PFR_LN_CASE(6) PFR_LN_CASE(8) PFR_LN_CASE(12) PFR_LN_CASE(16) PFR_LN_CASE(24)
+  PFR_LN_CASE(32)
+#undef PFR_LN_CASE
+  pfr_set_error("pfr_layernorm_bwd: C > 2048");
+  return PFR_ERR_UNSUPPORTED;
 }
 
 extern "C" int pfr_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
@@ -109,11 +155,9 @@ extern "C" int pfr_layernorm_bwd(const void* dy, const void* x, const float* mea
   PFR_CHECK_ARG(dy && x && mean && rstd && gamma && dx && part, "pfr_layernorm_bwd: null pointer");
   const int nb = pfr_layernorm_bwd_blocks(rows);
   const int rpb = (int)((rows + nb - 1) / nb);
-  const size_t shb = (size_t)2 * C * sizeof(float);
-  if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), shb, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, part, rows, C, rpb);
-  else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb), dim3(256), shb, st, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, part, rows, C, rpb);
+  int rc = dtype == PFR_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, part, rows, C, nb, rpb, st)
+                             : ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, part, rows, C, nb, rpb, st);
+  if (rc != PFR_OK) return rc;
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

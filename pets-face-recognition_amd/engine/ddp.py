@@ -83,7 +83,8 @@ class FlatDDP:
         self.eng = eng
         # replicate rank 0's parameters / BN buffers
         dist.broadcast(eng.master, 0, group=group)
-        dist.broadcast(eng.stats, 0, group=group)
+        if hasattr(eng, "stats"):
+            dist.broadcast(eng.stats, 0, group=group)   # BN running statistics (ResNet engines)
         self.extra = [p for n, p in model_loss.named_parameters() if not n.startswith("module.")]
         for p in self.extra:
             dist.broadcast(p.data, 0, group=group)

@@ -513,7 +513,7 @@ class FEEngine:
                     a[-1] = acc if fn == "wgrad" else 0
                     res.append((lib.pfr_conv2d_wgrad, tuple(a)))
                 elif fn == "colsum":
-                    res.append((lib.pfr_colsum, tuple(args[:-1]) + (acc,)))
+                    res.append((lib.pfr_colsum, tuple(args[:-1]) + (acc, 0)))
                 elif fn == "copy2d":
                     res.append((lib.pfr_copy2d_f32, tuple(args[:-1]) + (acc,)))
                 elif fn is lib.pfr_bn_bwd_finalize:

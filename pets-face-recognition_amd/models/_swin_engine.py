@@ -198,8 +198,11 @@ class SwinEngine:
             ops.append((lib.pfr_conv2d_fwd, (dy.data_ptr(), r.wt.data_ptr(), dx.data_ptr(), did, did, rows, 1, 1, r.out, r.inp, 1,
                                              1, 1, 0, 0, 1, 1, r.inp, 0, 0, 0, 0, 0, 0, 0, 0)))
 
+        cs_need = [0]
+
         def colsum(ops, x, rows, C, out, dt=None):
-            ops.append((lib.pfr_colsum, (x.data_ptr(), dt if dt is not None else did, rows, C, out.data_ptr(), 0)))
+            cs_need[0] = max(cs_need[0], lib.pfr_colsum_ws_floats(rows, C))
+            ops.append(("colsum", (x.data_ptr(), dt if dt is not None else did, rows, C, out.data_ptr(), 0, None)))
 
         x_nhwc = A((N, H, W, self.cp))
         cur, cshape = x_nhwc, (N, H, W, self.cp)
@@ -268,8 +271,8 @@ class SwinEngine:
             part = G((2, nb, C), torch.float32)
             ops.append((lib.pfr_layernorm_bwd, (dy.data_ptr(), xin.data_ptr(), mu.data_ptr(), rs.data_ptr(), lnrec.gamma.data_ptr(),
                                                 0 if dres is None else dres.data_ptr(), dx.data_ptr(), part.data_ptr(), did, rows, C)))
-            ops.append((lib.pfr_colsum, (part[0].data_ptr(), 0, nb, C, lnrec.dgamma.data_ptr(), 0)))
-            ops.append((lib.pfr_colsum, (part[1].data_ptr(), 0, nb, C, lnrec.dbeta.data_ptr(), 0)))
+            colsum(ops, part[0], nb, C, lnrec.dgamma, 0)
+            colsum(ops, part[1], nb, C, lnrec.dbeta, 0)
             release(part)
 
         demb = A((N, self.emb_dim))
@@ -319,7 +322,7 @@ class SwinEngine:
                 bwd.append((lib.pfr_window_attn_bwd, (sv["qkv"].data_ptr(), b["pos"].data_ptr(), datt.data_ptr(), dqkv.data_ptr(),
                                                       dpart.data_ptr(), did, N, OH, OW, b["heads"], b["hd"], b["w"], b["shift"],
                                                       float(b["scale"]))))
-                bwd.append((lib.pfr_colsum, (dpart.data_ptr(), 0, nblk, ntab, b["dpos"].data_ptr(), 0)))
+                colsum(bwd, dpart, nblk, ntab, b["dpos"], 0)
                 release(dpart)
                 release(datt)
                 wgrad(bwd, sv["ln1"], (rows, 1, 1, C), dqkv, (rows, 1, 1, 3 * C), b["qkv"], 1, 1, b["qkv"].g)
@@ -348,6 +351,8 @@ class SwinEngine:
             bwd.append((None, (st["off"],)))
         if self.ws is None or self.ws.numel() < ws_need[0]:
             self.ws = torch.empty(ws_need[0], dtype=torch.float32, device=dev)
+        if getattr(self, "cs_ws", None) is None or self.cs_ws.numel() < cs_need[0]:
+            self.cs_ws = torch.empty(max(1, cs_need[0]), dtype=torch.float32, device=dev)
         plan["bwd_sym"] = bwd
         return plan
 
@@ -358,10 +363,12 @@ class SwinEngine:
                 a = list(args)
                 a[3] = self.ws.data_ptr()
                 res.append((lib.pfr_conv2d_wgrad, tuple(a)))
+            elif fn == "colsum":
+                res.append((lib.pfr_colsum, tuple(args[:-1]) + (self.cs_ws.data_ptr(),)))
             else:
                 res.append((fn, args))
         plan["bwd"] = res
-        plan["ws_ptr"] = self.ws.data_ptr()
+        plan["ws_ptr"] = (self.ws.data_ptr(), self.cs_ws.data_ptr())
 
     def get_plan(self, N, H, W, with_backward):
         key = (N, H, W, with_backward)
@@ -373,7 +380,7 @@ class SwinEngine:
             if with_backward:
                 self._finalize(p)
             self.plans[key] = p
-        elif with_backward and p["ws_ptr"] != self.ws.data_ptr():
+        elif with_backward and p["ws_ptr"] != (self.ws.data_ptr(), self.cs_ws.data_ptr()):
             self._finalize(p)
         return p
 
