@@ -47,7 +47,7 @@ struct IgemmParams {
 #define PFR_IGEMM_NST 2
 #endif
 
-template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP>
+template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_>
 __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   constexpr int KP = DT<T>::KPACK;
   constexpr int KCH = KCH_;                    // 16-byte chunks per LDS row per k-step (4: 64-B rows, 8: 128-B rows)
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   constexpr int QCH = BQ / (NW * RPI), PCH = BP / (NW * RPI);  // DMA instructions per thread per operand per k-step
   static_assert(TP >= 1 && TQ >= 1 && QCH >= 1 && PCH >= 1, "tile too small for this wave grid");
   constexpr int NLD = QCH + PCH;
-  constexpr int NST = PFR_IGEMM_NST;           // LDS ring depth: loads are issued NST-1 k-steps ahead of their use
+  constexpr int NST = NST_;                    // LDS ring depth: loads are issued NST-1 k-steps ahead of their use
+  static_assert(NST >= 2 && NST <= 4 && (!PRO || NST <= 3), "unsupported ring depth");
   constexpr int STAGE = (BP + BQ) * ROWB;
   constexpr int KPO = 16 / (int)sizeof(TO);
   constexpr int OROWB = BP * (int)sizeof(TO) + 16;
@@ -272,34 +273,41 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- NST-slot ring with counted waits: with NST = 3 the DMA of k-step kt+2 stays in flight across the barrier that
+  // ---- NST-slot ring with counted waits: the DMA of k-steps kt+2 … kt+NST-1 stays in flight across the barrier that
   //      publishes kt+1 (raw s_barrier: no implicit vmcnt(0) drain); NST = 2 is the classic double buffer.
+  auto wait_pending = [&](int tiles) {  // wait until at most `tiles` k-steps of DMA remain outstanding
+    if (NST >= 4 && tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+    else if (NST >= 3 && tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   const int nk = nk_all;
-  gload(0);
-  if (NST == 3 && nk > 1) {
-    gload(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-    if constexpr (PRO) { __syncthreads(); }  // coefficients visible
-    fixup(0, okA, cA);
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (PRO) { __syncthreads(); }
-    fixup(0, okB, cB);
+  const int npre = nk < NST - 1 ? nk : NST - 1;
+  for (int s0 = 0; s0 < npre; ++s0) gload(s0);
+  wait_pending(npre - 1);
+  if constexpr (PRO) {
+    __syncthreads();  // coefficients visible
+    if (npre > 1) fixup(0, okA, cA); else fixup(0, okB, cB);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const int slot = kt % NST;
-    if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
     const char* base = smem + slot * STAGE;
+#ifdef PFR_GLOAD_FIRST
+    if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
     mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc);
+#else
+    // the next tile's DMA is issued behind the first k-group's MFMAs (see mma_kstep_sw)
+    mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc, [&]() {
+      if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
+    });
+#endif
     if (kt + 1 < nk) {
-      if (NST == 3 && kt + 2 < nk) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-        fixup((kt + 1) % NST, okA, cA);
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        fixup((kt + 1) % NST, okB, cB);
+      const int last = kt + NST - 1 < nk - 1 ? kt + NST - 1 : nk - 1;  // newest k-step in flight
+      const int pending = last - (kt + 1);
+      wait_pending(pending);
+      if constexpr (PRO) {
+        if (pending >= 1) fixup((kt + 1) % NST, okA, cA); else fixup((kt + 1) % NST, okB, cB);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -441,18 +449,18 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename TO, int BQ, int BP, int KCH, int NW, int WP>
+template <typename T, typename TO, int BQ, int BP, int KCH, int NW, int WP, int NST = 2>
 static int launch_tile_k(IgemmParams& p, hipStream_t st) {
   p.tilesM = (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
   const dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(NW * 64);
   const bool fast = (p.C % (KCH * DT<T>::KPACK)) == 0;
   if (p.pro_scale) {
-    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, true, KCH, NW, WP>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, false, KCH, NW, WP>), grid, block, 0, st, p);
+    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, true, KCH, NW, WP, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, false, KCH, NW, WP, 2>), grid, block, 0, st, p);
   } else {
-    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true, KCH, NW, WP>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, false, KCH, NW, WP>), grid, block, 0, st, p);
+    if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true, KCH, NW, WP, NST>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, false, KCH, NW, WP, NST>), grid, block, 0, st, p);
   }
   PFR_CHECK_LAUNCH();
   return PFR_OK;
@@ -491,6 +499,11 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
   int bq;
   const int v = pick_tile(p.M, p.Cout, p.K, dtype, out_dtype, &bq);
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+    const char* big = getenv("PFR_IGEMM_BIGCFG");   // experiment switch: "k4n4" = 64-byte rows, 4-slot ring
+    if (big && big[0] == 'k') {
+      if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 4, 8, 2, 4>(p, st);
+      if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 4, 8, 2, 4>(p, st);
+    }
     if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 8, 8, 2>(p, st);
     if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 8, 8, 2>(p, st);
   }

@@ -23,6 +23,7 @@ struct WgradParams {
   int N, H, W, C, R, S, OH, OW, stride, pad;
   int Cout, lddy, M, KK;
   int splits, mchunk;
+  int simple;  // 1x1, stride 1, pad 0: the gathered row of x is row m itself (no (n,oh,ow) decomposition)
   const float* pro_scale;
   const float* pro_shift;
   int pro_relu;
@@ -30,8 +31,11 @@ struct WgradParams {
   int tilesP, tilesQ;
 };
 
+#ifndef PFR_WGRAD_MUL
+#define PFR_WGRAD_MUL 2
+#endif
 template <typename T> struct WG {
-  static constexpr int BMR = 64 / (int)sizeof(T);  // reduction rows per k-step: 32 bf16 / 16 f32
+  static constexpr int BMR = PFR_WGRAD_MUL * 64 / (int)sizeof(T);  // reduction rows per k-step (one barrier each)
 };
 
 template <typename T, int BP, int BQ, bool PRO>
@@ -94,7 +98,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     for (int i = 0; i < NCHQ; ++i) {
       const int m = mb + qrow0 + i * (256 / CPRQ);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (m < mend && kkok) {
+      if (m < mend && kkok && p.simple) {
+        v = ld16(xb + ((size_t)m * p.C + ci) * sizeof(T));
+        if constexpr (PRO) {
+          float f[KP];
+          Chunk<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < KP; ++e) {
+            float z = fmaf(f[e], psc[e], psh[e]);
+            f[e] = p.pro_relu ? fmaxf(z, 0.f) : z;
+          }
+          v = Chunk<T>::pack(f);
+        }
+      } else if (m < mend && kkok) {
         const uint32_t n_img = fdiv((uint32_t)m, p.div_ohow);
         const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
         const uint32_t oh = fdiv(rem, p.div_ow);
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       const int roff = (g >> 1) * 8 + (s >> 2);          // row within the 16-row k-group (plus q*4)
       const int coff = ((g & 1) * 16 + (s & 3) * 4) * 2;  // byte offset of this lane's 8-byte piece
 #pragma unroll
-      for (int kg = 0; kg < 2; ++kg) {
+      for (int kg = 0; kg < BMR / 16; ++kg) {
         bf16x8 fp[TP], fq[TQ];
 #pragma unroll
         for (int i = 0; i < TP; ++i) {
@@ -292,7 +308,8 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
   p.splits = pfr_conv2d_wgrad_splits(p.M, Cout, p.KK);
-  const int bmr = dtype == PFR_BF16 ? 32 : 16;
+  const int bmr = PFR_WGRAD_MUL * (dtype == PFR_BF16 ? 32 : 16);
+  p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
   int mchunk = (p.M + p.splits - 1) / p.splits;
   mchunk = (mchunk + bmr - 1) / bmr * bmr;
   p.mchunk = mchunk;
