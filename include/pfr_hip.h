@@ -164,6 +164,11 @@ int pfr_topk_rescore(const float* q, const float* g, int rows, int D, const int*
 int pfr_pair_similarity(const float* emb, int D, const long* idx_a, const long* idx_b, int P, float eps, float* out,
                         pfr_stream_t stream);
 
+/* mean-strategy card matching (generate_tsv.py:71-78,91-125): centroid of the L2-normalised photo embeddings of each card;
+ * seg [ncards+1] int64 row offsets; cent32 fp32 [ncards][D] (always written), cent (cent_dtype) optional copy */
+int pfr_card_centroids(const float* emb, const long* seg, int ncards, int D, float eps, float* cent32, void* cent,
+                       int cent_dtype, pfr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -276,3 +276,42 @@ extern "C" int pfr_pair_similarity(const float* emb, int D, const long* idx_a, c
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
+
+// card centroid of the reference's "mean strategy" (generate_tsv.py:71-78): the card-vs-card score is the mean over the
+// photo cross product of (cos+1)/2 = (⟨mean_i q̂_i, mean_j ĝ_j⟩ + 1)/2, so each card is reduced ONCE to the mean of its
+// L2-normalised photo embeddings and card matching becomes the same GEMM + top-K as photo matching.
+// one wave per card; seg[c] .. seg[c+1] are the photo rows of card c.
+template <typename TOo>
+__global__ __launch_bounds__(256) void card_centroid_kernel(const float* __restrict__ emb, const long* __restrict__ seg, int ncards,
+                                                            int D, float eps, float* __restrict__ cent32, TOo* __restrict__ cent) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= ncards) return;
+  const long r0 = seg[c], r1 = seg[c + 1];
+  const float invn = r1 > r0 ? 1.f / (float)(r1 - r0) : 0.f;
+  for (int d0 = lane; d0 < D; d0 += 64) {
+    if (cent32) cent32[(size_t)c * D + d0] = 0.f;
+  }
+  for (long r = r0; r < r1; ++r) {
+    const float* x = emb + (size_t)r * D;
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) ss = fmaf(x[d], x[d], ss);
+    ss = wave_sum(ss);
+    const float inv = invn / fmaxf(sqrtf(ss), eps);
+    for (int d = lane; d < D; d += 64) cent32[(size_t)c * D + d] += x[d] * inv;
+  }
+  if (cent)
+    for (int d = lane; d < D; d += 64) cent[(size_t)c * D + d] = from_f32<TOo>(cent32[(size_t)c * D + d]);
+}
+
+extern "C" int pfr_card_centroids(const float* emb, const long* seg, int ncards, int D, float eps, float* cent32, void* cent,
+                                  int cent_dtype, hipStream_t st) {
+  PFR_CHECK_ARG(emb && seg && cent32 && ncards > 0, "pfr_card_centroids: bad args");
+  const dim3 grid((ncards + 3) / 4);
+  if (cent && cent_dtype == PFR_BF16)
+    hipLaunchKernelGGL(card_centroid_kernel<bf16_t>, grid, dim3(256), 0, st, emb, seg, ncards, D, eps, cent32, (bf16_t*)cent);
+  else
+    hipLaunchKernelGGL(card_centroid_kernel<float>, grid, dim3(256), 0, st, emb, seg, ncards, D, eps, cent32, (float*)cent);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}

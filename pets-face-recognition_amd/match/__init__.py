@@ -17,14 +17,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self=False, rescore=None, slack=None):
+def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self=False, rescore=None, slack=None,
+                normalize=True):
     """Top-k gallery rows per query by cosine similarity.  q [Q,D], g [G,D] (any scale; rows are L2-normalised here).
     → (scores [Q,k] fp32 cosine, idx [Q,k] int32, −1 / −inf padded when fewer than k exist).
     exclude_self: q and g are the same set, the diagonal is skipped (the reference excludes the query itself).
     rescore (default: True for bf16): candidates are selected on bf16-input scores with `slack` extra entries, then
     re-scored exactly in fp32 and re-sorted, so that the final order is the fp32 order."""
     if not q.is_cuda:
-        return _cosine_topk_torch(q, g, k, exclude_self)
+        return _cosine_topk_torch(q, g, k, exclude_self, normalize)
     Q, D = q.shape
     G = g.shape[0]
     T = compute_dtype
@@ -36,11 +37,15 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     kc = min(kc, 512)
     q32 = q.float().contiguous()
     g32 = g.float().contiguous()
-    qn, _, _ = ops.l2norm_fwd(q32, T)
-    gn, _, _ = ops.l2norm_fwd(g32, T)
-    if rescore:
-        qn32, _, _ = ops.l2norm_fwd(q32, torch.float32)
-        gn32, _, _ = ops.l2norm_fwd(g32, torch.float32)
+    if normalize:
+        qn, _, _ = ops.l2norm_fwd(q32, T)
+        gn, _, _ = ops.l2norm_fwd(g32, T)
+        if rescore:
+            qn32, _, _ = ops.l2norm_fwd(q32, torch.float32)
+            gn32, _, _ = ops.l2norm_fwd(g32, torch.float32)
+    else:   # rows are used as given (card centroids)
+        qn, gn = (q32, g32) if T == torch.float32 else (ops.cast(q32, T), ops.cast(g32, T))
+        qn32, gn32 = q32, g32
     chunk = min(chunk, G)
     ld = (chunk + 3) // 4 * 4
     sbuf = torch.empty((Q, 1, 1, ld), dtype=torch.float32, device=q.device)
@@ -64,9 +69,9 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     return sc[:, :k].contiguous(), idx[:, :k].contiguous()
 
 
-def _cosine_topk_torch(q, g, k, exclude_self):
-    qn = q / q.norm(dim=1, keepdim=True).clamp_min(1e-8)
-    gn = g / g.norm(dim=1, keepdim=True).clamp_min(1e-8)
+def _cosine_topk_torch(q, g, k, exclude_self, normalize=True):
+    qn = q / q.norm(dim=1, keepdim=True).clamp_min(1e-8) if normalize else q
+    gn = g / g.norm(dim=1, keepdim=True).clamp_min(1e-8) if normalize else g
     sc = qn @ gn.t()
     if exclude_self:
         sc.fill_diagonal_(-float("inf"))
@@ -104,3 +109,53 @@ def pair_similarity(emb, idx_a, idx_b, eps=1e-8):
     out = torch.empty(ia.numel(), dtype=torch.float32, device=emb.device)
     lib.pfr_pair_similarity(e.data_ptr(), e.shape[1], ia.data_ptr(), ib.data_ptr(), ia.numel(), float(eps), out.data_ptr(), _stream())
     return out
+
+
+def card_centroids(emb, seg, compute_dtype=torch.float32):
+    """Mean of the L2-normalised photo embeddings per card.  emb [P, D]; seg: int64 [ncards+1] row offsets."""
+    seg = torch.as_tensor(seg, dtype=torch.int64, device=emb.device).contiguous()
+    n = seg.numel() - 1
+    if not emb.is_cuda:
+        e = emb.float() / emb.float().norm(dim=1, keepdim=True).clamp_min(1e-8)
+        return torch.stack([e[seg[i]:seg[i + 1]].mean(0) if seg[i + 1] > seg[i] else torch.zeros(e.shape[1]) for i in range(n)])
+    e = emb.float().contiguous()
+    out = torch.empty((n, e.shape[1]), dtype=torch.float32, device=emb.device)
+    lib.pfr_card_centroids(e.data_ptr(), seg.data_ptr(), n, e.shape[1], 1e-8, out.data_ptr(), 0, 0, _stream())
+    return out
+
+
+def card_match(q_emb, q_seg, g_emb, g_seg, k=100, compute_dtype=torch.bfloat16):
+    """Mean-strategy card-vs-card ranking of the reference's inference pipeline (generate_tsv.py:71-78, 91-125, one
+    modality): score(card_q, card_g) = clamp(mean over photo pairs of (cos+1)/2, min=0); → (scores [Q,k], idx [Q,k]),
+    best first.  The mean over the photo cross product equals (⟨centroid_q, centroid_g⟩ + 1)/2, so this is ONE GEMM of
+    card centroids with the running top-k."""
+    qc = card_centroids(q_emb, q_seg)
+    gc = card_centroids(g_emb, g_seg)
+    dots, idx = cosine_topk(qc, gc, k, compute_dtype=compute_dtype, normalize=False)
+    return ((dots + 1) / 2).clamp_min(0), idx
+
+
+def cosine_topk_sharded(q, g_local, k, g_offset, group=None, **kw):
+    """Gallery sharded by rows across the ranks of `group` (each rank holds rows [g_offset, g_offset + len(g_local))),
+    queries replicated: local GEMM + top-k per rank, ONE all-gather of the (score, index) lists (k·8 bytes per query
+    and rank), merge to the global top-k on every rank.  SURVEY.md §8e."""
+    import torch.distributed as dist
+    sc, idx = cosine_topk(q, g_local, k, **kw)
+    kk = sc.shape[1]
+    if kk < k:   # pad short lists so that every rank gathers equal shapes
+        pad = k - kk
+        sc = torch.cat([sc, torch.full((sc.shape[0], pad), -float("inf"), device=sc.device)], 1)
+        idx = torch.cat([idx, torch.full((idx.shape[0], pad), -1, dtype=idx.dtype, device=idx.device)], 1)
+    gidx = torch.where(idx >= 0, idx.long() + int(g_offset), idx.long())
+    world = dist.get_world_size(group)
+    all_sc = [torch.empty_like(sc) for _ in range(world)]
+    all_ix = [torch.empty_like(gidx) for _ in range(world)]
+    dist.all_gather(all_sc, sc.contiguous(), group=group)
+    dist.all_gather(all_ix, gidx.contiguous(), group=group)
+    S, I = torch.cat(all_sc, 1), torch.cat(all_ix, 1)
+    # merge: score descending, ties → lower global index
+    key_i = torch.where(I >= 0, I, torch.full_like(I, 2 ** 62))
+    order = torch.argsort(key_i, dim=1, stable=True)
+    S, I = torch.gather(S, 1, order), torch.gather(I, 1, order)
+    order = torch.argsort(S, dim=1, descending=True, stable=True)[:, :k]
+    return torch.gather(S, 1, order), torch.gather(I, 1, order)

@@ -118,3 +118,30 @@ def test_ddp_gloo_world2(tmp_path):
                         "127.0.0.1", "--master-port", "29631", str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count("ok") == 2
+
+
+_SHARD_SCRIPT = textwrap.dedent("""
+    import sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from pets_face_recognition_amd.match import cosine_topk, cosine_topk_sharded
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(40, 64, generator=g); gal = torch.randn(1001, 64, generator=g)
+    gal[900] = gal[17]                                   # duplicate row across shards: tie → lower global index
+    bounds = [0, 430, 1001]
+    sc, idx = cosine_topk_sharded(q, gal[bounds[rank]:bounds[rank + 1]], 25, bounds[rank])
+    ref_sc, ref_idx = cosine_topk(q, gal, 25)
+    assert torch.allclose(sc, ref_sc, atol=1e-6) and torch.equal(idx, ref_idx.long()), (rank)
+    dist.destroy_process_group()
+    print('rank', rank, 'ok')
+""")
+
+
+def test_gallery_sharded_match_gloo_world2(tmp_path):
+    script = tmp_path / "shard_check.py"
+    script.write_text(_SHARD_SCRIPT.format(root=ROOT))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29633", str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("ok") == 2

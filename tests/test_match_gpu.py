@@ -63,3 +63,31 @@ def test_query_gallery_topk_chunked(dtype):
     sc2, idx2 = cosine_topk(qry[:5].to(DEV), gal[:40].to(DEV), K, compute_dtype=dtype)
     torch.cuda.synchronize()
     assert (idx2[:, 40:] == -1).all() and (idx2[:, :40] >= 0).all()
+
+
+def test_card_match_mean_strategy_vs_reference_formula():
+    """generate_tsv.py:71-78: card score = clamp(mean over the photo cross product of (cos+1)/2, 0) — literal double loop
+    on CPU vs the centroid-GEMM path on the GPU."""
+    from pets_face_recognition_amd.match import card_match
+    g = torch.Generator().manual_seed(8)
+    D, nq, ng = 512, 17, 230
+    qn = torch.randint(1, 5, (nq,), generator=g); gn = torch.randint(1, 6, (ng,), generator=g)
+    qseg = torch.cat([torch.zeros(1, dtype=torch.long), qn.cumsum(0)]); gseg = torch.cat([torch.zeros(1, dtype=torch.long), gn.cumsum(0)])
+    centers = torch.randn(40, D, generator=g)
+    gcard_cls = torch.randint(0, 40, (ng,), generator=g); qcard_cls = torch.randint(0, 40, (nq,), generator=g)
+    gemb = torch.cat([centers[gcard_cls[i]] + 1.5 * torch.randn(int(gn[i]), D, generator=g) for i in range(ng)])
+    qemb = torch.cat([centers[qcard_cls[i]] + 1.5 * torch.randn(int(qn[i]), D, generator=g) for i in range(nq)])
+    from oracle.arcface_ref import similarity_f
+    ref = torch.zeros(nq, ng)
+    for i in range(nq):
+        a = qemb[qseg[i]:qseg[i + 1]]
+        for j in range(ng):
+            b = gemb[gseg[j]:gseg[j + 1]]
+            pa = a.repeat_interleave(b.shape[0], 0); pb = b.repeat(a.shape[0], 1)
+            ref[i, j] = similarity_f(pa, pb).mean().clamp(min=0.0)
+    rs, ri = torch.sort(ref, dim=1, descending=True, stable=True)
+    for dt in (torch.float32, torch.bfloat16):
+        sc, idx = card_match(qemb.to(DEV), qseg, gemb.to(DEV), gseg, k=100, compute_dtype=dt)
+        torch.cuda.synchronize()
+        assert torch.allclose(sc.cpu(), rs[:, :100], rtol=1e-5, atol=1e-6)
+        assert (idx.cpu().long() == ri[:, :100]).float().mean() > 0.999
