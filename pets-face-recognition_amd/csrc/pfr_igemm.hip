@@ -37,6 +37,10 @@ struct IgemmParams {
   int out_relu;
   FastDiv div_ohow, div_ow;
   int tilesM, tilesN;
+  // parity-class mode (data gradient of a stride-2 conv, FAST path): output rows are processed per (oh%2, ow%2) class so
+  // that only the taps that exist for that class are visited (a 3x3/s2 dgrad does 9/4 instead of 9 taps per output).
+  int pclass, mclass, tpc;
+  FastDiv div_chw, div_cw;
 };
 
 // tile geometry knobs: chunks of 16 B per LDS row per k-step, and LDS ring depth
@@ -78,7 +82,28 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
 
   const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = t % p.tilesN, tm = t / p.tilesN;
-  const int m0 = tm * BQ, n0 = tn * BP;
+  const int n0 = tn * BP;
+  const int cls = p.pclass ? tm / p.tpc : 0;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int m0 = (p.pclass ? tm - cls * p.tpc : tm) * BQ;   // first row of the tile (within its parity class, if any)
+  const int mlim = p.pclass ? p.mclass : p.M;
+  // tile row -> (image, oh, ow); returns false past the end
+  auto decode = [&](int m, uint32_t& n_img, uint32_t& oh, uint32_t& ow) -> bool {
+    if (m >= mlim) return false;
+    if (p.pclass) {
+      n_img = fdiv((uint32_t)m, p.div_chw);
+      const uint32_t rem = m - n_img * (uint32_t)((p.OH >> 1) * (p.OW >> 1));
+      const uint32_t i = fdiv(rem, p.div_cw);
+      oh = 2 * i + ph;
+      ow = 2 * (rem - i * (p.OW >> 1)) + pw;
+    } else {
+      n_img = fdiv((uint32_t)m, p.div_ohow);
+      const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
+      oh = fdiv(rem, p.div_ow);
+      ow = rem - oh * p.OW;
+    }
+    return true;
+  };
 
   // staging geometry: wave w, pass j covers tile rows (j*4 + w)*RPI .. +RPI, lane l -> row l/KCH, physical chunk l%KCH;
   // the logical (k) chunk it must fetch is phys ^ swizzle(row), which is the same for every pass j.
@@ -90,11 +115,8 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
   for (int j = 0; j < QCH; ++j) {
     const int m = m0 + (j * NW + wave) * RPI + rsub;
-    if (m < p.M) {
-      const uint32_t n_img = fdiv((uint32_t)m, p.div_ohow);
-      const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
-      const uint32_t oh = fdiv(rem, p.div_ow);
-      const uint32_t ow = rem - oh * p.OW;
+    uint32_t n_img, oh, ow;
+    if (decode(m, n_img, oh, ow)) {
       ihb[j] = (int)oh * p.ostride - p.pad;
       iwb[j] = (int)ow * p.ostride - p.pad;
       pixb[j] = n_img * p.H * p.W;
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   const uint32_t OOBB = 0xF0000000u;
   uint32_t qbase[QCH], wbase[PCH];
   uint32_t okcur = 0;
-  int u_tr = 0, u_ts = 0, cbyte = 0, kbyte = 0;  // uniform (scalar) walker state
+  int u_tr = 0, u_ts = 0, cbyte = 0;  // uniform (scalar) walker state
   auto newtap = [&]() {
     okcur = 0;
 #pragma unroll
@@ -151,29 +173,24 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
       okcur |= ok ? (1u << j) : 0u;
     }
   };
-  // optional k-loop rotation (-DPFR_KROT): workgroup (tm,tn) starts its reduction at a different k-step and wraps.
-  // Measured: it HURTS (c3x3 256ch 14x14: 80 → 104 µs) — lock-step workgroups sharing one L2 fetch of the same weight
-  // k-slice is a benefit, not a hot spot.  Kept only as an experiment switch.
-  const int nk_all = (p.K + BK - 1) / BK;
-  int kwrap = 0;  // k-steps until the walker wraps to k = 0
+  // tap walk: all taps (step 1), or — in parity-class mode — only the taps whose dilated coordinate is even for this class
+  const int tstep = p.pclass ? 2 : 1;
+  const int tr0 = p.pclass ? ((p.pad + ph) & 1) : 0, ts0 = p.pclass ? ((p.pad + pw) & 1) : 0;
+  int nk_all = (p.K + BK - 1) / BK;
+  int tapbyte = 0;  // byte offset of the current tap inside a weight row
   if constexpr (FAST) {
 #pragma unroll
     for (int j = 0; j < PCH; ++j) {
       const int row = n0 + (j * NW + wave) * RPI + rsub;
       wbase[j] = row < p.Cout ? (uint32_t)(((size_t)row * p.K + lc * KP) * sizeof(T)) : OOBB;
     }
-#ifdef PFR_KROT
-    const int kstart = (int)(((unsigned)tm * 5u + (unsigned)tn * 3u) % (unsigned)nk_all);
-#else
-    const int kstart = 0;
-#endif
-    const int spt = p.C / BK;          // k-steps per tap
-    const int tap0 = kstart / spt;
-    u_tr = tap0 / p.S;
-    u_ts = tap0 - u_tr * p.S;
-    cbyte = (kstart - tap0 * spt) * BK * (int)sizeof(T);
-    kbyte = kstart * BK * (int)sizeof(T);
-    kwrap = nk_all - kstart;
+    if (p.pclass) {
+      const int ntr = (p.R - tr0 + 1) / 2, nts = (p.S - ts0 + 1) / 2;
+      nk_all = ntr * nts * (p.C / BK);
+    }
+    u_tr = tr0;
+    u_ts = ts0;
+    tapbyte = (u_tr * p.S + u_ts) * p.C * (int)sizeof(T);
     newtap();
   }
 
@@ -184,21 +201,19 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int j = 0; j < PCH; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * NW + wave) * RPI * ROWB),
-                                                 16, (int)(wbase[j] + (uint32_t)kbyte), 0, 0, 0);
+                                                 16, (int)(wbase[j] + (uint32_t)(tapbyte + cbyte)), 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < QCH; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * NW + wave) * RPI) * ROWB),
                                                  16, (int)(qbase[j] + (uint32_t)cbyte), 0, 0, 0);
       okA = okB; cA = cB;
       okB = okcur; cB = cbyte / (int)sizeof(T) + lc * KP;
-      kbyte += BK * (int)sizeof(T);
       cbyte += BK * (int)sizeof(T);
-      if (--kwrap == 0) {  // wrap the rotated reduction back to k = 0
-        kbyte = 0; cbyte = 0; u_tr = 0; u_ts = 0;
-        newtap();
-      } else if (cbyte >= p.C * (int)sizeof(T)) {
+      if (cbyte >= p.C * (int)sizeof(T)) {
         cbyte = 0;
-        if (++u_ts == p.S) { u_ts = 0; ++u_tr; }
+        u_ts += tstep;
+        if (u_ts >= p.S) { u_ts = ts0; u_tr += tstep; }
+        tapbyte = (u_tr * p.S + u_ts) * p.C * (int)sizeof(T);
         newtap();
       }
       return;
@@ -359,8 +374,13 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   char* yb = reinterpret_cast<char*>(p.y);
 #pragma unroll 4
   for (int rr = rl; rr < BQ; rr += RPP) {
-    const int m = m0 + rr;
-    if (m >= p.M || co >= p.Cout) continue;
+    int m = m0 + rr;
+    if (m >= mlim || co >= p.Cout) continue;
+    if (p.pclass) {
+      uint32_t n_img, oh, ow;
+      decode(m, n_img, oh, ow);
+      m = (int)((n_img * p.OH + oh) * p.OW + ow);
+    }
     u32x4 v = *reinterpret_cast<const u32x4*>(smem + rr * OROWB + oc * 16);
     float f[KPO];
     Chunk<TO>::unpack(v, f);
@@ -440,7 +460,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
         a += red[(w * 2 + 0) * BP + ch];
         b += red[(w * 2 + 1) * BP + ch];
       }
-      const float nt = (float)min(BQ, p.M - m0);
+      const float nt = (float)min(BQ, mlim - m0);
       const float k = to_f32(*reinterpret_cast<const TO*>(smem + ch * (int)sizeof(TO)));
       p.stats_part[((size_t)tm * 2 + 0) * p.Cout + n0 + ch] = k + a / nt;          // tile mean
       p.stats_part[((size_t)tm * 2 + 1) * p.Cout + n0 + ch] = b - a * a / nt;      // tile M2 = Σ (x − mean_t)²
@@ -451,10 +471,15 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename TO, int BQ, int BP, int KCH, int NW, int WP, int NST = 2>
 static int launch_tile_k(IgemmParams& p, hipStream_t st) {
-  p.tilesM = (p.M + BQ - 1) / BQ;
+  const bool fast = (p.C % (KCH * DT<T>::KPACK)) == 0;
+  p.pclass = (fast && p.idil_log2 == 1 && p.ostride == 1 && p.R > 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part) ? 1 : 0;
+  p.mclass = p.N * (p.OH / 2) * (p.OW / 2);
+  p.tpc = (p.mclass + BQ - 1) / BQ;
+  p.div_chw = make_fastdiv((uint32_t)((p.OH / 2) * (p.OW / 2) > 0 ? (p.OH / 2) * (p.OW / 2) : 1));
+  p.div_cw = make_fastdiv((uint32_t)(p.OW / 2 > 0 ? p.OW / 2 : 1));
+  p.tilesM = p.pclass ? 4 * p.tpc : (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
   const dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(NW * 64);
-  const bool fast = (p.C % (KCH * DT<T>::KPACK)) == 0;
   if (p.pro_scale) {
     if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, true, KCH, NW, WP, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, false, KCH, NW, WP, 2>), grid, block, 0, st, p);

@@ -37,6 +37,8 @@ CONV_CASES = [
     (2, 32, 32, 8, 64, 7, 2, 3),
     (5, 7, 7, 512, 512, 3, 1, 1),
     (1, 9, 11, 32, 96, 3, 1, 1),
+    (2, 16, 16, 64, 128, 3, 2, 1),     # stride-2 3x3 with even extent: parity-class data gradient
+    (3, 28, 28, 128, 128, 3, 2, 1),
     (64, 28, 28, 128, 256, 3, 1, 1),   # 8-wave 256x256 / 256x128 tiles (bf16)
     (180, 14, 14, 256, 128, 3, 1, 1),
 ]
