@@ -13,6 +13,7 @@
 // The reduction over m is split across workgroups; each split writes an fp32 partial slab
 // [split][Cout][KK] (deterministic), summed by pfr_wgrad_reduce.
 #include "pfr_mma.h"
+#include <stdlib.h>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -23,6 +24,7 @@ struct WgradParams {
   int N, H, W, C, R, S, OH, OW, stride, pad;
   int Cout, lddy, M, KK;
   int splits, mchunk;
+  int v2;      // use the LDS-DMA kernel (no fused prologue)
   int simple;  // 1x1, stride 1, pad 0: the gathered row of x is row m itself (no (n,oh,ow) decomposition)
   const float* pro_scale;
   const float* pro_shift;
@@ -228,6 +230,187 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 (no fused prologue): both operand tiles are staged by LDS-DMA (buffer_load … lds) exactly as they lie in HBM
+// ([m][channel]); rows are unpadded (wave-linear DMA destination) and the 32-byte granules of a row are XOR-swizzled with
+// row bits so that the two 16-lane groups of a `ds_read_b64_tr_b16` (4 rows x 2 granules = 8 pieces of 32 B) cover all
+// 64 banks exactly once.  64 reduction rows (bf16) per barrier = 16 MFMAs per wave; out-of-range rows / padding taps /
+// channel tails are zero-filled by the buffer descriptor's bounds check.
+template <int GPR> __device__ __forceinline__ int gran_swz(int row) {   // GPR = 32-byte granules per LDS row
+  return GPR >= 8 ? ((row & 3) << 1) : (((row >> 1) & 1) << 1);
+}
+
+template <typename T, int BP, int BQ>
+__global__ __launch_bounds__(256) void wgrad2_kernel(WgradParams p) {
+  constexpr int KP = DT<T>::KPACK;
+  constexpr int BMR = 128 / (int)sizeof(T);              // reduction rows per k-step: 64 bf16 / 32 f32
+  constexpr int TP = BP / 64, TQ = BQ / 64;
+  constexpr int RSP = BP * (int)sizeof(T), RSQ = BQ * (int)sizeof(T);   // unpadded row bytes
+  constexpr int GPRP = RSP / 32, GPRQ = RSQ / 32;
+  constexpr int TILEP = BMR * RSP, TILEQ = BMR * RSQ, STAGE = TILEP + TILEQ;
+  constexpr int RPIP = 1024 / RSP, RPIQ = 1024 / RSQ;    // rows covered by one wave-wide DMA instruction
+  constexpr int NDP = BMR / (4 * RPIP), NDQ = BMR / (4 * RPIQ);   // DMA instructions per thread per k-step
+  constexpr bool SWZ = sizeof(T) == 2;                    // f32 fragments are read with ds_read_b32: no swizzle needed
+  static_assert(NDP >= 1 && NDQ >= 1, "tile too wide");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave >> 1, wq = wave & 1;
+
+  const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = p.tilesP * p.tilesQ;
+  const int split = t / ntile, tile = t % ntile;
+  const int tq = tile % p.tilesQ, tpp = tile / p.tilesQ;
+  const int co0 = tpp * BP, kk0 = tq * BQ;
+  const int mbeg = split * p.mchunk;
+  const int mend = min(p.M, mbeg + p.mchunk);
+
+  // DMA geometry: lane l of a wave instruction lands at tile row (l / CPR), physical 16-byte chunk (l % CPR)
+  constexpr int CPRP = RSP / 16, CPRQ = RSQ / 16;
+  const int prsub = lane / CPRP, qrsub = lane / CPRQ;
+  int pchunk = lane % CPRP, qchunk = lane % CPRQ;
+  if constexpr (SWZ) {   // logical chunk fetched into this physical slot (row & 7 depends on the lane only: passes add multiples of 8... see RPI)
+    pchunk = ((((pchunk >> 1) ^ gran_swz<GPRP>((wave * RPIP + prsub))) << 1) | (pchunk & 1));
+    qchunk = ((((qchunk >> 1) ^ gran_swz<GPRQ>((wave * RPIQ + qrsub))) << 1) | (qchunk & 1));
+  }
+  const int pco = co0 + pchunk * KP;
+  const int kk = kk0 + qchunk * KP;
+  const bool kkok = kk < p.KK;
+  const int tap = kkok ? kk / p.C : 0;
+  const int ci = kk - tap * p.C;
+  const int tr = tap / p.S, ts = tap - tr * p.S;
+
+  const uint32_t OOB = 0xFFFFFF00u;
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.C * sizeof(T)), 0x00020000);
+  __amdgpu_buffer_rsrc_t drsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)((size_t)p.M * p.lddy * sizeof(T)), 0x00020000);
+
+  auto gload = [&](int buf, int mb) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < NDP; ++j) {
+      const int m = mb + (j * 4 + wave) * RPIP + prsub;
+      const uint32_t off = (m < mend && pco < p.Cout) ? (uint32_t)(((size_t)m * p.lddy + pco) * sizeof(T)) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (__attribute__((address_space(3))) void*)(base + (j * 4 + wave) * RPIP * RSP),
+                                               16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NDQ; ++j) {
+      const int m = mb + (j * 4 + wave) * RPIQ + qrsub;
+      uint32_t off = OOB;
+      if (m < mend && kkok) {
+        if (p.simple) {
+          off = (uint32_t)(((size_t)m * p.C + ci) * sizeof(T));
+        } else {
+          const uint32_t n_img = fdiv((uint32_t)m, p.div_ohow);
+          const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
+          const uint32_t oh = fdiv(rem, p.div_ow);
+          const uint32_t ow = rem - oh * p.OW;
+          const int ih = (int)oh * p.stride - p.pad + tr, iw = (int)ow * p.stride - p.pad + ts;
+          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+            off = (uint32_t)(((size_t)((n_img * p.H + ih) * p.W + iw) * p.C + ci) * sizeof(T));
+        }
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + TILEP + (j * 4 + wave) * RPIQ * RSQ),
+                                               16, (int)off, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[TP][TQ];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (mend - mbeg + BMR - 1) / BMR;
+  if (nk > 0) gload(0, mbeg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const char* bp = smem + buf * STAGE;
+    const char* bq = smem + buf * STAGE + TILEP;
+    bool issued = false;
+    auto mid = [&]() {
+      if (!issued && kt + 1 < nk) gload(buf ^ 1, mbeg + (kt + 1) * BMR);
+      issued = true;
+    };
+    if constexpr (sizeof(T) == 2) {
+      // lane l: g = l>>4 ; fragment column (channel) = (g&1)*16 + (l&15) = l&31 ; k-half = g>>1 = l>>5
+      const int g = lane >> 4, s4 = lane & 15;
+#pragma unroll
+      for (int kg = 0; kg < BMR / 16; ++kg) {
+        bf16x8 fp[TP], fq[TQ];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int r = kg * 16 + (g >> 1) * 8 + q * 4 + (s4 >> 2);
+#pragma unroll
+          for (int i = 0; i < TP; ++i) {
+            const int gran = (wp * (BP / 2) + i * 32) / 16 + (g & 1);
+            const char* a = bp + r * RSP + ((gran ^ gran_swz<GPRP>(r)) << 5) + (s4 & 3) * 8;
+            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+            u32x2 v2 = __builtin_bit_cast(u32x2, v);
+            u32x4 u = __builtin_bit_cast(u32x4, fp[i]);
+            u[2 * q] = v2[0]; u[2 * q + 1] = v2[1];
+            fp[i] = __builtin_bit_cast(bf16x8, u);
+          }
+#pragma unroll
+          for (int j = 0; j < TQ; ++j) {
+            const int gran = (wq * (BQ / 2) + j * 32) / 16 + (g & 1);
+            const char* a = bq + r * RSQ + ((gran ^ gran_swz<GPRQ>(r)) << 5) + (s4 & 3) * 8;
+            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+            u32x2 v2 = __builtin_bit_cast(u32x2, v);
+            u32x4 u = __builtin_bit_cast(u32x4, fq[j]);
+            u[2 * q] = v2[0]; u[2 * q + 1] = v2[1];
+            fq[j] = __builtin_bit_cast(bf16x8, u);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[i], fq[j], acc[i][j], 0, 0, 0);
+        if (kg == 0) mid();
+      }
+    } else {
+      const int row = lane & 31, kh = lane >> 5;
+#pragma unroll
+      for (int e = 0; e < BMR / 2; ++e) {
+        float fp[TP], fq[TQ];
+#pragma unroll
+        for (int i = 0; i < TP; ++i) fp[i] = *reinterpret_cast<const float*>(bp + (2 * e + kh) * RSP + (wp * (BP / 2) + i * 32 + row) * 4);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) fq[j] = *reinterpret_cast<const float*>(bq + (2 * e + kh) * RSQ + (wq * (BQ / 2) + j * 32 + row) * 4);
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fp[i], fq[j], acc[i][j], 0, 0, 0);
+        if (e == 3) mid();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  float* out = p.dw + (size_t)split * p.Cout * p.KK;
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int col = kk0 + wq * (BQ / 2) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wp * (BP / 2) + i * 32 + acc_row(r, lane);
+        if (co < p.Cout && col < p.KK) out[(size_t)co * p.KK + col] = acc[i][j][r];
+      }
+    }
+}
+
 // sums the split slabs: block = 64 columns (of 4 floats) x 4 split-lanes; every lane keeps 4 independent loads in flight
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4,
                                                            int splits, float scale, int accumulate) {
@@ -264,6 +447,8 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
   const dim3 grid((unsigned)(p.tilesP * p.tilesQ * p.splits));
   if (p.pro_scale)
     hipLaunchKernelGGL((wgrad_kernel<T, BP, BQ, true>), grid, dim3(256), 0, st, p);
+  else if (p.v2)
+    hipLaunchKernelGGL((wgrad2_kernel<T, BP, BQ>), grid, dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL((wgrad_kernel<T, BP, BQ, false>), grid, dim3(256), 0, st, p);
   PFR_CHECK_LAUNCH();
@@ -308,7 +493,8 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
   p.splits = pfr_conv2d_wgrad_splits(p.M, Cout, p.KK);
-  const int bmr = PFR_WGRAD_MUL * (dtype == PFR_BF16 ? 32 : 16);
+  { const char* e = getenv("PFR_WGRAD_V2"); p.v2 = (!pro_scale && !(e && e[0] == '0')) ? 1 : 0; }
+  const int bmr = p.v2 ? (dtype == PFR_BF16 ? 64 : 32) : PFR_WGRAD_MUL * (dtype == PFR_BF16 ? 32 : 16);
   p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
   int mchunk = (p.M + p.splits - 1) / p.splits;
   mchunk = (mchunk + bmr - 1) / bmr * bmr;
