@@ -123,13 +123,15 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_ddp = world > 1 or os.environ.get("PFR_FORCE_DDP") == "1"   # the switch exercises the RCCL path on one GPU
+    if use_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     ml, opt = build(args, device)
     ddp = None
-    if world > 1:
+    if use_ddp:
         from pets_face_recognition_amd.engine import FlatDDP
         ddp = FlatDDP(ml)
 
