@@ -103,7 +103,7 @@ struct ColGeom {
   int gy;      // blocks along columns
   int gx;      // blocks along rows
 };
-static ColGeom col_geom(int C, int kp, size_t rows) {
+static ColGeom col_geom(int C, int kp, size_t rows, size_t target = 512) {
   ColGeom g;
   g.cpr = C / kp;
   int cw = 1;
@@ -111,7 +111,7 @@ static ColGeom col_geom(int C, int kp, size_t rows) {
   g.cw = cw;
   g.rl = 256 / cw;
   g.gy = (g.cpr + cw - 1) / cw;
-  size_t want = 1024 / g.gy;
+  size_t want = target / g.gy;
   size_t maxb = (rows + g.rl * 4 - 1) / (g.rl * 4);  // at least 4 rows per lane
   if (want > maxb) want = maxb;
   if (want < 1) want = 1;
@@ -389,7 +389,7 @@ extern "C" int pfr_bn_act(const void* x1, const float* a1, const float* b1, cons
   PFR_CHECK_ARG(x1 && a1 && b1 && y, "pfr_bn_act: null pointer");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_act: C %% %d != 0", kp);
-  ColGeom g = col_geom(C, kp, (size_t)rows);
+  ColGeom g = col_geom(C, kp, (size_t)rows, 512);   // pure streaming: many resident waves (no partial rows to merge)
   if (dtype == PFR_BF16)
     hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)x1, a1, b1, (const bf16_t*)x2, a2, b2, (bf16_t*)y, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
   else
@@ -551,7 +551,7 @@ extern "C" int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x
   PFR_CHECK_ARG(dout && x && coef && dx, "pfr_bn_bwd_apply: null pointer");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_apply: C %% %d != 0", kp);
-  ColGeom g = col_geom(C, kp, (size_t)rows);
+  ColGeom g = col_geom(C, kp, (size_t)rows, 512);
   if (dtype == PFR_BF16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, coef, scale, shift, mask_mode, (bf16_t*)dx, (bf16_t*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
   else
