@@ -245,6 +245,26 @@ __device__ __forceinline__ float wa_mask_bias(const WinAttn& a, int gy, int gx, 
   return b;
 }
 
+// bias(+mask) table of one attention block: tab[variant][i][j], variant = 2*(last window row) + (last window column),
+// rows padded to ntp = ceil4(w²) with −inf outside the w² x w² block (one tiny launch per block and step instead of integer
+// divisions per score element in every workgroup).
+__global__ void window_bias_table_kernel(const float* __restrict__ pos, float* __restrict__ tab, int w, int shift) {
+  const int nt = w * w, ntp = (nt + 3) & ~3;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 4 * ntp * ntp) return;
+  const int var = e / (ntp * ntp), i = (e / ntp) % ntp, j = e % ntp;
+  float b = -INFINITY;
+  if (i < nt && j < nt) {
+    const int yi = i / w, xi = i % w, yj = j / w, xj = j % w;
+    b = pos[(yj - yi + w - 1) * (2 * w - 1) + (xj - xi + w - 1)];
+    if (shift) {
+      if ((var & 2) && ((yi >= w - shift) != (yj >= w - shift))) b = -INFINITY;
+      if ((var & 1) && ((xi >= w - shift) != (xj >= w - shift))) b = -INFINITY;
+    }
+  }
+  tab[e] = b;
+}
+
 __device__ __forceinline__ size_t wa_token_off(const WinAttn& a, int b, int gy, int gx, int t) {
   int y = gy * a.w + t / a.w + a.shift, x = gx * a.w + t % a.w + a.shift;
   if (y >= a.H) y -= a.H;
@@ -252,58 +272,111 @@ __device__ __forceinline__ size_t wa_token_off(const WinAttn& a, int b, int gy, 
   return ((size_t)b * a.H + y) * a.W + x;
 }
 
+// LDS strides (floats): multiples of 4 so that 4 consecutive d / j values are one ds_read_b128
+#define WA_SD 36   // q/k/v/go rows: WA_MAXD + 4
+#define WA_SS 68   // score rows: WA_MAXT + 4
+
+// register-blocked helpers: each thread owns a 4x4 block of an output matrix and streams the reduction dimension with
+// 128-bit LDS reads (8 reads per 64 FMAs instead of 2 reads per FMA).
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
 template <typename T>
-__global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ pos,
+__global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ tab,
                                                               T* __restrict__ out, WinAttn a) {
-  __shared__ float q[WA_MAXT][WA_MAXD + 1], k[WA_MAXT][WA_MAXD + 1], v[WA_MAXT][WA_MAXD + 1];
-  __shared__ float s[WA_MAXT][WA_MAXT + 1];
+  __shared__ __attribute__((aligned(16))) float q[WA_MAXT * WA_SD], k[WA_MAXT * WA_SD], v[WA_MAXT * WA_SD];
+  __shared__ __attribute__((aligned(16))) float s[WA_MAXT * WA_SS];
   const int nwh = a.H / a.w, nww = a.W / a.w, nt = a.w * a.w, C = a.heads * a.hd;
   int bid = blockIdx.x;
   const int h = bid % a.heads; bid /= a.heads;
   const int gx = bid % nww; bid /= nww;
   const int gy = bid % nwh;
   const int b = bid / nwh;
-  for (int e = threadIdx.x; e < nt * a.hd; e += 256) {
-    const int t = e / a.hd, d = e % a.hd;
-    const T* base = qkv + wa_token_off(a, b, gy, gx, t) * (3 * C) + h * a.hd + d;
-    q[t][d] = to_f32(base[0]);
-    k[t][d] = to_f32(base[C]);
-    v[t][d] = to_f32(base[2 * C]);
+  const int ntp = (nt + 3) & ~3, hdp = (a.hd + 3) & ~3;
+  constexpr int KPL = DT<T>::KPACK;                      // elements per 16-byte chunk
+  const int cpt = (a.hd + KPL - 1) / KPL;                // chunks per token and operand (hd is a multiple of KPL)
+  const float* btab = tab + (size_t)(((gy == nwh - 1) ? 2 : 0) + ((gx == nww - 1) ? 1 : 0)) * ntp * ntp;
+  for (int e = threadIdx.x; e < ntp * cpt; e += 256) {    // 16-byte loads; rows nt..ntp-1 are zero padding
+    const int t = e / cpt, d = (e % cpt) * KPL;
+    float fq[KPL], fk[KPL], fv[KPL];
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) { fq[u] = 0.f; fk[u] = 0.f; fv[u] = 0.f; }
+    if (t < nt) {
+      const T* base = qkv + wa_token_off(a, b, gy, gx, t) * (3 * C) + h * a.hd + d;
+      Chunk<T>::unpack(ld16(base), fq);
+      Chunk<T>::unpack(ld16(base + C), fk);
+      Chunk<T>::unpack(ld16(base + 2 * C), fv);
+    }
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) { q[t * WA_SD + d + u] = fq[u]; k[t * WA_SD + d + u] = fk[u]; v[t * WA_SD + d + u] = fv[u]; }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < nt * nt; e += 256) {
-    const int i = e / nt, j = e % nt;
-    float acc = 0.f;
-    for (int d = 0; d < a.hd; ++d) acc = fmaf(q[i][d], k[j][d], acc);
-    s[i][j] = acc * a.scale + wa_mask_bias(a, gy, gx, nwh, nww, i, j, pos);
+  // S = q·kᵀ·scale + bias(+mask): 4x4 blocks
+  const int nb = ntp / 4;
+  for (int blk = threadIdx.x; blk < nb * nb; blk += 256) {
+    const int i0 = (blk / nb) * 4, j0 = (blk % nb) * 4;
+    float acc[4][4] = {};
+    for (int d = 0; d < hdp; d += 4) {
+      f32x4 qa[4], kb[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { qa[x] = ld4(&q[(i0 + x) * WA_SD + d]); kb[x] = ld4(&k[(j0 + x) * WA_SD + d]); }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          acc[x][y] += qa[x][0] * kb[y][0] + qa[x][1] * kb[y][1] + qa[x][2] * kb[y][2] + qa[x][3] * kb[y][3];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        s[(i0 + x) * WA_SS + j0 + y] = acc[x][y] * a.scale + btab[(i0 + x) * ntp + j0 + y];   // −inf outside w² x w²
+      }
   }
   __syncthreads();
-  // softmax: one wave handles rows wave, wave+4, ...
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < nt; i += 4) {
-    const float x = lane < nt ? s[i][lane] : -INFINITY;
+  for (int i = wave; i < ntp; i += 4) {
+    const float x = (lane < nt && i < nt) ? s[i * WA_SS + lane] : -INFINITY;
     const float m = wave_max(x);
-    const float ex = lane < nt ? __expf(x - m) : 0.f;
+    const float ex = (lane < nt && i < nt) ? __expf(x - m) : 0.f;
     const float sum = wave_sum(ex);
-    if (lane < nt) s[i][lane] = ex / sum;
+    if (lane < ntp) s[i * WA_SS + lane] = (i < nt && lane < nt) ? ex / sum : 0.f;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < nt * a.hd; e += 256) {
-    const int i = e / a.hd, d = e % a.hd;
-    float acc = 0.f;
-    for (int j = 0; j < nt; ++j) acc = fmaf(s[i][j], v[j][d], acc);
-    out[wa_token_off(a, b, gy, gx, i) * C + h * a.hd + d] = from_f32<T>(acc);
+  // O = P·V: 4 (tokens) x 4 (d) blocks
+  const int ndb = hdp / 4;
+  for (int blk = threadIdx.x; blk < nb * ndb; blk += 256) {
+    const int i0 = (blk / ndb) * 4, d0 = (blk % ndb) * 4;
+    f32x4 acc[4] = {};
+    for (int j = 0; j < ntp; j += 4) {
+      f32x4 pr[4], vv[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { pr[x] = ld4(&s[(i0 + x) * WA_SS + j]); vv[x] = ld4(&v[(j + x) * WA_SD + d0]); }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x] += pr[x][y] * vv[y];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int i = i0 + x;
+      if (i < nt) {
+        T* o = out + wa_token_off(a, b, gy, gx, i) * C + h * a.hd + d0;
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          if (d0 + y < a.hd) o[y] = from_f32<T>(acc[x][y]);
+      }
+    }
   }
 }
 
 // backward: recomputes the probabilities; writes dqkv and this workgroup's partial of the position-table gradient
 // (dpos_part [nblocks][(2w−1)²], summed afterwards by pfr_colsum → deterministic).
 template <typename T>
-__global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ pos,
+__global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ tab,
                                                               const T* __restrict__ dout, T* __restrict__ dqkv,
                                                               float* __restrict__ dpos_part, WinAttn a) {
-  __shared__ float q[WA_MAXT][WA_MAXD + 1], k[WA_MAXT][WA_MAXD + 1], v[WA_MAXT][WA_MAXD + 1], go[WA_MAXT][WA_MAXD + 1];
-  __shared__ float s[WA_MAXT][WA_MAXT + 1], ds[WA_MAXT][WA_MAXT + 1];
+  __shared__ __attribute__((aligned(16))) float q[WA_MAXT * WA_SD], k[WA_MAXT * WA_SD], v[WA_MAXT * WA_SD], go[WA_MAXT * WA_SD];
+  __shared__ __attribute__((aligned(16))) float s[WA_MAXT * WA_SS], ds[WA_MAXT * WA_SS];  // P, dS
   __shared__ float dtab[256];
   const int nwh = a.H / a.w, nww = a.W / a.w, nt = a.w * a.w, C = a.heads * a.hd;
   const int ntab = (2 * a.w - 1) * (2 * a.w - 1);
@@ -312,40 +385,74 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
   const int gx = bid % nww; bid /= nww;
   const int gy = bid % nwh;
   const int b = bid / nwh;
+  const int ntp = (nt + 3) & ~3, hdp = (a.hd + 3) & ~3;
   for (int e = threadIdx.x; e < ntab; e += 256) dtab[e] = 0.f;
-  for (int e = threadIdx.x; e < nt * a.hd; e += 256) {
-    const int t = e / a.hd, d = e % a.hd;
-    const size_t tok = wa_token_off(a, b, gy, gx, t);
-    const T* base = qkv + tok * (3 * C) + h * a.hd + d;
-    q[t][d] = to_f32(base[0]);
-    k[t][d] = to_f32(base[C]);
-    v[t][d] = to_f32(base[2 * C]);
-    go[t][d] = to_f32(dout[tok * C + h * a.hd + d]);
+  constexpr int KPL = DT<T>::KPACK;
+  const int cpt = (a.hd + KPL - 1) / KPL;
+  const float* btab = tab + (size_t)(((gy == nwh - 1) ? 2 : 0) + ((gx == nww - 1) ? 1 : 0)) * ntp * ntp;
+  for (int e = threadIdx.x; e < ntp * cpt; e += 256) {
+    const int t = e / cpt, d = (e % cpt) * KPL;
+    float fq[KPL], fk[KPL], fv[KPL], fg[KPL];
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) { fq[u] = 0.f; fk[u] = 0.f; fv[u] = 0.f; fg[u] = 0.f; }
+    if (t < nt) {
+      const size_t tok = wa_token_off(a, b, gy, gx, t);
+      const T* base = qkv + tok * (3 * C) + h * a.hd + d;
+      Chunk<T>::unpack(ld16(base), fq);
+      Chunk<T>::unpack(ld16(base + C), fk);
+      Chunk<T>::unpack(ld16(base + 2 * C), fv);
+      Chunk<T>::unpack(ld16(dout + tok * C + h * a.hd + d), fg);
+    }
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+      q[t * WA_SD + d + u] = fq[u]; k[t * WA_SD + d + u] = fk[u]; v[t * WA_SD + d + u] = fv[u]; go[t * WA_SD + d + u] = fg[u];
+    }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < nt * nt; e += 256) {
-    const int i = e / nt, j = e % nt;
-    float acc = 0.f, dp = 0.f;
-    for (int d = 0; d < a.hd; ++d) {
-      acc = fmaf(q[i][d], k[j][d], acc);
-      dp = fmaf(go[i][d], v[j][d], dp);   // dP = dO·Vᵀ
+  const int nb = ntp / 4;
+  for (int blk = threadIdx.x; blk < nb * nb; blk += 256) {
+    const int i0 = (blk / nb) * 4, j0 = (blk % nb) * 4;
+    float acc[4][4] = {}, dpa[4][4] = {};
+    for (int d = 0; d < hdp; d += 4) {
+      f32x4 qa[4], kb[4], ga[4], vb[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        qa[x] = ld4(&q[(i0 + x) * WA_SD + d]); kb[x] = ld4(&k[(j0 + x) * WA_SD + d]);
+        ga[x] = ld4(&go[(i0 + x) * WA_SD + d]); vb[x] = ld4(&v[(j0 + x) * WA_SD + d]);
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          acc[x][y] += qa[x][0] * kb[y][0] + qa[x][1] * kb[y][1] + qa[x][2] * kb[y][2] + qa[x][3] * kb[y][3];
+          dpa[x][y] += ga[x][0] * vb[y][0] + ga[x][1] * vb[y][1] + ga[x][2] * vb[y][2] + ga[x][3] * vb[y][3];   // dP = dO·Vᵀ
+        }
     }
-    s[i][j] = acc * a.scale + wa_mask_bias(a, gy, gx, nwh, nww, i, j, pos);
-    ds[i][j] = dp;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const int i = i0 + x, j = j0 + y;
+        const bool ok = i < nt && j < nt;
+        s[i * WA_SS + j] = acc[x][y] * a.scale + btab[i * ntp + j];
+        ds[i * WA_SS + j] = ok ? dpa[x][y] : 0.f;
+      }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < nt; i += 4) {
-    const float x = lane < nt ? s[i][lane] : -INFINITY;
+  for (int i = wave; i < ntp; i += 4) {
+    const bool okr = i < nt;
+    const float x = (lane < nt && okr) ? s[i * WA_SS + lane] : -INFINITY;
     const float m = wave_max(x);
-    const float ex = lane < nt ? __expf(x - m) : 0.f;
+    const float ex = (lane < nt && okr) ? __expf(x - m) : 0.f;
     const float sum = wave_sum(ex);
-    const float p = ex / sum;
-    const float dp = lane < nt ? ds[i][lane] : 0.f;
+    const float p = okr ? ex / sum : 0.f;
+    const float dp = (lane < nt && okr) ? ds[i * WA_SS + lane] : 0.f;
     const float dot = wave_sum(p * dp);
-    if (lane < nt) {
-      s[i][lane] = p;
-      ds[i][lane] = p * (dp - dot);       // dS = P ∘ (dP − rowsum(dP ∘ P))
+    if (lane < ntp) {
+      const float dsv = p * (dp - dot);     // dS = P ∘ (dP − rowsum(dP ∘ P))
+      s[i * WA_SS + lane] = p;
+      ds[i * WA_SS + lane] = dsv;
     }
   }
   __syncthreads();
@@ -354,21 +461,50 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
     const int i = e / nt, j = e % nt;
     const int w = a.w;
     const int idx = ((j / w) - (i / w) + w - 1) * (2 * w - 1) + ((j % w) - (i % w) + w - 1);
-    atomicAdd(&dtab[idx], ds[i][j]);
+    atomicAdd(&dtab[idx], ds[i * WA_SS + j]);
   }
-  // dV = Pᵀ·dO ; dQ = dS·K·scale ; dK = dSᵀ·Q·scale
-  for (int e = threadIdx.x; e < nt * a.hd; e += 256) {
-    const int t = e / a.hd, d = e % a.hd;
-    float dv = 0.f, dq = 0.f, dk = 0.f;
-    for (int j = 0; j < nt; ++j) {
-      dv = fmaf(s[j][t], go[j][d], dv);
-      dq = fmaf(ds[t][j], k[j][d], dq);
-      dk = fmaf(ds[j][t], q[j][d], dk);
+  // dV = Pᵀ·dO ; dQ = dS·K·scale ; dK = dSᵀ·Q·scale : 4 (tokens) x 4 (d) blocks, reduction over the other token index
+  const int ndb = hdp / 4;
+  for (int blk = threadIdx.x; blk < nb * ndb; blk += 256) {
+    const int t0 = (blk / ndb) * 4, d0 = (blk % ndb) * 4;
+    f32x4 dv[4] = {}, dq[4] = {}, dk[4] = {};
+    for (int j = 0; j < ntp; j += 4) {
+      f32x4 gj[4], kj[4], qj[4];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        gj[y] = ld4(&go[(j + y) * WA_SD + d0]); kj[y] = ld4(&k[(j + y) * WA_SD + d0]); qj[y] = ld4(&q[(j + y) * WA_SD + d0]);
+      }
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const f32x4 pT = ld4(&s[(j + y) * WA_SS + t0]);     // P[j+y][t0..t0+3]
+        const f32x4 dT = ld4(&ds[(j + y) * WA_SS + t0]);    // dS[j+y][t0..t0+3]
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          dv[x] += pT[x] * gj[y];
+          dk[x] += dT[x] * qj[y];
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const f32x4 drow = ld4(&ds[(t0 + x) * WA_SS + j]);  // dS[t0+x][j..j+3]
+#pragma unroll
+        for (int y = 0; y < 4; ++y) dq[x] += drow[y] * kj[y];
+      }
     }
-    T* base = dqkv + wa_token_off(a, b, gy, gx, t) * (3 * C) + h * a.hd + d;
-    base[0] = from_f32<T>(dq * a.scale);
-    base[C] = from_f32<T>(dk * a.scale);
-    base[2 * C] = from_f32<T>(dv);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int t = t0 + x;
+      if (t < nt) {
+        T* base = dqkv + wa_token_off(a, b, gy, gx, t) * (3 * C) + h * a.hd + d0;
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          if (d0 + y < a.hd) {
+            base[y] = from_f32<T>(dq[x][y] * a.scale);
+            base[C + y] = from_f32<T>(dk[x][y] * a.scale);
+            base[2 * C + y] = from_f32<T>(dv[x][y]);
+          }
+      }
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < ntab; e += 256) dpos_part[(size_t)blockIdx.x * ntab + e] = dtab[e];
@@ -380,9 +516,23 @@ static int wa_check(int B, int H, int W, int heads, int hd, int w, int shift) {
   return PFR_OK;
 }
 
+extern "C" long pfr_window_bias_table_floats(int window) {
+  const int ntp = (window * window + 3) & ~3;
+  return 4L * ntp * ntp;
+}
+// tab: fp32 [4][ceil4(w²)][ceil4(w²)], recomputed whenever pos changes (once per block and step)
+extern "C" int pfr_window_bias_table(const float* pos, float* tab, int window, int shift, hipStream_t st) {
+  PFR_CHECK_ARG(pos && tab && window * window <= WA_MAXT, "pfr_window_bias_table: bad args");
+  const long n = pfr_window_bias_table_floats(window);
+  hipLaunchKernelGGL(window_bias_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pos, tab, window, shift);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 extern "C" int pfr_window_attn_fwd(const void* qkv, const float* pos, void* out, int dtype, int B, int H, int W, int heads,
                                    int head_dim, int window, int shift, float scale, hipStream_t st) {
   PFR_CHECK_ARG(qkv && pos && out, "pfr_window_attn_fwd: null pointer");
+  PFR_CHECK_ARG(head_dim % (dtype == PFR_BF16 ? 8 : 4) == 0, "pfr_window_attn_fwd: head_dim must be a multiple of the 16-byte chunk");
   if (int rc = wa_check(B, H, W, heads, head_dim, window, shift)) return rc;
   WinAttn a{B, H, W, heads, head_dim, window, shift, scale};
   const dim3 grid((unsigned)(B * (H / window) * (W / window) * heads));
@@ -397,6 +547,7 @@ extern "C" int pfr_window_attn_bwd(const void* qkv, const float* pos, const void
                                    int B, int H, int W, int heads, int head_dim, int window, int shift, float scale,
                                    hipStream_t st) {
   PFR_CHECK_ARG(qkv && pos && dout && dqkv && dpos_part, "pfr_window_attn_bwd: null pointer");
+  PFR_CHECK_ARG(head_dim % (dtype == PFR_BF16 ? 8 : 4) == 0, "pfr_window_attn_bwd: head_dim must be a multiple of the 16-byte chunk");
   if (int rc = wa_check(B, H, W, heads, head_dim, window, shift)) return rc;
   WinAttn a{B, H, W, heads, head_dim, window, shift, scale};
   const dim3 grid((unsigned)(B * (H / window) * (W / window) * heads));

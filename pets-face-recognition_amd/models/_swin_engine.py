@@ -129,6 +129,7 @@ class SwinEngine:
                     b["pos"] = self.master[po:po + ntab]
                     b["dpos"] = self.grad[po:po + ntab]
                     b["hd"] = att.to_qkv.out_features // (3 * att.heads)
+                    b["tab"] = torch.empty(lib.pfr_window_bias_table_floats(att.window_size), dtype=torch.float32, device=dev)
                     rec["blocks"].append(b)
             self.stages.append(rec)
             cin = pm.linear.out_features
@@ -225,7 +226,8 @@ class SwinEngine:
                 qkv = A((rows, 3 * C))
                 gemm(fwd, ln1, rows, C, b["qkv"], qkv)
                 att = A((rows, C))
-                fwd.append((lib.pfr_window_attn_fwd, (qkv.data_ptr(), b["pos"].data_ptr(), att.data_ptr(), did, N, OH, OW,
+                fwd.append((lib.pfr_window_bias_table, (b["pos"].data_ptr(), b["tab"].data_ptr(), b["w"], b["shift"])))
+                fwd.append((lib.pfr_window_attn_fwd, (qkv.data_ptr(), b["tab"].data_ptr(), att.data_ptr(), did, N, OH, OW,
                                                       b["heads"], b["hd"], b["w"], b["shift"], float(b["scale"]))))
                 y = A((rows, C))
                 gemm(fwd, att, rows, C, b["out"], y, residual=x)
@@ -319,7 +321,7 @@ class SwinEngine:
                 nblk = N * (OH // b["w"]) * (OW // b["w"]) * b["heads"]
                 ntab = (2 * b["w"] - 1) ** 2
                 dpart = G((nblk, ntab), torch.float32)
-                bwd.append((lib.pfr_window_attn_bwd, (sv["qkv"].data_ptr(), b["pos"].data_ptr(), datt.data_ptr(), dqkv.data_ptr(),
+                bwd.append((lib.pfr_window_attn_bwd, (sv["qkv"].data_ptr(), b["tab"].data_ptr(), datt.data_ptr(), dqkv.data_ptr(),
                                                       dpart.data_ptr(), did, N, OH, OW, b["heads"], b["hd"], b["w"], b["shift"],
                                                       float(b["scale"]))))
                 colsum(bwd, dpart, nblk, ntab, b["dpos"], 0)

@@ -56,6 +56,9 @@ def test_window_attention_kernel(dtype, shift):
     qd = qkv.detach().to(DEV, dtype).contiguous()
     pos = att.pos_embedding.detach().to(DEV).contiguous()
     od = torch.empty(B, H, W, C, dtype=dtype, device=DEV)
+    tab = torch.empty(lib.pfr_window_bias_table_floats(w), dtype=torch.float32, device=DEV)
+    lib.pfr_window_bias_table(pos.data_ptr(), tab.data_ptr(), w, shift, st)
+    pos = tab
     lib.pfr_window_attn_fwd(qd.data_ptr(), pos.data_ptr(), od.data_ptr(), dtype_id(dtype), B, H, W, heads, hd, w, shift,
                             float(att.scale), st)
     dq = torch.empty_like(qd)
