@@ -812,6 +812,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     out[c] = accumulate ? out[c] + a : a;
   }
 }
+// final merge of fp32 partials [n][C]: block = 16 columns x 16 row lanes, four independent accumulators per thread (the
+// single-pass kernel above walks n/4 dependent loads per thread, which is latency-bound for n in the hundreds)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int C,
+                                                           int accumulate) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  __shared__ float l[16][17];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    int r = rl;
+    for (; r + 48 < n; r += 64) {
+      a0 += part[(size_t)r * C + c];
+      a1 += part[(size_t)(r + 16) * C + c];
+      a2 += part[(size_t)(r + 32) * C + c];
+      a3 += part[(size_t)(r + 48) * C + c];
+    }
+    for (; r < n; r += 16) a0 += part[(size_t)r * C + c];
+  }
+  l[rl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += l[r][cl];
+    out[c] = accumulate ? out[c] + a : a;
+  }
+}
 // partial column sums of row block blockIdx.y: grid (ceil(C/64), nblk) → part [nblk][C]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, float* __restrict__ part, long rows, int C,
@@ -835,21 +862,71 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
   if (rl == 0 && c < C) part[(size_t)blockIdx.y * C + c] = l[0][threadIdx.x] + l[1][threadIdx.x] + l[2][threadIdx.x] + l[3][threadIdx.x];
 }
 
+// 16-byte-chunk variant (C % KPACK == 0): thread = (channel chunk, row lane), grid-stride rows → part [gridDim.x][C]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_chunk_kernel(const T* __restrict__ x, float* __restrict__ part, size_t rows, int C,
+                                                           int cw, int rl, int cpr) {
+  constexpr int KP = DT<T>::KPACK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
+  const int cglob = blockIdx.y * cw + col;
+  float v[2][KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) { v[0][e] = 0.f; v[1][e] = 0.f; }
+  if (cglob < cpr) {
+    const size_t step = (size_t)gridDim.x * rl;
+    size_t r = (size_t)blockIdx.x * rl + rlane;
+    for (; r + step < rows; r += 2 * step) {   // two independent loads in flight
+      float a[KP], b[KP];
+      Chunk<T>::unpack(ld16(x + r * C + cglob * KP), a);
+      Chunk<T>::unpack(ld16(x + (r + step) * C + cglob * KP), b);
+#pragma unroll
+      for (int e = 0; e < KP; ++e) { v[0][e] += a[e]; v[1][e] += b[e]; }
+    }
+    if (r < rows) {
+      float a[KP];
+      Chunk<T>::unpack(ld16(x + r * C + cglob * KP), a);
+#pragma unroll
+      for (int e = 0; e < KP; ++e) v[0][e] += a[e];
+    }
+  }
+  float w[1][KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) w[0][e] = v[0][e] + v[1][e];
+  col_block_reduce<1, KP>(w, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * C, C);
+}
+
 static long colsum_blocks(long rows, int C) {
-  if (rows <= 2048) return 0;  // single-kernel path
+  if (rows <= 256) return 0;  // single-kernel path
   long want = 2048 / ((C + 63) / 64);
   if (want < 8) want = 8;
   const long maxb = (rows + 255) / 256;
   return want < maxb ? want : maxb;
 }
-extern "C" long pfr_colsum_ws_floats(long rows, int C) { return colsum_blocks(rows, C) * C; }
+extern "C" long pfr_colsum_ws_floats(long rows, int C) {
+  const long a = colsum_blocks(rows, C);
+  return (a > 512 ? a : (a ? 512 : 0)) * C;   // chunked path: at most 512 row blocks
+}
 
 extern "C" int pfr_colsum(const void* x, int dtype, long rows, int C, float* out, int accumulate, float* workspace,
                           hipStream_t st) {
   PFR_CHECK_ARG(x && out, "pfr_colsum: null pointer");
-  const long nblk = colsum_blocks(rows, C);
+  const long nblk = (workspace || rows > 2048) ? colsum_blocks(rows, C) : 0;   // ≤ 2048 rows may run without workspace
   if (nblk > 0) {
     PFR_CHECK_ARG(workspace, "pfr_colsum: workspace of pfr_colsum_ws_floats(rows, C) floats required for %ld rows", rows);
+    const int kp = dtype == PFR_BF16 ? 8 : 4;
+    if (C % kp == 0) {
+      ColGeom g = col_geom(C, kp, (size_t)rows, 512);
+      const size_t shb = (size_t)256 * kp * sizeof(float);
+      if (dtype == PFR_BF16)
+        hipLaunchKernelGGL(colsum_chunk_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), shb, st, (const bf16_t*)x, workspace, (size_t)rows, C, g.cw, g.rl, g.cpr);
+      else
+        hipLaunchKernelGGL(colsum_chunk_kernel<float>, dim3(g.gx, g.gy), dim3(256), shb, st, (const float*)x, workspace, (size_t)rows, C, g.cw, g.rl, g.cpr);
+      PFR_CHECK_LAUNCH();
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)workspace, out, g.gx, C, accumulate);
+      PFR_CHECK_LAUNCH();
+      return PFR_OK;
+    }
     const long rpb = (rows + nblk - 1) / nblk;
     const dim3 grid((C + 63) / 64, (unsigned)nblk);
     if (dtype == PFR_BF16)
@@ -857,7 +934,7 @@ extern "C" int pfr_colsum(const void* x, int dtype, long rows, int C, float* out
     else
       hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(256), 0, st, (const float*)x, workspace, rows, C, rpb);
     PFR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)workspace, out, (int)nblk, C, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)workspace, out, (int)nblk, C, accumulate);
     PFR_CHECK_LAUNCH();
     return PFR_OK;
   }

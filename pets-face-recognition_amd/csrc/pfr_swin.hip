@@ -231,20 +231,6 @@ struct WinAttn {
   float scale;
 };
 
-__device__ __forceinline__ float wa_mask_bias(const WinAttn& a, int gy, int gx, int nwh, int nww, int i, int j,
-                                              const float* __restrict__ pos) {
-  const int w = a.w;
-  const int yi = i / w, xi = i % w, yj = j / w, xj = j % w;
-  float b = pos[(yj - yi + w - 1) * (2 * w - 1) + (xj - xi + w - 1)];
-  if (a.shift) {
-    // last row of windows: tokens from the upper (w-d rows) and lower (d rows) part must not see each other
-    if (gy == nwh - 1 && ((yi >= w - a.shift) != (yj >= w - a.shift))) b = -INFINITY;
-    // last column of windows: left / right parts
-    if (gx == nww - 1 && ((xi >= w - a.shift) != (xj >= w - a.shift))) b = -INFINITY;
-  }
-  return b;
-}
-
 // bias(+mask) table of one attention block: tab[variant][i][j], variant = 2*(last window row) + (last window column),
 // rows padded to ntp = ceil4(w²) with −inf outside the w² x w² block (one tiny launch per block and step instead of integer
 // divisions per score element in every workgroup).
