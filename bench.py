@@ -160,6 +160,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time to ENQUEUE a step (GPU-bound if << ms_per_step)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -230,7 +231,7 @@ def main():
 
     if rank == 0:
         line = {"metric": f"FE train images/sec @224^2 bs={args.batch}/GPU", "value": round(value, 1), "unit": "images/sec",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_ms, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"{args.arch} FE + ArcFace(s=64,m=0.5) + CE, {args.classes} ids, 224x224x3, "
                                        f"fwd+bwd+SGD(momentum 0.9, param groups of the reference recipe)",

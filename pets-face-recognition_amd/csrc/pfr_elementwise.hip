@@ -369,11 +369,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, c
     A2[e] = a2 ? a2[cglob * KP + e] : 1.f;
     B2[e] = a2 ? b2[cglob * KP + e] : 0.f;
   }
-  for (size_t r = (size_t)blockIdx.x * rl + rlane; r < rows; r += (size_t)gridDim.x * rl) {
-    const size_t off = r * C + cglob * KP;
+  auto body = [&](u32x4 v1, u32x4 v2, size_t off) {
     float f[KP], g[KP];
-    Chunk<T>::unpack(ld16(x1 + off), f);
-    if (x2) Chunk<T>::unpack(ld16(x2 + off), g);
+    Chunk<T>::unpack(v1, f);
+    if (x2) Chunk<T>::unpack(v2, g);
 #pragma unroll
     for (int e = 0; e < KP; ++e) {
       float z = fmaf(f[e], A1[e], B1[e]);
@@ -381,6 +380,26 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, c
       f[e] = relu ? fmaxf(z, 0.f) : z;
     }
     st16(y + off, Chunk<T>::pack(f));
+  };
+  // four rows per thread in flight: at ~2 µs HBM latency the load queue, not the bandwidth, limits a 1-deep loop
+  const size_t step = (size_t)gridDim.x * rl;
+  size_t r = (size_t)blockIdx.x * rl + rlane;
+  for (; r + 3 * step < rows; r += 4 * step) {
+    u32x4 v1[4], v2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t off = (r + u * step) * C + cglob * KP;
+      v1[u] = ld16(x1 + off);
+      if (x2) v2[u] = ld16(x2 + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(v1[u], v2[u], (r + u * step) * C + cglob * KP);
+  }
+  for (; r < rows; r += step) {
+    const size_t off = r * C + cglob * KP;
+    u32x4 v2 = {};
+    if (x2) v2 = ld16(x2 + off);
+    body(ld16(x1 + off), v2, off);
   }
 }
 
@@ -423,12 +442,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       sc[e] = mask_mode == 2 ? scale[cglob * KP + e] : 0.f;
       sh[e] = mask_mode == 2 ? shift[cglob * KP + e] : 0.f;
     }
-    for (size_t r = (size_t)blockIdx.x * rl + rlane; r < rows; r += (size_t)gridDim.x * rl) {
-      const size_t off = r * C + cglob * KP;
+    auto body = [&](u32x4 vg, u32x4 vx, u32x4 vo) {
       float g[KP], xv[KP], o[KP];
-      Chunk<T>::unpack(ld16(dout + off), g);
-      Chunk<T>::unpack(ld16(x + off), xv);
-      if (mask_mode == 1) Chunk<T>::unpack(ld16(out + off), o);
+      Chunk<T>::unpack(vg, g);
+      Chunk<T>::unpack(vx, xv);
+      if (mask_mode == 1) Chunk<T>::unpack(vo, o);
 #pragma unroll
       for (int e = 0; e < KP; ++e) {
         float gg = g[e];
@@ -437,6 +455,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         v[0][e] += gg;
         v[1][e] = fmaf(gg, (xv[e] - mu[e]) * is[e], v[1][e]);
       }
+    };
+    const size_t step = (size_t)gridDim.x * rl;
+    size_t r = (size_t)blockIdx.x * rl + rlane;
+    for (; r + 3 * step < rows; r += 4 * step) {   // four rows per thread in flight
+      u32x4 vg[4], vx[4], vo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t off = (r + u * step) * C + cglob * KP;
+        vg[u] = ld16(dout + off);
+        vx[u] = ld16(x + off);
+        if (mask_mode == 1) vo[u] = ld16(out + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u]);
+    }
+    for (; r < rows; r += step) {
+      const size_t off = r * C + cglob * KP;
+      u32x4 vo = {};
+      if (mask_mode == 1) vo = ld16(out + off);
+      body(ld16(dout + off), ld16(x + off), vo);
     }
   }
   col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
@@ -526,12 +564,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     sc[e] = mask_mode == 2 ? scale[c] : 0.f;
     sh[e] = mask_mode == 2 ? shift[c] : 0.f;
   }
-  for (size_t r = (size_t)blockIdx.x * rl + rlane; r < rows; r += (size_t)gridDim.x * rl) {
-    const size_t off = r * C + cglob * KP;
+  auto body = [&](u32x4 vg, u32x4 vx, u32x4 vo, size_t off) {
     float g[KP], xv[KP], o[KP];
-    Chunk<T>::unpack(ld16(dout + off), g);
-    Chunk<T>::unpack(ld16(x + off), xv);
-    if (mask_mode == 1) Chunk<T>::unpack(ld16(out + off), o);
+    Chunk<T>::unpack(vg, g);
+    Chunk<T>::unpack(vx, xv);
+    if (mask_mode == 1) Chunk<T>::unpack(vo, o);
 #pragma unroll
     for (int e = 0; e < KP; ++e) {
       float gg = g[e];
@@ -542,6 +579,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     st16(dx + off, Chunk<T>::pack(xv));
     if (gres) st16(gres + off, Chunk<T>::pack(g));
+  };
+  const size_t step = (size_t)gridDim.x * rl;
+  size_t r = (size_t)blockIdx.x * rl + rlane;
+  for (; r + 3 * step < rows; r += 4 * step) {   // four rows per thread in flight (dx may alias dout: loads precede stores)
+    u32x4 vg[4], vx[4], vo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t off = (r + u * step) * C + cglob * KP;
+      vg[u] = ld16(dout + off);
+      vx[u] = ld16(x + off);
+      if (mask_mode == 1) vo[u] = ld16(out + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u], (r + u * step) * C + cglob * KP);
+  }
+  for (; r < rows; r += step) {
+    const size_t off = r * C + cglob * KP;
+    u32x4 vo = {};
+    if (mask_mode == 1) vo = ld16(out + off);
+    body(ld16(dout + off), ld16(x + off), vo, off);
   }
 }
 

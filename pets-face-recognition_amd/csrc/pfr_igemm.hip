@@ -41,18 +41,34 @@ struct IgemmParams {
   // that only the taps that exist for that class are visited (a 3x3/s2 dgrad does 9/4 instead of 9 taps per output).
   int pclass, mclass, tpc;
   FastDiv div_chw, div_cw;
+#ifdef PFR_IGEMM_TRACE
+  long long* trace;   // [grid][8] wall-clock stamps of workgroup phases (profiling builds only)
+  int dbg;            // 1: gather every tile from rows 0.. (L2-hot operands)   2: skip the output stores
+#endif
 };
+#ifdef PFR_IGEMM_TRACE
+static long long* g_igemm_trace = nullptr;
+static int g_igemm_dbg = 0;
+extern "C" void pfr_debug_igemm_trace(void* buf) { g_igemm_trace = (long long*)buf; }
+extern "C" void pfr_debug_igemm_flags(int f) { g_igemm_dbg = f; }
+#define TSTAMP(i) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(i) do {} while (0)
+#endif
 
 // tile geometry knobs: chunks of 16 B per LDS row per k-step, and LDS ring depth
 #ifndef PFR_IGEMM_KCH
 #define PFR_IGEMM_KCH 8
+#endif
+#ifndef PFR_IGEMM_OCC4
+#define PFR_IGEMM_OCC4 4   // resident workgroups per CU requested for the 64-byte-row 4-wave tiles (caps VGPR+AGPR at 128)
 #endif
 #ifndef PFR_IGEMM_NST
 #define PFR_IGEMM_NST 2
 #endif
 
 template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_>
-__global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && sizeof(T) == 2) ? PFR_IGEMM_OCC4 : 1) void igemm_kernel(IgemmParams p) {
   constexpr int KP = DT<T>::KPACK;
   constexpr int KCH = KCH_;                    // 16-byte chunks per LDS row per k-step (4: 64-B rows, 8: 128-B rows)
   constexpr int ROWB = KCH * 16;
@@ -79,6 +95,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave / WQ, wq = wave % WQ;
+  TSTAMP(0);
 
   const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = t % p.tilesN, tm = t / p.tilesN;
@@ -114,7 +131,11 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   int ihb[QCH], iwb[QCH], pixb[QCH];
 #pragma unroll
   for (int j = 0; j < QCH; ++j) {
+#ifdef PFR_IGEMM_TRACE
+    const int m = ((p.dbg & 1) ? 0 : m0) + (j * NW + wave) * RPI + rsub;
+#else
     const int m = m0 + (j * NW + wave) * RPI + rsub;
+#endif
     uint32_t n_img, oh, ow;
     if (decode(m, n_img, oh, ow)) {
       ihb[j] = (int)oh * p.ostride - p.pad;
@@ -297,6 +318,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   };
   const int nk = nk_all;
   const int npre = nk < NST - 1 ? nk : NST - 1;
+  TSTAMP(1);
   for (int s0 = 0; s0 < npre; ++s0) gload(s0);
   wait_pending(npre - 1);
   if constexpr (PRO) {
@@ -305,6 +327,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  TSTAMP(2);
   for (int kt = 0; kt < nk; ++kt) {
     const int slot = kt % NST;
     const char* base = smem + slot * STAGE;
@@ -329,6 +352,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
     __builtin_amdgcn_s_barrier();
   }
 
+  TSTAMP(3);
   // ---- epilogue phase 1: accumulators -> LDS tile [BQ rows m][BP couts] of TO
 #pragma unroll
   for (int i = 0; i < TP; ++i)
@@ -353,6 +377,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
       }
     }
   __syncthreads();
+  TSTAMP(4);
 
   // ---- epilogue phase 2: row-major 16-byte chunks: bias / accumulate / relu / BN partial sums / store
   constexpr int CPR = BP * (int)sizeof(TO) / 16;  // chunks per output row
@@ -426,6 +451,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
         s2[e] = fmaf(d, d, s2[e]);
       }
     }
+#ifdef PFR_IGEMM_TRACE
+    if (p.dbg & 2) continue;
+#endif
     if (vec_ok) {
       st16(dst, v);
     } else {
@@ -434,6 +462,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
         if (co + e < p.Cout) reinterpret_cast<TO*>(dst)[e] = from_f32<TO>(f[e]);
     }
   }
+  TSTAMP(5);
   if (p.stats_part) {
     // lanes with equal (lane % CPR) hold partials of the same channels
 #pragma unroll
@@ -451,7 +480,8 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
         red[(wave * 2 + 1) * BP + oc * KPO + e] = s2[e];
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS only: the output stores stay in flight
+    __builtin_amdgcn_s_barrier();
     if (tid < BP && n0 + tid < p.Cout) {
       const int ch = tid;
       float a = 0.f, b = 0.f;
@@ -466,6 +496,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(IgemmParams p) {
       p.stats_part[((size_t)tm * 2 + 1) * p.Cout + n0 + ch] = b - a * a / nt;      // tile M2 = Σ (x − mean_t)²
     }
   }
+  TSTAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -496,6 +527,9 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
 template <typename T, typename TO, int BQ, int BP>
 static int launch_tile(IgemmParams& p, hipStream_t st) {
   if (p.K >= 512 && p.C % (8 * DT<T>::KPACK) == 0) return launch_tile_k<T, TO, BQ, BP, 8, 4, 2>(p, st);
+  static const int nst4 = getenv("PFR_IGEMM_NST4") ? atoi(getenv("PFR_IGEMM_NST4")) : 2;
+  if (nst4 == 3) return launch_tile_k<T, TO, BQ, BP, 4, 4, 2, 3>(p, st);
+  if (nst4 == 4) return launch_tile_k<T, TO, BQ, BP, 4, 4, 2, 4>(p, st);
   return launch_tile_k<T, TO, BQ, BP, 4, 4, 2>(p, st);
 }
 
@@ -525,6 +559,10 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
   const int v = pick_tile(p.M, p.Cout, p.K, dtype, out_dtype, &bq);
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
     const char* big = getenv("PFR_IGEMM_BIGCFG");   // experiment switch: "k4n4" = 64-byte rows, 4-slot ring
+    if (big && big[0] == 'w') {   // 4-wave variants: 128x128 / 128x64 register tiles per wave
+      if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 8, 4, 2>(p, st);
+      if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 8, 4, 2>(p, st);
+    }
     if (big && big[0] == 'k') {
       if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 4, 8, 2, 4>(p, st);
       if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 4, 8, 2, 4>(p, st);
@@ -570,6 +608,10 @@ extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, 
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
+#ifdef PFR_IGEMM_TRACE
+  p.trace = g_igemm_trace;
+  p.dbg = g_igemm_dbg;
+#endif
   if (dtype == PFR_BF16) {
     if (out_dtype == PFR_BF16) return launch_igemm<bf16_t, bf16_t>(p, dtype, out_dtype, stream);
     return launch_igemm<bf16_t, float>(p, dtype, out_dtype, stream);

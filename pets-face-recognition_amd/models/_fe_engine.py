@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .._hip import lib, dtype_id, PfrError
+from .._hip.lib import _TRACER
 from .._hip.ops import conv_out_hw
 
 _ALIGN = 64  # elements; keeps every parameter 16-byte aligned in both fp32 and bf16 shadows
@@ -36,6 +37,10 @@ class _Conv:
 
 class _BN:
     pass
+
+
+# op codes of the backward list besides plain (ctypes function, args) launches on the main stream
+_SIDE, _FORK, _SREC, _WAIT = 1, 2, 3, 4
 
 
 class _Plan:
@@ -67,6 +72,11 @@ class FEEngine:
         self.model_id = id(model)
         self.fc_id = id(model.fc)
         self.plans = {}
+        self.side = None          # side stream of the weight-gradient launches (see build_plan)
+        self.side_events = []
+        self.wt_fork = self.wt_ready = None
+        self.wt_pending = False
+        self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
         # Fusing BN-apply+ReLU into the CONSUMER conv's operand prologue saves one write+read of the normalised
         # activation, but the transform is then repeated for every tap and every Cout tile (18x for a 3x3 256->256
         # conv): measured on MI355X it costs ~2x the kernel time, far more than the single elementwise pass it saves.
@@ -245,9 +255,24 @@ class FEEngine:
         lib.pfr_nchw_to_nhwc(self.master.data_ptr() + 4 * st.off, st.w_pad.data_ptr(), self.did, st.Cout * st.R * st.S,
                              st.Cin, 1, 1, self.cp, stream)
         if for_backward:
+            # the flipped / transposed copies are first needed by the backward pass: build them on the side stream,
+            # concurrent with the forward pass (backward() waits for wt_ready)
+            sptr = stream
+            use_side = self.side_stream_enabled and _TRACER[0] is None
+            if use_side:
+                if self.side is None:
+                    self.side = torch.cuda.Stream(device=self.device)
+                if self.wt_fork is None:
+                    self.wt_fork, self.wt_ready = torch.cuda.Event(), torch.cuda.Event()
+                self.wt_fork.record(torch.cuda.current_stream())
+                self.side.wait_event(self.wt_fork)
+                sptr = self.side.cuda_stream
             for c in self.all_convs:
                 if c.need_wt:
-                    lib.pfr_weight_dgrad_layout(c.w.data_ptr(), c.wt.data_ptr(), self.did, c.Cout, c.R, c.S, c.Cin, stream)
+                    lib.pfr_weight_dgrad_layout(c.w.data_ptr(), c.wt.data_ptr(), self.did, c.Cout, c.R, c.S, c.Cin, sptr)
+            self.wt_pending = use_side
+            if use_side:
+                self.wt_ready.record(self.side)
 
     # ------------------------------------------------------------------------------------------ plan building
     def _A(self, plan, shape, dtype=None):
@@ -370,13 +395,24 @@ class FEEngine:
             return plan
 
         # =================================================================== backward (appended after n_fwd)
+        # Weight gradients feed nothing downstream until the optimizer, so they run on a SIDE stream, concurrent with the
+        # dgrad -> BN-backward chain of the following layers (MFMA/LDS-bound wgrad next to HBM-bound streaming kernels).
+        # Symbolic ops: ("fork", k): side waits for main's current point; ("srec", k): side records "wgrad k done";
+        # ("wait", k): main waits for wgrad k (emitted before a pooled buffer it read is handed out again, before every
+        # grad-ready mark and at the end).  The pool is FIFO so that a re-used buffer is the one released longest ago.
         pool = {}
+        pending = {}   # data_ptr -> index of the last side-stream wgrad that reads this buffer
+        nside = [0]
 
         def G(shape, dtype=None):
             key = (tuple(shape), dtype or T)
             lst = pool.setdefault(key, [])
             if lst:
-                return lst.pop()
+                t = lst.pop(0)
+                k = pending.pop(t.data_ptr(), None)
+                if k is not None:
+                    ops.append(("wait", (k,)))
+                return t
             return self._A(plan, shape, dtype)
 
         def release(t):
@@ -395,8 +431,13 @@ class FEEngine:
             if pro is not None:
                 ps, psh, prelu = pro[0].data_ptr(), pro[1].data_ptr(), 1
             dst = out if out is not None else c.g
+            k = nside[0]
+            nside[0] += 1
+            ops.append(("fork", (k,)))
             ops.append(("wgrad_noacc" if out is not None else "wgrad", (x.data_ptr(), dy.data_ptr(), dst.data_ptr(), None, self.did, Nq, Hq, Wq, Cq, Co, c.R, c.S,
                                   c.stride, c.pad, OH, OW, Co, ps, psh, prelu, 1.0, acc)))
+            ops.append(("srec", (k,)))
+            pending[dy.data_ptr()] = k
 
         def dgrad(dy, dyshape, c, dx, dxshape, accumulate=0):
             log2 = {1: 0, 2: 1}[c.stride]
@@ -476,8 +517,10 @@ class FEEngine:
         release(dcur)
         bn_bwd(dz, None, c1, s1, stbn, 2, dz, None, acc)
         wgrad(x_nhwc, (N, H, W, self.cp), dz, s1, st, out=st.g_pad)
+        ops.append(("wait", (nside[0] - 1,)))   # the un-padding copy below reads what the stem wgrad wrote
         ops.append(("copy2d", (st.g_pad.data_ptr(), self.cp, st.g.data_ptr(), st.Cin, st.Cout * st.R * st.S, st.Cin, 1.0, acc)))
         self._mark(ops, 0)
+        plan.meta["n_side"] = nside[0]
         # workspace
         if self.ws is None or self.ws.numel() < ws_need[0]:
             self.ws = torch.empty(ws_need[0], dtype=torch.float32, device=self.device)
@@ -485,6 +528,10 @@ class FEEngine:
         return plan
 
     def _mark(self, ops, off):
+        # gradients of flat offsets >= off are final once main has also seen the side stream's latest wgrad
+        last = max((a[0] for f, a in ops if f == "srec"), default=None)
+        if last is not None:
+            ops.append(("wait", (last,)))
         ops.append((None, (off,)))
 
     # ------------------------------------------------------------------------------------------ execution
@@ -511,7 +558,13 @@ class FEEngine:
                     a = list(args)
                     a[3] = self.ws.data_ptr()
                     a[-1] = acc if fn == "wgrad" else 0
-                    res.append((lib.pfr_conv2d_wgrad, tuple(a)))
+                    res.append((_SIDE, (lib.pfr_conv2d_wgrad, tuple(a))))
+                elif fn == "fork":
+                    res.append((_FORK, args[0]))
+                elif fn == "srec":
+                    res.append((_SREC, args[0]))
+                elif fn == "wait":
+                    res.append((_WAIT, args[0]))
                 elif fn == "colsum":
                     res.append((lib.pfr_colsum, tuple(args[:-1]) + (acc, 0)))
                 elif fn == "copy2d":
@@ -550,10 +603,37 @@ class FEEngine:
         lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan.meta["demb"].data_ptr(), self.did, demb.numel(), stream)
         acc = 1 if self.first_param.grad is not None else 0
         hook = self.grad_ready_hook
+        main = torch.cuda.current_stream()
+        if self.wt_pending:
+            main.wait_event(self.wt_ready)
+            self.wt_pending = False
+        # side stream off: PFR_SIDE_STREAM=0, or a launch tracer is active (it brackets launches with events on ONE stream)
+        use_side = self.side_stream_enabled and _TRACER[0] is None
+        if use_side:
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=self.device)
+            side, sptr = self.side, self.side.cuda_stream
+            ev = self.side_events
+            while len(ev) < 2 * plan.meta.get("n_side", 0):
+                ev.append(torch.cuda.Event())
         for fn, args in plan.meta["bwd%d" % acc]:
             if fn is None:
                 if hook is not None:
                     hook(args[0])
+            elif fn.__class__ is int:
+                if not use_side:
+                    if fn == _SIDE:
+                        args[0](*args[1], stream)
+                elif fn == _SIDE:
+                    args[0](*args[1], sptr)
+                elif fn == _FORK:
+                    e = ev[2 * args]
+                    e.record(main)
+                    side.wait_event(e)
+                elif fn == _SREC:
+                    ev[2 * args + 1].record(side)
+                else:
+                    main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)
         if not acc:
