@@ -90,7 +90,12 @@ int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, const float*
 /* y = relu?( a1*x1 + b1 (+ a2*x2 + b2 | + x2) ): BN apply, ReLU and the residual add of a bottleneck in one pass */
 int pfr_bn_act(const void* x1, const float* a1, const float* b1, const void* x2, const float* a2, const float* b2, void* y,
                int dtype, long rows, int C, int relu, pfr_stream_t stream);
-/* backward: g = dout * mask (mask_mode 0 none, 1: out > 0, 2: scale*x+shift > 0);
+/* same, and (mask != NULL) also writes the sign of the pre-ReLU value as a bit mask: one byte per (row, 16-byte channel
+ * chunk) = [rows][C / (8 bf16 | 4 f32)], bit e = (value of channel chunk*KP + e) > 0; the backward pass of a block's last
+ * BN (relu(bn(x) + shortcut), torchvision Bottleneck.forward) reads this instead of the activation tensor */
+int pfr_bn_act_mask(const void* x1, const float* a1, const float* b1, const void* x2, const float* a2, const float* b2,
+                    void* y, unsigned char* mask, int dtype, long rows, int C, int relu, pfr_stream_t stream);
+/* backward: g = dout * mask (mask_mode 0 none, 1: out > 0, 2: scale*x+shift > 0, 3: `out` is the bit mask of pfr_bn_act_mask);
  * reduce → partials of (Σg, Σg·x̂); finalize → dgamma, dbeta, coef[3][C]; apply → dx = coef0*g + coef1*x + coef2, gres = g */
 int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* x, const float* mean, const float* invstd,
                       const float* scale, const float* shift, int mask_mode, int dtype, long rows, int C, float* part,

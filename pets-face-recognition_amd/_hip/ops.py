@@ -171,11 +171,18 @@ def bn_eval_coeff(gamma, beta, running_mean, running_var, eps, out=None):
     return out
 
 
-def bn_act(x1, a1, b1, x2=None, a2=None, b2=None, relu=True, out=None):
+def bn_act(x1, a1, b1, x2=None, a2=None, b2=None, relu=True, out=None, want_mask=False):
+    """-> out, or (out, mask) with the ReLU bit mask ([rows][C / KPACK] bytes) that bn_bwd(mask_mode=3) consumes."""
     C = x1.shape[-1]
     rows = x1.numel() // C
     if out is None:
         out = torch.empty_like(x1)
+    if want_mask:
+        kp = 8 if x1.dtype == torch.bfloat16 else 4
+        mask = torch.empty((rows, C // kp), dtype=torch.uint8, device=x1.device)
+        lib.pfr_bn_act_mask(_p(x1), _p(a1), _p(b1), _p(x2), _p(a2), _p(b2), _p(out), _p(mask), dtype_id(x1.dtype), rows, C,
+                            int(relu), _stream())
+        return out, mask
     lib.pfr_bn_act(_p(x1), _p(a1), _p(b1), _p(x2), _p(a2), _p(b2), _p(out), dtype_id(x1.dtype), rows, C, int(relu), _stream())
     return out
 

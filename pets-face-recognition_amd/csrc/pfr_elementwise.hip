@@ -356,7 +356,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, const float* __restrict__ a1,
                                                      const float* __restrict__ b1, const T* __restrict__ x2,
                                                      const float* __restrict__ a2, const float* __restrict__ b2,
-                                                     T* __restrict__ y, size_t rows, int C, int cw, int rl, int cpr, int relu) {
+                                                     T* __restrict__ y, unsigned char* __restrict__ mask, size_t rows, int C,
+                                                     int cw, int rl, int cpr, int relu) {
   constexpr int KP = DT<T>::KPACK;
   const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
   const int cglob = blockIdx.y * cw + col;
@@ -369,17 +370,21 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, c
     A2[e] = a2 ? a2[cglob * KP + e] : 1.f;
     B2[e] = a2 ? b2[cglob * KP + e] : 0.f;
   }
-  auto body = [&](u32x4 v1, u32x4 v2, size_t off) {
+  auto body = [&](u32x4 v1, u32x4 v2, size_t row) {
+    const size_t off = row * C + cglob * KP;
     float f[KP], g[KP];
     Chunk<T>::unpack(v1, f);
     if (x2) Chunk<T>::unpack(v2, g);
+    unsigned bits = 0;
 #pragma unroll
     for (int e = 0; e < KP; ++e) {
       float z = fmaf(f[e], A1[e], B1[e]);
       if (x2) z += fmaf(g[e], A2[e], B2[e]);
+      bits |= (z > 0.f ? 1u : 0u) << e;
       f[e] = relu ? fmaxf(z, 0.f) : z;
     }
     st16(y + off, Chunk<T>::pack(f));
+    if (mask) mask[row * cpr + cglob] = (unsigned char)bits;   // ReLU mask for the backward pass: 1 bit instead of 16
   };
   // four rows per thread in flight: at ~2 µs HBM latency the load queue, not the bandwidth, limits a 1-deep loop
   const size_t step = (size_t)gridDim.x * rl;
@@ -393,26 +398,34 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, c
       if (x2) v2[u] = ld16(x2 + off);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) body(v1[u], v2[u], (r + u * step) * C + cglob * KP);
+    for (int u = 0; u < 4; ++u) body(v1[u], v2[u], r + u * step);
   }
   for (; r < rows; r += step) {
     const size_t off = r * C + cglob * KP;
     u32x4 v2 = {};
     if (x2) v2 = ld16(x2 + off);
-    body(ld16(x1 + off), v2, off);
+    body(ld16(x1 + off), v2, r);
   }
 }
 
+extern "C" int pfr_bn_act_mask(const void* x1, const float* a1, const float* b1, const void* x2, const float* a2,
+                               const float* b2, void* y, unsigned char* mask, int dtype, long rows, int C, int relu,
+                               hipStream_t st);
 extern "C" int pfr_bn_act(const void* x1, const float* a1, const float* b1, const void* x2, const float* a2,
                           const float* b2, void* y, int dtype, long rows, int C, int relu, hipStream_t st) {
+  return pfr_bn_act_mask(x1, a1, b1, x2, a2, b2, y, nullptr, dtype, rows, C, relu, st);
+}
+extern "C" int pfr_bn_act_mask(const void* x1, const float* a1, const float* b1, const void* x2, const float* a2,
+                               const float* b2, void* y, unsigned char* mask, int dtype, long rows, int C, int relu,
+                               hipStream_t st) {
   PFR_CHECK_ARG(x1 && a1 && b1 && y, "pfr_bn_act: null pointer");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_act: C %% %d != 0", kp);
   ColGeom g = col_geom(C, kp, (size_t)rows, 512);   // pure streaming: many resident waves (no partial rows to merge)
   if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)x1, a1, b1, (const bf16_t*)x2, a2, b2, (bf16_t*)y, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
+    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)x1, a1, b1, (const bf16_t*)x2, a2, b2, (bf16_t*)y, mask, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
   else
-    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, (const float*)x1, a1, b1, (const float*)x2, a2, b2, (float*)y, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
+    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, (const float*)x1, a1, b1, (const float*)x2, a2, b2, (float*)y, mask, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
@@ -442,7 +455,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       sc[e] = mask_mode == 2 ? scale[cglob * KP + e] : 0.f;
       sh[e] = mask_mode == 2 ? shift[cglob * KP + e] : 0.f;
     }
-    auto body = [&](u32x4 vg, u32x4 vx, u32x4 vo) {
+    const unsigned char* mk = reinterpret_cast<const unsigned char*>(out);   // mask_mode 3: one byte per (row, chunk)
+    auto body = [&](u32x4 vg, u32x4 vx, u32x4 vo, unsigned bits) {
       float g[KP], xv[KP], o[KP];
       Chunk<T>::unpack(vg, g);
       Chunk<T>::unpack(vx, xv);
@@ -451,6 +465,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       for (int e = 0; e < KP; ++e) {
         float gg = g[e];
         if (mask_mode == 1) gg = o[e] > 0.f ? gg : 0.f;
+        if (mask_mode == 3) gg = (bits >> e) & 1u ? gg : 0.f;
         if (mask_mode == 2) gg = fmaf(xv[e], sc[e], sh[e]) > 0.f ? gg : 0.f;
         v[0][e] += gg;
         v[1][e] = fmaf(gg, (xv[e] - mu[e]) * is[e], v[1][e]);
@@ -460,21 +475,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     size_t r = (size_t)blockIdx.x * rl + rlane;
     for (; r + 3 * step < rows; r += 4 * step) {   // four rows per thread in flight
       u32x4 vg[4], vx[4], vo[4];
+      unsigned bits[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t off = (r + u * step) * C + cglob * KP;
         vg[u] = ld16(dout + off);
         vx[u] = ld16(x + off);
         if (mask_mode == 1) vo[u] = ld16(out + off);
+        if (mask_mode == 3) bits[u] = mk[(r + u * step) * cpr + cglob];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u]);
+      for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u], bits[u]);
     }
     for (; r < rows; r += step) {
       const size_t off = r * C + cglob * KP;
       u32x4 vo = {};
       if (mask_mode == 1) vo = ld16(out + off);
-      body(ld16(dout + off), ld16(x + off), vo);
+      body(ld16(dout + off), ld16(x + off), vo, mask_mode == 3 ? mk[r * cpr + cglob] : 0u);
     }
   }
   col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
@@ -484,7 +501,7 @@ extern "C" int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* 
                                  const float* invstd, const float* scale, const float* shift, int mask_mode, int dtype,
                                  long rows, int C, float* part, hipStream_t st) {
   PFR_CHECK_ARG(dout && x && mean && invstd && part, "pfr_bn_bwd_reduce: null pointer");
-  PFR_CHECK_ARG(mask_mode != 1 || out, "pfr_bn_bwd_reduce: mask_mode 1 needs out");
+  PFR_CHECK_ARG((mask_mode != 1 && mask_mode != 3) || out, "pfr_bn_bwd_reduce: mask_mode 1 / 3 needs out / the bit mask");
   PFR_CHECK_ARG(mask_mode != 2 || (scale && shift), "pfr_bn_bwd_reduce: mask_mode 2 needs scale/shift");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_reduce: C %% %d != 0", kp);
@@ -564,7 +581,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     sc[e] = mask_mode == 2 ? scale[c] : 0.f;
     sh[e] = mask_mode == 2 ? shift[c] : 0.f;
   }
-  auto body = [&](u32x4 vg, u32x4 vx, u32x4 vo, size_t off) {
+  const unsigned char* mk = reinterpret_cast<const unsigned char*>(out);
+  auto body = [&](u32x4 vg, u32x4 vx, u32x4 vo, unsigned bits, size_t off) {
     float g[KP], xv[KP], o[KP];
     Chunk<T>::unpack(vg, g);
     Chunk<T>::unpack(vx, xv);
@@ -573,6 +591,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (int e = 0; e < KP; ++e) {
       float gg = g[e];
       if (mask_mode == 1) gg = o[e] > 0.f ? gg : 0.f;
+      if (mask_mode == 3) gg = (bits >> e) & 1u ? gg : 0.f;
       if (mask_mode == 2) gg = fmaf(xv[e], sc[e], sh[e]) > 0.f ? gg : 0.f;
       g[e] = gg;
       xv[e] = fmaf(cg[e], gg, fmaf(cx[e], xv[e], c0[e]));
@@ -584,21 +603,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   size_t r = (size_t)blockIdx.x * rl + rlane;
   for (; r + 3 * step < rows; r += 4 * step) {   // four rows per thread in flight (dx may alias dout: loads precede stores)
     u32x4 vg[4], vx[4], vo[4];
+    unsigned bits[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t off = (r + u * step) * C + cglob * KP;
       vg[u] = ld16(dout + off);
       vx[u] = ld16(x + off);
       if (mask_mode == 1) vo[u] = ld16(out + off);
+      if (mask_mode == 3) bits[u] = mk[(r + u * step) * cpr + cglob];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u], (r + u * step) * C + cglob * KP);
+    for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u], bits[u], (r + u * step) * C + cglob * KP);
   }
   for (; r < rows; r += step) {
     const size_t off = r * C + cglob * KP;
     u32x4 vo = {};
     if (mask_mode == 1) vo = ld16(out + off);
-    body(ld16(dout + off), ld16(x + off), vo, off);
+    body(ld16(dout + off), ld16(x + off), vo, mask_mode == 3 ? mk[r * cpr + cglob] : 0u, off);
   }
 }
 

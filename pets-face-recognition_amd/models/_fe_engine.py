@@ -371,16 +371,19 @@ class FEEngine:
             out = self._A(plan, sshape)
             rows = sshape[0] * sshape[1] * sshape[2]
             cd = None
+            # sign of the pre-ReLU block output as a bit mask (1 bit instead of a 16-bit re-read, twice, in backward)
+            rmask = self._A(plan, (rows, sshape[3] // self.kp), torch.uint8) if with_backward else None
+            mptr = 0 if rmask is None else rmask.data_ptr()
             if down is not None:
                 dc, dbn = down
                 cd, _ = self._conv_bn(plan, ops, xin, xshape, dc, dbn, train)
-                ops.append((lib.pfr_bn_act, (src.data_ptr(), lastbn.coef[2].data_ptr(), lastbn.coef[3].data_ptr(),
-                                             cd.data_ptr(), dbn.coef[2].data_ptr(), dbn.coef[3].data_ptr(), out.data_ptr(),
-                                             self.did, rows, sshape[3], 1)))
+                ops.append((lib.pfr_bn_act_mask, (src.data_ptr(), lastbn.coef[2].data_ptr(), lastbn.coef[3].data_ptr(),
+                                                  cd.data_ptr(), dbn.coef[2].data_ptr(), dbn.coef[3].data_ptr(), out.data_ptr(),
+                                                  mptr, self.did, rows, sshape[3], 1)))
             else:
-                ops.append((lib.pfr_bn_act, (src.data_ptr(), lastbn.coef[2].data_ptr(), lastbn.coef[3].data_ptr(),
-                                             xin.data_ptr(), 0, 0, out.data_ptr(), self.did, rows, sshape[3], 1)))
-            bsaved.append((xin, xshape, raws, cd, out, sshape, acts))
+                ops.append((lib.pfr_bn_act_mask, (src.data_ptr(), lastbn.coef[2].data_ptr(), lastbn.coef[3].data_ptr(),
+                                                  xin.data_ptr(), 0, 0, out.data_ptr(), mptr, self.did, rows, sshape[3], 1)))
+            bsaved.append((xin, xshape, raws, cd, out if rmask is None else rmask, sshape, acts))
             cur, cshape = out, sshape
         # ---- global average pool + fc
         Nn, Hh, Ww, Cf = cshape
@@ -480,7 +483,7 @@ class FEEngine:
             ylast, _ = raws[-1]
             gres = G(oshape)
             # BN(last) + residual + ReLU backward; dx in place over dcur
-            bn_bwd(dcur, out, ylast, oshape, lastbn, 1, dcur, gres, acc)
+            bn_bwd(dcur, out, ylast, oshape, lastbn, 3, dcur, gres, acc)   # `out` here is the block's ReLU bit mask
             dy, dyshape = dcur, oshape
             for i in range(len(convs) - 1, 0, -1):
                 c, bn = convs[i]

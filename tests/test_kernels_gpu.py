@@ -195,6 +195,16 @@ def test_batchnorm_train_fwd_bwd(dtype, C):
     assert rel_err(gres.cpu(), nhwc(res.grad)) < (2e-2 if dtype == torch.bfloat16 else 1e-5)
     assert rel_err(dgam.cpu(), gam.grad) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
     assert rel_err(dbet.cpu(), bet.grad) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+    # the 1-bit ReLU mask written by the forward pass (mask_mode 3) gives bit-identical gradients to re-reading the output
+    yd2, mask = o.bn_act(xd, coef[2], coef[3], x2=resd, relu=True, want_mask=True)
+    dx3, gres3, dgam3, dbet3 = o.bn_bwd(nhwc(dy).to(DEV, dtype), xd, coef[0], coef[1], gamma.to(DEV), N * H * W, mask_mode=3,
+                                         out_act=mask, want_gres=True)
+    torch.cuda.synchronize()
+    assert torch.equal(yd2, yd)
+    if dtype == torch.float32:   # (a bf16 output can round a tiny positive pre-activation to +0: mask bit set, out > 0 false)
+        assert torch.equal(dx3, dx) and torch.equal(gres3, gres) and torch.equal(dgam3, dgam) and torch.equal(dbet3, dbet)
+    else:
+        assert rel_err(dx3.cpu(), dx.cpu()) < 1e-2 and rel_err(dgam3.cpu(), dgam.cpu()) < 1e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
