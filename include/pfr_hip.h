@@ -143,7 +143,7 @@ int pfr_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
                       const void* dres, void* dx, float* part, int dtype, long rows, int C, pfr_stream_t stream);
 int pfr_gelu_fwd(const void* x, void* y, int dtype, size_t n, pfr_stream_t stream);
 int pfr_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, size_t n, pfr_stream_t stream);
-/* bias(+mask) table of one attention block: tab fp32 [4][n][n], n = ceil4(w*w); variant 2*(last window row)+(last window
+/* bias(+mask) table of one attention block: tab fp32 [4][64][64] (-inf outside w*w x w*w); variant 2*(last window row)+(last window
  * column); built from the (2w-1)x(2w-1) relative-position table `pos`; rebuild whenever pos changed */
 long pfr_window_bias_table_floats(int window);
 int pfr_window_bias_table(const float* pos, float* tab, int window, int shift, pfr_stream_t stream);

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       for (int j = 0; j < PCH; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * NW + wave) * RPI * ROWB),
                                                  16, (int)(wbase[j] + (uint32_t)(tapbyte + cbyte)), 0, 0, 0);
+#ifdef PFR_IGEMM_TRACE
+      if (!(p.dbg & 4) || tapbyte == 0)
+#endif
 #pragma unroll
       for (int j = 0; j < QCH; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * NW + wave) * RPI) * ROWB),

@@ -12,6 +12,8 @@
 // The shift and the window partition are pure addressing here: token (wy,wx) of window (gy,gx) lives at image position
 // ((gy·w + wy + d) mod H, (gx·w + wx + d) mod W) with d = w/2 for shifted blocks — nothing is rolled or copied.
 #include "pfr_common.h"
+#include <stdlib.h>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // one wave per row
@@ -232,10 +234,11 @@ struct WinAttn {
 };
 
 // bias(+mask) table of one attention block: tab[variant][i][j], variant = 2*(last window row) + (last window column),
-// rows padded to ntp = ceil4(w²) with −inf outside the w² x w² block (one tiny launch per block and step instead of integer
+// rows padded to WA_MAXT = 64 with −inf outside the w² x w² block (one tiny launch per block and step instead of integer
 // divisions per score element in every workgroup).
 __global__ void window_bias_table_kernel(const float* __restrict__ pos, float* __restrict__ tab, int w, int shift) {
-  const int nt = w * w, ntp = (nt + 3) & ~3;
+  const int nt = w * w;
+  constexpr int ntp = WA_MAXT;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 4 * ntp * ntp) return;
   const int var = e / (ntp * ntp), i = (e / ntp) % ntp, j = e % ntp;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restric
   const int ntp = (nt + 3) & ~3, hdp = (a.hd + 3) & ~3;
   constexpr int KPL = DT<T>::KPACK;                      // elements per 16-byte chunk
   const int cpt = (a.hd + KPL - 1) / KPL;                // chunks per token and operand (hd is a multiple of KPL)
-  const float* btab = tab + (size_t)(((gy == nwh - 1) ? 2 : 0) + ((gx == nww - 1) ? 1 : 0)) * ntp * ntp;
+  const float* btab = tab + (size_t)(((gy == nwh - 1) ? 2 : 0) + ((gx == nww - 1) ? 1 : 0)) * WA_MAXT * WA_MAXT;
   for (int e = threadIdx.x; e < ntp * cpt; e += 256) {    // 16-byte loads; rows nt..ntp-1 are zero padding
     const int t = e / cpt, d = (e % cpt) * KPL;
     float fq[KPL], fk[KPL], fv[KPL];
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restric
     for (int x = 0; x < 4; ++x)
 #pragma unroll
       for (int y = 0; y < 4; ++y) {
-        s[(i0 + x) * WA_SS + j0 + y] = acc[x][y] * a.scale + btab[(i0 + x) * ntp + j0 + y];   // −inf outside w² x w²
+        s[(i0 + x) * WA_SS + j0 + y] = acc[x][y] * a.scale + btab[(i0 + x) * WA_MAXT + j0 + y];   // −inf outside w² x w²
       }
   }
   __syncthreads();
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
   for (int e = threadIdx.x; e < ntab; e += 256) dtab[e] = 0.f;
   constexpr int KPL = DT<T>::KPACK;
   const int cpt = (a.hd + KPL - 1) / KPL;
-  const float* btab = tab + (size_t)(((gy == nwh - 1) ? 2 : 0) + ((gx == nww - 1) ? 1 : 0)) * ntp * ntp;
+  const float* btab = tab + (size_t)(((gy == nwh - 1) ? 2 : 0) + ((gx == nww - 1) ? 1 : 0)) * WA_MAXT * WA_MAXT;
   for (int e = threadIdx.x; e < ntp * cpt; e += 256) {
     const int t = e / cpt, d = (e % cpt) * KPL;
     float fq[KPL], fk[KPL], fv[KPL], fg[KPL];
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
       for (int y = 0; y < 4; ++y) {
         const int i = i0 + x, j = j0 + y;
         const bool ok = i < nt && j < nt;
-        s[i * WA_SS + j] = acc[x][y] * a.scale + btab[i * ntp + j];
+        s[i * WA_SS + j] = acc[x][y] * a.scale + btab[i * WA_MAXT + j];
         ds[i * WA_SS + j] = ok ? dpa[x][y] : 0.f;
       }
   }
@@ -496,6 +499,328 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
   for (int e = threadIdx.x; e < ntab; e += 256) dpos_part[(size_t)blockIdx.x * ntab + e] = dtab[e];
 }
 
+// ================================================================================================
+// MFMA window attention (bf16, head_dim 32, w² ≤ 64): ONE WAVE per (image, window, head), no inter-wave traffic.
+//
+// All products run on v_mfma_f32_32x32x16_bf16 over 64x64 (padded) token tiles.  Scores are produced TRANSPOSED
+// (rows j = keys, columns i = queries): the 32x32 accumulator then holds, per lane, one query column and 16 keys in
+// registers, so the softmax over keys is an in-lane reduction plus ONE lane^32 exchange, and the probabilities are
+// ALREADY in the B-operand layout of the next product (Oᵀ = Vᵀ·Pᵀ) — no shuffles, no LDS round trip.  The register order
+// of the accumulator rows is (r&3) + 8(r>>2) + 4(lane>>5); the A operand (Vᵀ, Kᵀ, Qᵀ, dOᵀ) is read from a natural
+// [token][d] LDS tile with ds_read_b64_tr_b16 at exactly those rows, so the reduction index is permuted identically on
+// both sides.
+#define WA_RS 80   // LDS row stride in bytes of a [64 tokens][32 d] bf16 tile (64 B + 16 B pad)
+
+__device__ __forceinline__ bf16x8 wa_rowfrag(const char* tile, int tok_tile, int ks, int lane) {
+  // A/B operand with the reduction over d: row (token) = lane&31 (+32·tok_tile), d = 16·ks + 8·(lane>>5) … +7
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + ((lane & 31) + 32 * tok_tile) * WA_RS + (16 * ks + 8 * (lane >> 5)) * 2));
+}
+__device__ __forceinline__ bf16x8 wa_trfrag(const char* tile, int tok_tile, int t, int lane) {
+  // A operand [M = d][K = token] from the [token][d] tile: lane (d = lane&31, half = lane>>5), reduction slots e = 0..7 ↔
+  // token 32·tok_tile + 16·t + 8·(e>>2) + 4·half + (e&3)   (the accumulator-row order, see above)
+  const int g = lane >> 4, s4 = lane & 15;
+  const char* a = tile + (32 * tok_tile + 16 * t + (g >> 1) * 4 + (s4 >> 2)) * WA_RS + ((g & 1) * 16 + (s4 & 3) * 4) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 8 * WA_RS));
+  u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  u32x4 u = {l2[0], l2[1], h2[0], h2[1]};
+  return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ bf16x8 wa_accfrag(const f32x16& v, int t) {   // accumulator rows 8t … 8t+7 → bf16 B operand
+  bf16x8 f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (bf16_t)v[8 * t + e];
+  return f;
+}
+__device__ __forceinline__ int wa_accrow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+struct WaUnit { int b, gy, gx, h, var; };
+__device__ __forceinline__ WaUnit wa_decode(const WinAttn& a, int unit) {
+  const int nwh = a.H / a.w, nww = a.W / a.w;
+  WaUnit u;
+  u.h = unit % a.heads; unit /= a.heads;
+  u.gx = unit % nww; unit /= nww;
+  u.gy = unit % nwh;
+  u.b = unit / nwh;
+  u.var = ((u.gy == nwh - 1) ? 2 : 0) + ((u.gx == nww - 1) ? 1 : 0);
+  return u;
+}
+// loads the d-chunks {half, 2+half} of this lane's two token rows of one operand into the LDS tile (zeros past nt)
+__device__ __forceinline__ void wa_load_tile(char* tile, const bf16_t* base, const size_t (&tokoff)[2], const bool (&ok)[2], size_t rowstride, int lane) {
+  const int row = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ch = half + 2 * c;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok[tt]) v = ld16(base + tokoff[tt] * rowstride + ch * 8);
+      *reinterpret_cast<u32x4*>(tile + (row + 32 * tt) * WA_RS + ch * 16) = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ tab,
+                                                                  bf16_t* __restrict__ out, WinAttn a) {
+  __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS];
+  const int lane = threadIdx.x;
+  const WaUnit u = wa_decode(a, blockIdx.x);
+  const int nt = a.w * a.w, C = a.heads * a.hd;
+  const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
+  size_t tokoff[2];
+  bool ok[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = (lane & 31) + 32 * tt;
+    ok[tt] = t < nt;
+    tokoff[tt] = ok[tt] ? wa_token_off(a, u.b, u.gy, u.gx, t) : 0;
+  }
+  const bf16_t* qb = qkv + u.h * a.hd;
+  wa_load_tile(lq, qb, tokoff, ok, 3 * (size_t)C, lane);
+  wa_load_tile(lk, qb + C, tokoff, ok, 3 * (size_t)C, lane);
+  wa_load_tile(lv, qb + 2 * C, tokoff, ok, 3 * (size_t)C, lane);
+  __syncthreads();
+  // Sᵀ[j][i] = K·Qᵀ
+  f32x16 sacc[2][2];   // [jt][it]
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[jt][it][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        sacc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lk, jt, ks, lane), wa_rowfrag(lq, it, ks, lane), sacc[jt][it], 0, 0, 0);
+    }
+  f32x16 oacc[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = (lane & 31) + 32 * it;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(btab + i * WA_MAXT + 32 * jt + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(sacc[jt][it][4 * g + e], a.scale, bb[e]);
+          sacc[jt][it][4 * g + e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;   // padded query row: every score is −inf
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __expf(sacc[jt][it][e] - mx);
+        sacc[jt][it][e] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[it][e] = 0.f;
+    // Oᵀ[d][i] = Σ_j Vᵀ[d][j]·Pᵀ[j][i]   (normalised afterwards: one multiply per output instead of per probability)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        oacc[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lv, jt, t, lane), wa_accfrag(sacc[jt][it], t), oacc[it], 0, 0, 0);
+    if (ok[it]) {
+      bf16_t* ob = out + tokoff[it] * C + u.h * a.hd;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(oacc[it][4 * g + e] * inv);
+        *reinterpret_cast<bf16x4*>(ob + 8 * g + 4 * (lane >> 5)) = v;
+      }
+    }
+  }
+}
+
+// backward: recomputes Sᵀ/Pᵀ (orientation 1: rows j, columns i → dQ, dpos) and S/P (orientation 2: rows i, columns j →
+// dK, dV); per-query softmax statistics travel from orientation 1 to 2 through 3x64 floats of LDS.
+__global__ __launch_bounds__(64) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ tab,
+                                                                  const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                                  float* __restrict__ dpos_part, WinAttn a) {
+  __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS], lg[64 * WA_RS];
+  __shared__ __attribute__((aligned(16))) float st_m[64], st_l[64], st_d[64];
+  __shared__ float dtab[256];
+  const int lane = threadIdx.x;
+  const WaUnit u = wa_decode(a, blockIdx.x);
+  const int nt = a.w * a.w, C = a.heads * a.hd, w = a.w;
+  const int ntab = (2 * w - 1) * (2 * w - 1);
+  const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
+  for (int e = lane; e < ntab; e += 64) dtab[e] = 0.f;
+  size_t tokoff[2];
+  bool ok[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = (lane & 31) + 32 * tt;
+    ok[tt] = t < nt;
+    tokoff[tt] = ok[tt] ? wa_token_off(a, u.b, u.gy, u.gx, t) : 0;
+  }
+  const bf16_t* qb = qkv + u.h * a.hd;
+  wa_load_tile(lq, qb, tokoff, ok, 3 * (size_t)C, lane);
+  wa_load_tile(lk, qb + C, tokoff, ok, 3 * (size_t)C, lane);
+  wa_load_tile(lv, qb + 2 * C, tokoff, ok, 3 * (size_t)C, lane);
+  wa_load_tile(lg, dout + u.h * a.hd, tokoff, ok, (size_t)C, lane);
+  __syncthreads();
+
+  // ---------------- orientation 1: rows j (keys), columns i (queries)
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    const int i = (lane & 31) + 32 * it;
+    f32x16 sa[2], dp[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { sa[jt][e] = 0.f; dp[jt][e] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 qf = wa_rowfrag(lq, it, ks, lane), gf = wa_rowfrag(lg, it, ks, lane);
+        sa[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lk, jt, ks, lane), qf, sa[jt], 0, 0, 0);   // Sᵀ = K·Qᵀ
+        dp[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lv, jt, ks, lane), gf, dp[jt], 0, 0, 0);   // dPᵀ = V·dOᵀ
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(btab + i * WA_MAXT + 32 * jt + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(sa[jt][4 * g + e], a.scale, bb[e]);
+          sa[jt][4 * g + e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __expf(sa[jt][e] - mx);
+        sa[jt][e] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    float dl = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        sa[jt][e] *= inv;
+        dl = fmaf(sa[jt][e], dp[jt][e], dl);
+      }
+    dl += __shfl_xor(dl, 32, 64);
+    if (lane < 32) { st_m[i] = mx; st_l[i] = inv; st_d[i] = dl; }
+    // dSᵀ = Pᵀ∘(dPᵀ − δ_i); position-table gradient; dQᵀ = Kᵀ·dSᵀ
+    const int yi = i / w, xi = i - yi * w;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float dsv = sa[jt][e] * (dp[jt][e] - dl);
+        sa[jt][e] = dsv;
+        const int j = 32 * jt + wa_accrow(e, lane);
+        if (i < nt && j < nt) {
+          const int yj = j / w, xj = j - yj * w;
+          atomicAdd(&dtab[(yj - yi + w - 1) * (2 * w - 1) + (xj - xi + w - 1)], dsv);
+        }
+      }
+    f32x16 dq;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lk, jt, t, lane), wa_accfrag(sa[jt], t), dq, 0, 0, 0);
+    if (ok[it]) {
+      bf16_t* ob = dqkv + tokoff[it] * (3 * (size_t)C) + u.h * a.hd;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(dq[4 * g + e] * a.scale);
+        *reinterpret_cast<bf16x4*>(ob + 8 * g + 4 * (lane >> 5)) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- orientation 2: rows i (queries), columns j (keys)
+#pragma unroll 1
+  for (int jt = 0; jt < 2; ++jt) {
+    const int j = (lane & 31) + 32 * jt;
+    f32x16 pa[2], ds[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { pa[it][e] = 0.f; ds[it][e] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = wa_rowfrag(lk, jt, ks, lane), vf = wa_rowfrag(lv, jt, ks, lane);
+        pa[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lq, it, ks, lane), kf, pa[it], 0, 0, 0);   // S = Q·Kᵀ
+        ds[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lg, it, ks, lane), vf, ds[it], 0, 0, 0);   // dP = dO·Vᵀ
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i0 = 32 * it + 8 * g + 4 * (lane >> 5);
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(st_m + i0), l4 = *reinterpret_cast<const f32x4*>(st_l + i0),
+                    d4 = *reinterpret_cast<const f32x4*>(st_d + i0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sv = fmaf(pa[it][4 * g + e], a.scale, btab[(i0 + e) * WA_MAXT + j]);
+          const float pv = __expf(sv - m4[e]) * l4[e];   // −inf bias → 0
+          pa[it][4 * g + e] = pv;
+          ds[it][4 * g + e] = pv * (ds[it][4 * g + e] - d4[e]);
+        }
+      }
+    }
+    f32x16 dv, dk;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dv[e] = 0.f; dk[e] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lg, it, t, lane), wa_accfrag(pa[it], t), dv, 0, 0, 0);   // dVᵀ = dOᵀ·P
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lq, it, t, lane), wa_accfrag(ds[it], t), dk, 0, 0, 0);   // dKᵀ = Qᵀ·dS
+      }
+    if (ok[jt]) {
+      bf16_t* ob = dqkv + tokoff[jt] * (3 * (size_t)C) + u.h * a.hd;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 vk, vv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vk[e] = (bf16_t)(dk[4 * g + e] * a.scale);
+          vv[e] = (bf16_t)dv[4 * g + e];
+        }
+        *reinterpret_cast<bf16x4*>(ob + C + 8 * g + 4 * (lane >> 5)) = vk;
+        *reinterpret_cast<bf16x4*>(ob + 2 * C + 8 * g + 4 * (lane >> 5)) = vv;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < ntab; e += 64) dpos_part[(size_t)blockIdx.x * ntab + e] = dtab[e];
+}
+
+static bool wa_use_mfma(int dtype, int hd, int w) {
+  static const bool off = getenv("PFR_ATTN_MFMA") && getenv("PFR_ATTN_MFMA")[0] == '0';
+  return !off && dtype == PFR_BF16 && hd == 32 && w * w <= 64;
+}
+
 static int wa_check(int B, int H, int W, int heads, int hd, int w, int shift) {
   PFR_CHECK_ARG(w * w <= WA_MAXT && hd <= WA_MAXD && (2 * w - 1) * (2 * w - 1) <= 256, "window attention: window %d / head_dim %d too large", w, hd);
   PFR_CHECK_ARG(H % w == 0 && W % w == 0 && shift >= 0 && shift < w && B > 0 && heads > 0, "window attention: bad geometry");
@@ -503,10 +828,10 @@ static int wa_check(int B, int H, int W, int heads, int hd, int w, int shift) {
 }
 
 extern "C" long pfr_window_bias_table_floats(int window) {
-  const int ntp = (window * window + 3) & ~3;
-  return 4L * ntp * ntp;
+  (void)window;
+  return 4L * WA_MAXT * WA_MAXT;
 }
-// tab: fp32 [4][ceil4(w²)][ceil4(w²)], recomputed whenever pos changes (once per block and step)
+// tab: fp32 [4][64][64], recomputed whenever pos changes (once per block and step)
 extern "C" int pfr_window_bias_table(const float* pos, float* tab, int window, int shift, hipStream_t st) {
   PFR_CHECK_ARG(pos && tab && window * window <= WA_MAXT, "pfr_window_bias_table: bad args");
   const long n = pfr_window_bias_table_floats(window);
@@ -522,7 +847,8 @@ extern "C" int pfr_window_attn_fwd(const void* qkv, const float* pos, void* out,
   if (int rc = wa_check(B, H, W, heads, head_dim, window, shift)) return rc;
   WinAttn a{B, H, W, heads, head_dim, window, shift, scale};
   const dim3 grid((unsigned)(B * (H / window) * (W / window) * heads));
-  if (dtype == PFR_BF16) hipLaunchKernelGGL(window_attn_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, pos, (bf16_t*)out, a);
+  if (wa_use_mfma(dtype, head_dim, window)) hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, pos, (bf16_t*)out, a);
+  else if (dtype == PFR_BF16) hipLaunchKernelGGL(window_attn_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, pos, (bf16_t*)out, a);
   else hipLaunchKernelGGL(window_attn_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, pos, (float*)out, a);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
@@ -537,7 +863,8 @@ extern "C" int pfr_window_attn_bwd(const void* qkv, const float* pos, const void
   if (int rc = wa_check(B, H, W, heads, head_dim, window, shift)) return rc;
   WinAttn a{B, H, W, heads, head_dim, window, shift, scale};
   const dim3 grid((unsigned)(B * (H / window) * (W / window) * heads));
-  if (dtype == PFR_BF16) hipLaunchKernelGGL(window_attn_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
+  if (wa_use_mfma(dtype, head_dim, window)) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
+  else if (dtype == PFR_BF16) hipLaunchKernelGGL(window_attn_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
   else hipLaunchKernelGGL(window_attn_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, pos, (const float*)dout, (float*)dqkv, dpos_part, a);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
