@@ -644,18 +644,20 @@ __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* 
 
 // backward: recomputes Sᵀ/Pᵀ (orientation 1: rows j, columns i → dQ, dpos) and S/P (orientation 2: rows i, columns j →
 // dK, dV); per-query softmax statistics travel from orientation 1 to 2 through 3x64 floats of LDS.
-__global__ __launch_bounds__(64) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ tab,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ tab,
                                                                   const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                                   float* __restrict__ dpos_part, WinAttn a) {
   __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS], lg[64 * WA_RS];
   __shared__ __attribute__((aligned(16))) float st_m[64], st_l[64], st_d[64];
   __shared__ float dtab[256];
+  __shared__ __attribute__((aligned(16))) int cj[64];
   const int lane = threadIdx.x;
   const WaUnit u = wa_decode(a, blockIdx.x);
   const int nt = a.w * a.w, C = a.heads * a.hd, w = a.w;
   const int ntab = (2 * w - 1) * (2 * w - 1);
   const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
-  for (int e = lane; e < ntab; e += 64) dtab[e] = 0.f;
+  for (int e = lane; e < 256; e += 64) dtab[e] = 0.f;
+  cj[lane] = lane < nt ? (lane / w) * (2 * w - 1) + lane % w : -(1 << 20);
   size_t tokoff[2];
   bool ok[2];
 #pragma unroll
@@ -724,17 +726,21 @@ __global__ __launch_bounds__(64) void window_attn_bwd_mfma_kernel(const bf16_t* 
     dl += __shfl_xor(dl, 32, 64);
     if (lane < 32) { st_m[i] = mx; st_l[i] = inv; st_d[i] = dl; }
     // dSᵀ = Pᵀ∘(dPᵀ − δ_i); position-table gradient; dQᵀ = Kᵀ·dSᵀ
+    // table index of (i, j) = base(i) + cj[j]; padded rows / columns give a negative index and are skipped
     const int yi = i / w, xi = i - yi * w;
+    const int base_i = i < nt ? (w - 1 - yi) * (2 * w - 1) + (w - 1 - xi) : -(1 << 20);
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float dsv = sa[jt][e] * (dp[jt][e] - dl);
-        sa[jt][e] = dsv;
-        const int j = 32 * jt + wa_accrow(e, lane);
-        if (i < nt && j < nt) {
-          const int yj = j / w, xj = j - yj * w;
-          atomicAdd(&dtab[(yj - yi + w - 1) * (2 * w - 1) + (xj - xi + w - 1)], dsv);
+      for (int g = 0; g < 4; ++g) {
+        const int4 c4 = *reinterpret_cast<const int4*>(cj + 32 * jt + 8 * g + 4 * (lane >> 5));
+        const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dsv = sa[jt][4 * g + e] * (dp[jt][4 * g + e] - dl);
+          sa[jt][4 * g + e] = dsv;
+          const int idx = base_i + cc[e];
+          if (idx >= 0) atomicAdd(&dtab[idx], dsv);   // (LDS atomics are the expensive part: skip the padding)
         }
       }
     f32x16 dq;
@@ -822,7 +828,7 @@ static bool wa_use_mfma(int dtype, int hd, int w) {
 }
 
 static int wa_check(int B, int H, int W, int heads, int hd, int w, int shift) {
-  PFR_CHECK_ARG(w * w <= WA_MAXT && hd <= WA_MAXD && (2 * w - 1) * (2 * w - 1) <= 256, "window attention: window %d / head_dim %d too large", w, hd);
+  PFR_CHECK_ARG(w * w <= WA_MAXT && hd <= WA_MAXD && (2 * w - 1) * (2 * w - 1) < 256, "window attention: window %d / head_dim %d too large", w, hd);
   PFR_CHECK_ARG(H % w == 0 && W % w == 0 && shift >= 0 && shift < w && B > 0 && heads > 0, "window attention: bad geometry");
   return PFR_OK;
 }
