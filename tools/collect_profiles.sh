@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collects the evidence bench.py's roofline block refers to (run on the GPU box from the repo root):
+#   tools/collect_profiles.sh <tag>      e.g.  tools/collect_profiles.sh r01_d
+# 1. rocprofv3 --kernel-trace --stats of the default bench command  -> gpurun_out/<tag>_kernel_stats.csv
+# 2. two PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with other trace domains) -> gpurun_out/<tag>_traffic.json
+# 3. the bench lines themselves (default = ResNet-50 bs 256; Swin-T bs 128)          -> gpurun_out/<tag>_bench_*.json
+set -u
+TAG=${1:-r01_x}
+OUT=$PWD/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+# Profiling passes run with the weight-gradient side stream OFF (PFR_SIDE_STREAM=0): that is the condition under which
+# bench.py takes its per-launch HIP-event timings (a tracer forces serial execution), so the per-kernel averages of the
+# two agree; with the side stream on, concurrently running kernels stretch each other's durations.
+export PFR_SIDE_STREAM=0
+CMD="python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o stats -- $CMD > $OUT/${TAG}_prof_run.log 2>&1 )
+f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" $OUT/${TAG}_kernel_stats_bench_resnet50_bs256_bf16.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -o pmc -- $CMD > $OUT/${TAG}_pmc_$c.log 2>&1 )
+done
+python tools/hbm_traffic.py $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE 7 > $OUT/${TAG}_traffic.json
+unset PFR_SIDE_STREAM
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default.json
+python bench.py --arch swin_t --batch 128 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_swin_t_bs128.json
+rm -rf $OUT/prof_$TAG $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
+ls -la $OUT | tail -12
