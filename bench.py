@@ -133,7 +133,7 @@ def main():
     ddp = None
     if use_ddp:
         from pets_face_recognition_amd.engine import FlatDDP
-        ddp = FlatDDP(ml)
+        ddp = FlatDDP(ml, bucket_mb=int(os.environ.get("PFR_BUCKET_MB", "25")))
 
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     x = torch.rand(args.batch, 3, 224, 224, generator=g).to(device)

@@ -246,6 +246,12 @@ class FEEngine:
                 out.append((lo, hi))
         return out
 
+    def _side_ok(self):
+        """Side stream off: PFR_SIDE_STREAM=0; a launch tracer is active (it brackets launches with events on ONE stream);
+        or gradients are being all-reduced (DDP): with a third (communication) stream in play the three-way overlap
+        measured 4 % SLOWER than main + comm alone, while main + comm costs nothing over the single-GPU serial step."""
+        return self.side_stream_enabled and _TRACER[0] is None and self.grad_ready_hook is None
+
     # ------------------------------------------------------------------------------------------ weights
     def refresh_weights(self, stream, for_backward=True):
         """master fp32 → compute-dtype shadow, channel-padded stem weights, data-gradient weight layouts."""
@@ -258,7 +264,7 @@ class FEEngine:
             # the flipped / transposed copies are first needed by the backward pass: build them on the side stream,
             # concurrent with the forward pass (backward() waits for wt_ready)
             sptr = stream
-            use_side = self.side_stream_enabled and _TRACER[0] is None
+            use_side = self._side_ok()
             if use_side:
                 if self.side is None:
                     self.side = torch.cuda.Stream(device=self.device)
@@ -610,8 +616,7 @@ class FEEngine:
         if self.wt_pending:
             main.wait_event(self.wt_ready)
             self.wt_pending = False
-        # side stream off: PFR_SIDE_STREAM=0, or a launch tracer is active (it brackets launches with events on ONE stream)
-        use_side = self.side_stream_enabled and _TRACER[0] is None
+        use_side = self._side_ok()
         if use_side:
             if self.side is None:
                 self.side = torch.cuda.Stream(device=self.device)
