@@ -956,14 +956,19 @@ __global__ __launch_bounds__(256) void colsum_chunk_kernel(const T* __restrict__
   if (cglob < cpr) {
     const size_t step = (size_t)gridDim.x * rl;
     size_t r = (size_t)blockIdx.x * rl + rlane;
-    for (; r + step < rows; r += 2 * step) {   // two independent loads in flight
-      float a[KP], b[KP];
-      Chunk<T>::unpack(ld16(x + r * C + cglob * KP), a);
-      Chunk<T>::unpack(ld16(x + (r + step) * C + cglob * KP), b);
+    for (; r + 3 * step < rows; r += 4 * step) {   // four independent loads in flight
+      u32x4 q[4];
 #pragma unroll
-      for (int e = 0; e < KP; ++e) { v[0][e] += a[e]; v[1][e] += b[e]; }
+      for (int u = 0; u < 4; ++u) q[u] = ld16(x + (r + u * step) * C + cglob * KP);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float a[KP];
+        Chunk<T>::unpack(q[u], a);
+#pragma unroll
+        for (int e = 0; e < KP; ++e) v[u & 1][e] += a[e];
+      }
     }
-    if (r < rows) {
+    for (; r < rows; r += step) {
       float a[KP];
       Chunk<T>::unpack(ld16(x + r * C + cglob * KP), a);
 #pragma unroll

@@ -11,11 +11,14 @@ Mapping (tokens are kept NHWC = [B, H, W, C] end to end; the reference's NCHW↔
                                                      pfr_conv2d_wgrad, data gradient through pfr_conv2d_fwd
   cyclic shift, window partition, masks            → addressing / analytic mask inside the attention kernel
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .._hip import lib, dtype_id, PfrError
-from ._fe_engine import default_compute_dtype, _ALIGN
+from .._hip.lib import _TRACER
+from ._fe_engine import default_compute_dtype, _ALIGN, _SIDE, _FORK, _SREC, _WAIT
 
 
 class _Lin:
@@ -37,6 +40,9 @@ class SwinEngine:
         self.kp = 8 if self.dtype == torch.bfloat16 else 4
         self.model_id = id(model)
         self.plans = {}
+        self.side = None          # side stream of the weight-gradient / column-sum launches (see build_plan)
+        self.side_events = []
+        self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
         self.grad_ready_hook = None
         self._adopt(model)
 
@@ -192,8 +198,8 @@ class SwinEngine:
             KK = R * R * Cq
             splits = lib.pfr_conv2d_wgrad_splits(Nq * OH * OW, Co, KK)
             ws_need[0] = max(ws_need[0], splits * Co * KK)
-            ops.append(("wgrad", (x.data_ptr(), dy.data_ptr(), out.data_ptr(), None, did, Nq, Hq, Wq, Cq, Co, R, R, stride, 0,
-                                  OH, OW, Co, 0, 0, 0, 1.0, 0)))
+            side(ops, ("wgrad", (x.data_ptr(), dy.data_ptr(), out.data_ptr(), None, did, Nq, Hq, Wq, Cq, Co, R, R, stride, 0,
+                                OH, OW, Co, 0, 0, 0, 1.0, 0)), dy)
 
         def dgrad_lin(ops, dy, rows, r, dx):
             ops.append((lib.pfr_conv2d_fwd, (dy.data_ptr(), r.wt.data_ptr(), dx.data_ptr(), did, did, rows, 1, 1, r.out, r.inp, 1,
@@ -203,7 +209,7 @@ class SwinEngine:
 
         def colsum(ops, x, rows, C, out, dt=None):
             cs_need[0] = max(cs_need[0], lib.pfr_colsum_ws_floats(rows, C))
-            ops.append(("colsum", (x.data_ptr(), dt if dt is not None else did, rows, C, out.data_ptr(), 0, None)))
+            side(ops, ("colsum", (x.data_ptr(), dt if dt is not None else did, rows, C, out.data_ptr(), 0, None)), x)
 
         x_nhwc = A((N, H, W, self.cp))
         cur, cshape = x_nhwc, (N, H, W, self.cp)
@@ -258,15 +264,45 @@ class SwinEngine:
             return plan
 
         # ================================================================= backward
+        # Weight gradients, bias / LayerNorm-parameter / position-table column sums feed nothing before the optimizer: they run on
+        # a SIDE stream (≈ 150 short launches per step that would otherwise sit in the dependency chain).  Symbolic ops:
+        # ("fork", k) side waits for main's current point; ("srec", k) side records "op k done"; ("wait", k) main waits
+        # for op k — emitted before a pooled buffer that op k read is handed out again, before grad-ready marks and at the end.
         pool = {}
+        nalloc = {}
+        pending = {}      # data_ptr of a pooled buffer -> last side op that reads it
+        side_reads = []   # (k, data_ptr) of every side-op input
+        nside = [0]
 
         def G(shape, dtype=None):
             key = (tuple(shape), dtype or T)
             lst = pool.setdefault(key, [])
-            return lst.pop() if lst else A(shape, dtype)
+            for i, t in enumerate(lst):              # a buffer no side op is reading
+                if t.data_ptr() not in pending:
+                    return lst.pop(i)
+            if not lst or nalloc.get(key, 0) < 3:    # small rotation so that the side stream may lag behind
+                nalloc[key] = nalloc.get(key, 0) + 1
+                return A(shape, dtype)
+            t = lst.pop(0)
+            bwd.append(("wait", (pending.pop(t.data_ptr()),)))
+            return t
 
         def release(t):
+            lo, hi = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+            ks = [k for k, ptr in side_reads if lo <= ptr < hi]
+            if ks:
+                pending[t.data_ptr()] = max(ks)
+            side_reads[:] = [(k, ptr) for k, ptr in side_reads if not (lo <= ptr < hi)]
             pool.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+        def side(ops, op, *reads):
+            k = nside[0]
+            nside[0] += 1
+            ops.append(("fork", (k,)))
+            ops.append(op)
+            ops.append(("srec", (k,)))
+            for r in reads:
+                side_reads.append((k, r.data_ptr()))
 
         def ln_bwd(ops, dy, xin, mu, rs, lnrec, dres, dx, rows, C):
             nb = lib.pfr_layernorm_bwd_blocks(rows)
@@ -343,14 +379,17 @@ class SwinEngine:
                 colsum(bwd, dz, rows, C, pm.dbias)
             g_conv = pm.g_conv
             wgrad(bwd, srec["in"], (Ni, Hi, Wi, Ci), dz, (N, OH, OW, C), pm, f, f, g_conv)
-            bwd.append((lib.pfr_nhwc_to_nchw_f32, (g_conv.data_ptr(), pm.g.data_ptr(), pm.out, pm.cin, f * f, pm.cinp, 0)))
+            side(bwd, ("side", (lib.pfr_nhwc_to_nchw_f32, (g_conv.data_ptr(), pm.g.data_ptr(), pm.out, pm.cin, f * f, pm.cinp, 0))))
             if si > 0:
                 din = G((Ni, Hi, Wi, Ci))
                 bwd.append((lib.pfr_conv2d_fwd, (dz.data_ptr(), pm.wt.data_ptr(), din.data_ptr(), did, did, N, OH, OW, C, Ci, f, f, 1,
                                                  f - 1, {2: 1, 4: 2}[f], Hi, Wi, Ci, 0, 0, 0, 0, 0, 0, 0, 0)))
                 release(dz)
                 dz = din
+            if nside[0]:
+                bwd.append(("wait", (nside[0] - 1,)))   # everything the side stream was given so far is final
             bwd.append((None, (st["off"],)))
+        plan["n_side"] = nside[0]
         if self.ws is None or self.ws.numel() < ws_need[0]:
             self.ws = torch.empty(ws_need[0], dtype=torch.float32, device=dev)
         if getattr(self, "cs_ws", None) is None or self.cs_ws.numel() < cs_need[0]:
@@ -364,9 +403,17 @@ class SwinEngine:
             if fn == "wgrad":
                 a = list(args)
                 a[3] = self.ws.data_ptr()
-                res.append((lib.pfr_conv2d_wgrad, tuple(a)))
+                res.append((_SIDE, (lib.pfr_conv2d_wgrad, tuple(a))))
             elif fn == "colsum":
-                res.append((lib.pfr_colsum, tuple(args[:-1]) + (self.cs_ws.data_ptr(),)))
+                res.append((_SIDE, (lib.pfr_colsum, tuple(args[:-1]) + (self.cs_ws.data_ptr(),))))
+            elif fn == "side":
+                res.append((_SIDE, args))
+            elif fn == "fork":
+                res.append((_FORK, args[0]))
+            elif fn == "srec":
+                res.append((_SREC, args[0]))
+            elif fn == "wait":
+                res.append((_WAIT, args[0]))
             else:
                 res.append((fn, args))
         plan["bwd"] = res
@@ -406,10 +453,34 @@ class SwinEngine:
         demb = demb.contiguous()
         lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan["demb"].data_ptr(), self.did, demb.numel(), stream)
         hook = self.grad_ready_hook
+        main = torch.cuda.current_stream()
+        # side stream off: PFR_SIDE_STREAM=0, a launch tracer is active, or gradients are all-reduced (see FEEngine._side_ok)
+        use_side = self.side_stream_enabled and _TRACER[0] is None and hook is None
+        if use_side:
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=self.device)
+            side, sptr = self.side, self.side.cuda_stream
+            ev = self.side_events
+            while len(ev) < 2 * plan.get("n_side", 0):
+                ev.append(torch.cuda.Event())
         for fn, args in plan["bwd"]:
             if fn is None:
                 if hook is not None:
                     hook(args[0])
+            elif fn.__class__ is int:
+                if not use_side:
+                    if fn == _SIDE:
+                        args[0](*args[1], stream)
+                elif fn == _SIDE:
+                    args[0](*args[1], sptr)
+                elif fn == _FORK:
+                    e = ev[2 * args]
+                    e.record(main)
+                    side.wait_event(e)
+                elif fn == _SREC:
+                    ev[2 * args + 1].record(side)
+                else:
+                    main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)
         self.attach_grads()
