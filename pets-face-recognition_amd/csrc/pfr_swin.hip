@@ -45,9 +45,108 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     y[row * C + c] = from_f32<T>(fmaf((to_f32(xr[c]) - mu) * rs, gamma[c], beta[c]));
 }
 
+// Chunked LayerNorm (C a multiple of the 16-byte chunk, ≤ 256 chunks): a row is owned by G = 16 / 32 / 64 lanes (64/G rows per
+// wave), each lane keeps CPL chunks of ITS channels in registers — one 16-byte load per chunk instead of three 2-byte
+// passes — row statistics are xor-shuffles inside the G-lane group, γ/β stay in registers over a grid-stride row loop.
+struct LnGeom { int G, cpl, cpr; };
+static bool ln_geom(int C, int kp, LnGeom* g) {
+  if (C % kp) return false;
+  g->cpr = C / kp;
+  g->G = g->cpr <= 16 ? 16 : (g->cpr <= 32 ? 32 : 64);
+  g->cpl = (g->cpr + g->G - 1) / g->G;
+  return g->cpl <= 4;
+}
+static int ln_grid(long rows, int G) {
+  const long per_iter = 4L * (64 / G);
+  long nb = (rows + per_iter * 4 - 1) / (per_iter * 4);   // ≥ 4 rows per lane group
+  if (nb > 2048) nb = 2048;
+  return (int)(nb < 1 ? 1 : nb);
+}
+
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, T* __restrict__ y,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                             int C, float eps, int G, int cpr) {
+  constexpr int KP = DT<T>::KPACK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1), grp = lane / G, rpw = 64 / G;
+  float gm[CPL][KP], bt[CPL][KP];
+  bool okc[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = sub + G * k;
+    okc[k] = c < cpr;
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      gm[k][e] = okc[k] ? gamma[c * KP + e] : 0.f;
+      bt[k][e] = okc[k] ? beta[c * KP + e] : 0.f;
+    }
+  }
+  const float invC = 1.f / (float)C;
+  const long stride = (long)gridDim.x * 4 * rpw;
+  for (long row = ((long)blockIdx.x * 4 + wave) * rpw + grp; row < rows; row += stride) {
+    float f[CPL][KP];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      if (okc[k]) Chunk<T>::unpack(ld16(x + row * C + (sub + G * k) * KP), f[k]);
+#pragma unroll
+      for (int e = 0; e < KP; ++e) {
+        if (!okc[k]) f[k][e] = 0.f;
+        s += f[k][e];
+      }
+    }
+    for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s * invC;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+      for (int e = 0; e < KP; ++e) {
+        const float d = okc[k] ? f[k][e] - mu : 0.f;
+        v = fmaf(d, d, v);
+      }
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+    const float rs = rsqrtf(v * invC + eps);
+    if (sub == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      if (okc[k]) {
+#pragma unroll
+        for (int e = 0; e < KP; ++e) f[k][e] = fmaf((f[k][e] - mu) * rs, gm[k][e], bt[k][e]);
+        st16(y + row * C + (sub + G * k) * KP, Chunk<T>::pack(f[k]));
+      }
+  }
+}
+
+template <typename T>
+static bool ln_fwd2_launch(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long rows,
+                           int C, float eps, hipStream_t st) {
+  LnGeom g;
+  if (!ln_geom(C, DT<T>::KPACK, &g)) return false;
+  const dim3 grid(ln_grid(rows, g.G));
+#define PFR_LNF(K)                                                                                                      \
+  if (g.cpl == K) {                                                                                                     \
+    hipLaunchKernelGGL((layernorm_fwd2_kernel<T, K>), grid, dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, g.G, g.cpr); \
+    return true;                                                                                                        \
+  }
+  PFR_LNF(1) PFR_LNF(2) PFR_LNF(3) PFR_LNF(4)
+#undef PFR_LNF
+  return false;
+}
+
 extern "C" int pfr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                  int dtype, long rows, int C, float eps, hipStream_t st) {
   PFR_CHECK_ARG(x && gamma && beta && y, "pfr_layernorm_fwd: null pointer");
+  if (dtype == PFR_BF16 ? ln_fwd2_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, st)
+                        : ln_fwd2_launch<float>(x, gamma, beta, y, mean, rstd, rows, C, eps, st)) {
+    PFR_CHECK_LAUNCH();
+    return PFR_OK;
+  }
   const dim3 grid((unsigned)((rows + 3) / 4));
   if (dtype == PFR_BF16)
     hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
@@ -128,9 +227,105 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                             T* __restrict__ dx, float* __restrict__ part, long rows, int C,
+                                                             int G, int cpr) {
+  constexpr int KP = DT<T>::KPACK;
+  extern __shared__ float sh[];  // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1), grp = lane / G, rpw = 64 / G;
+  float gm[CPL][KP], ag[CPL][KP], ab[CPL][KP];
+  bool okc[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = sub + G * k;
+    okc[k] = c < cpr;
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      gm[k][e] = okc[k] ? gamma[c * KP + e] : 0.f;
+      ag[k][e] = 0.f;
+      ab[k][e] = 0.f;
+    }
+  }
+  const float invC = 1.f / (float)C;
+  const long stride = (long)gridDim.x * 4 * rpw;
+  for (long row = ((long)blockIdx.x * 4 + wave) * rpw + grp; row < rows; row += stride) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[CPL][KP], dv[CPL][KP];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      if (okc[k]) {
+        const size_t off = (size_t)row * C + (sub + G * k) * KP;
+        Chunk<T>::unpack(ld16(x + off), xh[k]);
+        Chunk<T>::unpack(ld16(dy + off), dv[k]);
+      }
+#pragma unroll
+      for (int e = 0; e < KP; ++e) {
+        xh[k][e] = okc[k] ? (xh[k][e] - mu) * rs : 0.f;
+        if (!okc[k]) dv[k][e] = 0.f;
+        const float g = dv[k][e] * gm[k][e];
+        a += g;
+        b = fmaf(g, xh[k][e], b);
+      }
+    }
+    for (int o = 1; o < G; o <<= 1) {
+      a += __shfl_xor(a, o, 64);
+      b += __shfl_xor(b, o, 64);
+    }
+    a *= invC;
+    b *= invC;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      if (okc[k]) {
+        const size_t off = (size_t)row * C + (sub + G * k) * KP;
+        float r[KP], o[KP];
+        if (dres) Chunk<T>::unpack(ld16(dres + off), r);
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          float v = rs * (dv[k][e] * gm[k][e] - a - xh[k][e] * b);
+          if (dres) v += r[e];
+          o[e] = v;
+          ag[k][e] = fmaf(dv[k][e], xh[k][e], ag[k][e]);
+          ab[k][e] += dv[k][e];
+        }
+        st16(dx + off, Chunk<T>::pack(o));
+      }
+  }
+  // lane groups of the wave own the same channels: fold them (xor offsets ≥ G), then the 4 waves through LDS
+#pragma unroll
+  for (int k = 0; k < CPL; ++k)
+#pragma unroll
+    for (int e = 0; e < KP; ++e)
+      for (int o = G; o < 64; o <<= 1) {
+        ag[k][e] += __shfl_xor(ag[k][e], o, 64);
+        ab[k][e] += __shfl_xor(ab[k][e], o, 64);
+      }
+  if (grp == 0) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      if (okc[k]) {
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          sh[(wave * 2 + 0) * C + (sub + G * k) * KP + e] = ag[k][e];
+          sh[(wave * 2 + 1) * C + (sub + G * k) * KP + e] = ab[k][e];
+        }
+      }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int q = c / C, cc = c % C;
+    const float v = sh[(0 * 2 + q) * C + cc] + sh[(1 * 2 + q) * C + cc] + sh[(2 * 2 + q) * C + cc] + sh[(3 * 2 + q) * C + cc];
+    part[((size_t)q * gridDim.x + blockIdx.x) * C + cc] = v;
+  }
+}
+
 extern "C" int pfr_layernorm_bwd_blocks(long rows) {
   long nb = (rows + 15) / 16;   // >= 4 rows per wave: the row loop is latency-bound, so favour many resident waves
-  if (nb > 16384) nb = 16384;
+  if (nb > 2048) nb = 2048;     // grid-stride kernels: the partial rows [2][nb][C] are summed by pfr_colsum afterwards
   return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -157,6 +352,20 @@ extern "C" int pfr_layernorm_bwd(const void* dy, const void* x, const float* mea
   PFR_CHECK_ARG(dy && x && mean && rstd && gamma && dx && part, "pfr_layernorm_bwd: null pointer");
   const int nb = pfr_layernorm_bwd_blocks(rows);
   const int rpb = (int)((rows + nb - 1) / nb);
+  {
+    LnGeom g;
+    const int kp = dtype == PFR_BF16 ? 8 : 4;
+    if (ln_geom(C, kp, &g)) {
+      const size_t shb = (size_t)8 * C * sizeof(float);
+#define PFR_LNB(TT, K)                                                                                                  \
+  if (g.cpl == K) hipLaunchKernelGGL((layernorm_bwd2_kernel<TT, K>), dim3(nb), dim3(256), shb, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, part, rows, C, g.G, g.cpr);
+      if (dtype == PFR_BF16) { PFR_LNB(bf16_t, 1) PFR_LNB(bf16_t, 2) PFR_LNB(bf16_t, 3) PFR_LNB(bf16_t, 4) }
+      else { PFR_LNB(float, 1) PFR_LNB(float, 2) PFR_LNB(float, 3) PFR_LNB(float, 4) }
+#undef PFR_LNB
+      PFR_CHECK_LAUNCH();
+      return PFR_OK;
+    }
+  }
   int rc = dtype == PFR_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, part, rows, C, nb, rpb, st)
                              : ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, part, rows, C, nb, rpb, st);
   if (rc != PFR_OK) return rc;
