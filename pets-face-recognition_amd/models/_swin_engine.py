@@ -42,6 +42,8 @@ class SwinEngine:
         self.plans = {}
         self.side = None          # side stream of the weight-gradient / column-sum launches (see build_plan)
         self.side_events = []
+        self.wt_fork = self.wt_ready = None
+        self.wt_pending = False
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
         self.grad_ready_hook = None
         self._adopt(model)
@@ -168,10 +170,28 @@ class SwinEngine:
             if r.f is not None:   # Unfold order (c, kh, kw) → conv layout [out][kh][kw][c(padded)]
                 lib.pfr_nchw_to_nhwc(self.master.data_ptr() + 4 * r.off, r.w.data_ptr(), self.did, r.out, r.cin, r.f * r.f, 1,
                                      r.cinp, stream)
-                if for_backward and r is not self.stages[0]["pm"]:
-                    lib.pfr_weight_dgrad_layout(r.w.data_ptr(), r.wt.data_ptr(), self.did, r.out, r.f, r.f, r.cinp, stream)
-            elif for_backward:
-                lib.pfr_weight_dgrad_layout(r.w.data_ptr(), r.wt.data_ptr(), self.did, r.out, 1, 1, r.inp, stream)
+        if not for_backward:
+            return
+        # data-gradient layouts are first needed by backward(): build them on the side stream, concurrent with forward
+        sptr = stream
+        use_side = self.side_stream_enabled and _TRACER[0] is None and self.grad_ready_hook is None
+        if use_side:
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=self.device)
+            if self.wt_fork is None:
+                self.wt_fork, self.wt_ready = torch.cuda.Event(), torch.cuda.Event()
+            self.wt_fork.record(torch.cuda.current_stream())
+            self.side.wait_event(self.wt_fork)
+            sptr = self.side.cuda_stream
+        for r in self._all_lins():
+            if r.f is not None:
+                if r is not self.stages[0]["pm"]:
+                    lib.pfr_weight_dgrad_layout(r.w.data_ptr(), r.wt.data_ptr(), self.did, r.out, r.f, r.f, r.cinp, sptr)
+            else:
+                lib.pfr_weight_dgrad_layout(r.w.data_ptr(), r.wt.data_ptr(), self.did, r.out, 1, 1, r.inp, sptr)
+        self.wt_pending = use_side
+        if use_side:
+            self.wt_ready.record(self.side)
 
     # ------------------------------------------------------------------------------------------ plan
     def build_plan(self, N, H, W, with_backward):
@@ -454,6 +474,9 @@ class SwinEngine:
         lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan["demb"].data_ptr(), self.did, demb.numel(), stream)
         hook = self.grad_ready_hook
         main = torch.cuda.current_stream()
+        if self.wt_pending:
+            main.wait_event(self.wt_ready)
+            self.wt_pending = False
         # side stream off: PFR_SIDE_STREAM=0, a launch tracer is active, or gradients are all-reduced (see FEEngine._side_ok)
         use_side = self.side_stream_enabled and _TRACER[0] is None and hook is None
         if use_side:
