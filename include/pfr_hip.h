@@ -178,6 +178,13 @@ int pfr_pair_similarity(const float* emb, int D, const long* idx_a, const long* 
 int pfr_card_centroids(const float* emb, const long* seg, int ncards, int D, float eps, float* cent32, void* cent,
                        int cent_dtype, pfr_stream_t stream);
 
+/* Linear layer with a fused activation epilogue — the Swin MLP `FeedForward` (reference models/swin.py:40-52: Linear →
+ * GELU → Linear) and its autograd.  x [M][K], w [N][K] (nn.Linear layout), y / y2 [M][N], all of `dtype`.
+ *   act 2: y2 = x·wT + bias (pre-activation, kept for backward), y = gelu(y2)            (forward of the first Linear)
+ *   act 3: y = (x·wT) * gelu'(y2)                         (data gradient of the second Linear joined with GELU backward) */
+int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
+                 void* y2, pfr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

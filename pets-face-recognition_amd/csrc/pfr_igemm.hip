@@ -35,6 +35,8 @@ struct IgemmParams {
   const float* pro_shift;
   int pro_relu;
   int out_relu;
+  int act;     // 0 none; 2: y2 = z (pre-activation), y = gelu(z); 3: y = z ∘ gelu'(y2)   (y2: [M][ldy] of TO; needs 16-B rows)
+  void* y2;
   FastDiv div_ohow, div_ow;
   int tilesM, tilesN;
   // parity-class mode (data gradient of a stride-2 conv, FAST path): output rows are processed per (oh%2, ow%2) class so
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
     float f[KPO];
     Chunk<TO>::unpack(v, f);
     char* dst = yb + ((size_t)m * p.ldy + co) * sizeof(TO);
-    const bool post = p.bias || p.accumulate || p.out_relu || p.residual;
+    const bool post = p.bias || p.accumulate || p.out_relu || p.residual || p.act;
     if (post) {
       if (p.residual) {
         float g[KPO];
@@ -445,6 +447,22 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       }
       v = Chunk<TO>::pack(f);
       Chunk<TO>::unpack(v, f);  // statistics see the value as stored
+      if (p.act == 2) {         // exact (erf) GELU of the STORED pre-activation; both tensors are kept for backward
+        st16(reinterpret_cast<char*>(p.y2) + ((size_t)m * p.ldy + co) * sizeof(TO), v);
+#pragma unroll
+        for (int e = 0; e < KPO; ++e) f[e] = 0.5f * f[e] * (1.f + erff(f[e] * 0.70710678118654752f));
+        v = Chunk<TO>::pack(f);
+      } else if (p.act == 3) {  // GELU backward fused into the data-gradient GEMM: dz = dh ∘ gelu'(z)
+        float z[KPO];
+        Chunk<TO>::unpack(ld16(reinterpret_cast<const char*>(p.y2) + ((size_t)m * p.ldy + co) * sizeof(TO)), z);
+#pragma unroll
+        for (int e = 0; e < KPO; ++e) {
+          const float cdf = 0.5f * (1.f + erff(z[e] * 0.70710678118654752f));
+          const float pdf = 0.3989422804014327f * __expf(-0.5f * z[e] * z[e]);
+          f[e] *= cdf + z[e] * pdf;
+        }
+        v = Chunk<TO>::pack(f);
+      }
     }
     if (p.stats_part) {
 #pragma unroll
@@ -608,6 +626,7 @@ extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, 
   p.Cout = Cout; p.ldy = ldy > 0 ? ldy : Cout;
   p.M = N * OH * OW; p.K = R * S * C;
   p.stats_part = stats_part; p.bias = bias; p.residual = residual; p.accumulate = accumulate; p.out_relu = out_relu;
+  p.act = 0; p.y2 = nullptr;
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
@@ -620,4 +639,34 @@ extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, 
     return launch_igemm<bf16_t, float>(p, dtype, out_dtype, stream);
   }
   return launch_igemm<float, float>(p, dtype, out_dtype, stream);
+}
+
+// Linear layer with a fused activation epilogue (Swin MLP: models/swin.py FeedForward = Linear → GELU → Linear):
+//   act 2: y = gelu(x·Wᵀ + b) and y2 = x·Wᵀ + b (the pre-activation, kept for backward)        [forward of fc1]
+//   act 3: y = (x·Wᵀ) ∘ gelu'(y2)                                                              [data gradient of fc2]
+extern "C" int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias,
+                            int act, void* y2, hipStream_t stream) {
+  PFR_CHECK_ARG(x && w && y && y2, "pfr_gemm_act: null pointer");
+  PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_gemm_act: bad dtype %d", dtype);
+  PFR_CHECK_ARG(act == 2 || act == 3, "pfr_gemm_act: act must be 2 (gelu, keep pre-activation) or 3 (multiply by gelu')");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(K % kp == 0 && N % kp == 0, "pfr_gemm_act: K and N must be multiples of %d", kp);
+  PFR_CHECK_ARG(M > 0 && M < (1L << 31) && (long)M * K < (1L << 31), "pfr_gemm_act: tensor too large");
+  IgemmParams p;
+  p.x = x; p.w = w; p.y = y;
+  p.N = (int)M; p.H = 1; p.W = 1; p.C = K;
+  p.R = 1; p.S = 1; p.OH = 1; p.OW = 1; p.ostride = 1; p.pad = 0; p.idil_log2 = 0;
+  p.Cout = N; p.ldy = N;
+  p.M = (int)M; p.K = K;
+  p.stats_part = nullptr; p.bias = bias; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
+  p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
+  p.act = act; p.y2 = y2;
+  p.div_ohow = make_fastdiv(1u);
+  p.div_ow = make_fastdiv(1u);
+#ifdef PFR_IGEMM_TRACE
+  p.trace = g_igemm_trace;
+  p.dbg = g_igemm_dbg;
+#endif
+  if (dtype == PFR_BF16) return launch_igemm<bf16_t, bf16_t>(p, dtype, dtype, stream);
+  return launch_igemm<float, float>(p, dtype, dtype, stream);
 }

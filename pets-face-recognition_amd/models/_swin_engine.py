@@ -42,6 +42,7 @@ class SwinEngine:
         self.plans = {}
         self.side = None          # side stream of the weight-gradient / column-sum launches (see build_plan)
         self.side_events = []
+        self.fuse_gelu = os.environ.get("PFR_FUSE_GELU", "1") != "0"
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
@@ -261,9 +262,13 @@ class SwinEngine:
                 fwd.append((lib.pfr_layernorm_fwd, (y.data_ptr(), b["ln2"].gamma.data_ptr(), b["ln2"].beta.data_ptr(), ln2.data_ptr(),
                                                     mu2.data_ptr(), rs2.data_ptr(), did, rows, C, float(b["ln2"].eps))))
                 h1 = A((rows, 4 * C))
-                gemm(fwd, ln2, rows, C, b["fc1"], h1)
                 h2 = A((rows, 4 * C))
-                fwd.append((lib.pfr_gelu_fwd, (h1.data_ptr(), h2.data_ptr(), did, rows * 4 * C)))
+                if self.fuse_gelu:   # GELU in the fc1 GEMM's epilogue (writes the pre-activation h1 and h2 = gelu(h1))
+                    fwd.append((lib.pfr_gemm_act, (ln2.data_ptr(), b["fc1"].w.data_ptr(), h2.data_ptr(), did, rows, C, 4 * C,
+                                                   b["fc1"].bias.data_ptr(), 2, h1.data_ptr())))
+                else:
+                    gemm(fwd, ln2, rows, C, b["fc1"], h1)
+                    fwd.append((lib.pfr_gelu_fwd, (h1.data_ptr(), h2.data_ptr(), did, rows * 4 * C)))
                 z = A((rows, C))
                 gemm(fwd, h2, rows, 4 * C, b["fc2"], z, residual=y)
                 srec["blocks"].append(dict(x=x, ln1=ln1, mu1=mu1, rs1=rs1, qkv=qkv, att=att, y=y, ln2=ln2, mu2=mu2, rs2=rs2,
@@ -357,8 +362,12 @@ class SwinEngine:
                 colsum(bwd, dz.view(rows, C), rows, C, b["fc2"].dbias)
                 wgrad(bwd, sv["h2"], (rows, 1, 1, 4 * C), dz, (rows, 1, 1, C), b["fc2"], 1, 1, b["fc2"].g)
                 dh2 = G((rows, 4 * C))
-                dgrad_lin(bwd, dz, rows, b["fc2"], dh2)
-                bwd.append((lib.pfr_gelu_bwd, (sv["h1"].data_ptr(), dh2.data_ptr(), dh2.data_ptr(), did, rows * 4 * C)))
+                if self.fuse_gelu:   # dh1 = (dz·W2) ∘ gelu'(h1) in the data-gradient GEMM's epilogue
+                    bwd.append((lib.pfr_gemm_act, (dz.data_ptr(), b["fc2"].wt.data_ptr(), dh2.data_ptr(), did, rows, C, 4 * C, 0, 3,
+                                                   sv["h1"].data_ptr())))
+                else:
+                    dgrad_lin(bwd, dz, rows, b["fc2"], dh2)
+                    bwd.append((lib.pfr_gelu_bwd, (sv["h1"].data_ptr(), dh2.data_ptr(), dh2.data_ptr(), did, rows * 4 * C)))
                 colsum(bwd, dh2, rows, 4 * C, b["fc1"].dbias)
                 wgrad(bwd, sv["ln2"], (rows, 1, 1, C), dh2, (rows, 1, 1, 4 * C), b["fc1"], 1, 1, b["fc1"].g)
                 dln2 = G((rows, C))
