@@ -91,3 +91,23 @@ def test_card_match_mean_strategy_vs_reference_formula():
         torch.cuda.synchronize()
         assert torch.allclose(sc.cpu(), rs[:, :100], rtol=1e-5, atol=1e-6)
         assert (idx.cpu().long() == ri[:, :100]).float().mean() > 0.999
+
+
+def test_match_edge_cases():
+    """single query, every class a singleton (the reference's ratio would be 0/0: counts must be [0, 0]), N = 2."""
+    from oracle import match_ref
+    from pets_face_recognition_amd.match import cosine_topk, recall_at_k
+    g = torch.Generator().manual_seed(9)
+    emb = torch.randn(37, 512, generator=g)
+    # singletons only
+    got = recall_at_k(emb.to(DEV), torch.arange(37).to(DEV), (10, 100), compute_dtype=torch.float32)
+    assert got[10] == [0, 0] and got[100] == [0, 0]
+    assert match_ref.recall_at_k_loop(emb, torch.arange(37), (10, 100)) == got
+    # two items of one class: each finds the other at rank 1
+    got = recall_at_k(emb[:2].to(DEV), torch.zeros(2, dtype=torch.long).to(DEV), (10, 100), compute_dtype=torch.float32)
+    assert got[10] == [2, 2] and got[100] == [2, 2]
+    # one query against a ragged gallery (not a multiple of any tile), k = 1
+    rs, ri = match_ref.topk_query_gallery(emb[:1], emb[1:], 1)
+    sc, idx = cosine_topk(emb[:1].to(DEV), emb[1:].to(DEV), 1, compute_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert idx.cpu().long().tolist() == ri.tolist() and torch.allclose(sc.cpu(), rs, rtol=1e-5, atol=1e-6)

@@ -164,3 +164,39 @@ def test_swin_fwd_bwd_vs_torch_restatement(dtype, tol_e, tol_g):
     cos = F.cosine_similarity(torch.cat(fh), torch.cat(fr), dim=0).item()
     assert cos > (0.99999 if dtype == torch.float32 else 0.99), cos
     assert worst[1] < tol_g, worst
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_with_fused_gelu_epilogues(dtype):
+    """pfr_gemm_act: act 2 (y2 = x·Wᵀ + b, y = gelu(y2)) and act 3 (y = (x·Wᵀ) ∘ gelu'(y2)) vs torch (exact erf GELU)."""
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    g = torch.Generator().manual_seed(8)
+    M, K, N = 777, 96, 384          # ragged M (tile tail)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    st = torch.cuda.current_stream().cuda_stream
+    xd, wd, bd = x.to(DEV, dtype), w.to(DEV, dtype), b.to(DEV)
+    y = torch.empty(M, N, dtype=dtype, device=DEV); y2 = torch.empty_like(y)
+    lib.pfr_gemm_act(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), dtype_id(dtype), M, K, N, bd.data_ptr(), 2, y2.data_ptr(), st)
+    torch.cuda.synchronize()
+    z = x @ w.t() + b
+    t = 1e-2 if dtype == torch.bfloat16 else 2e-5
+    assert rel(y2, z) < t
+    assert rel(y, F.gelu(y2.float().cpu())) < t          # GELU of the STORED pre-activation
+    # act 3: data gradient of a Linear(N -> K) joined with GELU backward at its input (pre-activation pre[M][K])
+    pre = torch.randn(M, K, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    if dtype == torch.bfloat16:
+        pre, dy = pre.bfloat16().float(), dy.bfloat16().float()
+    wt = w.t().contiguous()                                # [K][N]: rows = outputs of the gradient GEMM
+    out = torch.empty(M, K, dtype=dtype, device=DEV)
+    pd = pre.to(DEV, dtype)
+    lib.pfr_gemm_act(dy.to(DEV, dtype).data_ptr(), wt.to(DEV, dtype).data_ptr(), out.data_ptr(), dtype_id(dtype), M, N, K, 0, 3,
+                     pd.data_ptr(), st)
+    torch.cuda.synchronize()
+    pr = pre.clone().requires_grad_(True)
+    F.gelu(pr).backward(dy @ w)
+    assert rel(out, pr.grad) < t
