@@ -85,6 +85,12 @@ long pfr_bn_finalize_ws_floats(int nparts, int C); /* scratch floats for a paral
 int pfr_bn_finalize(const float* part, int nparts, long rows_per_part, int C, float count, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
                     float* invstd, float* scale, float* shift, float* workspace, pfr_stream_t stream);
+/* Inference embedder (Controller.validation_step / test_step, reference engine/controller.py:31-46, and the per-photo loop
+ * of generate_tsv.py:233-251): eval-mode BatchNorm folded into the producing convolution, all layers in ONE launch.
+ * descs: device array of ndesc records { const void* src; const float* gamma, *beta, *running_mean, *running_var;
+ * void* wout; float* bout; long cout, k; float eps; int src_is_f32; } (80 bytes, natural alignment):
+ * wout[co][k] = src[co][k] * gamma/sqrt(var+eps) in `dtype`, bout[co] = beta - mean*gamma/sqrt(var+eps) */
+int pfr_fold_bn(const void* descs, int ndesc, int dtype, pfr_stream_t stream);
 int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, pfr_stream_t stream);
 /* y = relu?( a1*x1 + b1 (+ a2*x2 + b2 | + x2) ): BN apply, ReLU and the residual add of a bottleneck in one pass */

@@ -334,6 +334,41 @@ extern "C" int pfr_bn_finalize(const float* part, int nparts, long rows_per_part
   return PFR_OK;
 }
 
+// eval-mode BN folded into the producing convolution (inference embedder): w'[co][k] = w[co][k]·γ/√(rv+eps),
+// b'[co] = β − rm·γ/√(rv+eps).  ONE launch for all convolutions of a network: blockIdx.y = layer, descriptors in HBM.
+struct FoldDesc {
+  const void* src;     // weights [Cout][K]: fp32 master (src_f32 = 1) or compute dtype
+  const float* gamma;  // may be null (→ 1)
+  const float* beta;   // may be null (→ 0)
+  const float* rm;
+  const float* rv;
+  void* wout;          // [Cout][K] compute dtype
+  float* bout;         // [Cout]
+  long cout, k;
+  float eps;
+  int src_f32;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void fold_bn_kernel(const FoldDesc* __restrict__ descs) {
+  const FoldDesc d = descs[blockIdx.y];
+  const long n = d.cout * d.k;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long co = i / d.k;
+    const float sc = (d.gamma ? d.gamma[co] : 1.f) * rsqrtf(d.rv[co] + d.eps);
+    const float w = d.src_f32 ? reinterpret_cast<const float*>(d.src)[i] : to_f32(reinterpret_cast<const T*>(d.src)[i]);
+    reinterpret_cast<T*>(d.wout)[i] = from_f32<T>(w * sc);
+    if (i - co * d.k == 0) d.bout[co] = (d.beta ? d.beta[co] : 0.f) - d.rm[co] * sc;
+  }
+}
+extern "C" int pfr_fold_bn(const void* descs, int ndesc, int dtype, hipStream_t st) {
+  PFR_CHECK_ARG(descs && ndesc > 0, "pfr_fold_bn: bad args");
+  const dim3 grid(64, (unsigned)ndesc);
+  if (dtype == PFR_BF16) hipLaunchKernelGGL(fold_bn_kernel<bf16_t>, grid, dim3(256), 0, st, (const FoldDesc*)descs);
+  else hipLaunchKernelGGL(fold_bn_kernel<float>, grid, dim3(256), 0, st, (const FoldDesc*)descs);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 // eval-mode BN: scale/shift from running statistics
 __global__ void bn_eval_coeff_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
                                      float eps, float* scale, float* shift) {

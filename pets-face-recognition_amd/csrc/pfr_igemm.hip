@@ -561,6 +561,7 @@ enum { TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x256, TILE_25
 static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) {
   const char* force = getenv("PFR_IGEMM_BIG");
   const bool allow_big = !(force && force[0] == '0');
+  // (8-wave tiles for K < 512 and 64-row tiles for the short-K layers were measured: no gain / slower)
   if (allow_big && dtype == PFR_BF16 && out_dtype == PFR_BF16 && K >= 512 && (K % 64) == 0) {
     const long t256 = (long)((M + 255) / 256);
     if (Cout >= 256 && t256 * ((Cout + 255) / 256) >= 160) { *bq = 256; return TILE_256x256; }

@@ -74,6 +74,8 @@ class FEEngine:
         self.plans = {}
         self.side = None          # side stream of the weight-gradient launches (see build_plan)
         self.side_events = []
+        self.fold_eval = os.environ.get("PFR_FOLD_BN", "1") != "0"   # inference: BN folded into the convs
+        self.fold_w = None
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
@@ -279,6 +281,82 @@ class FEEngine:
             self.wt_pending = use_side
             if use_side:
                 self.wt_ready.record(self.side)
+
+    # ------------------------------------------------------------------------------------------ inference (BN folded)
+    def _fold_setup(self):
+        """Folded-weight buffers + the descriptor table of pfr_fold_bn (one record per conv/BN pair)."""
+        import struct
+        pairs = [self.stem] + [cb for convs, down in self.blocks for cb in convs] + [down for _, down in self.blocks if down]
+        nw = sum((c.w_pad.numel() if c is self.stem[0] else c.w.numel()) for c, _ in pairs)
+        nb = sum(c.Cout for c, _ in pairs)
+        self.fold_w = torch.empty(nw + _ALIGN * len(pairs), dtype=self.dtype, device=self.device)
+        self.fold_b = torch.empty(nb, dtype=torch.float32, device=self.device)
+        rec = b""
+        wo = bo = 0
+        es = self.fold_w.element_size()
+        for c, bn in pairs:
+            if c is self.stem[0]:
+                src, f32, K = c.w_pad.data_ptr(), 0, c.R * c.S * self.cp   # padded compute-dtype copy (refresh_weights)
+            else:
+                src, f32, K = self.master.data_ptr() + 4 * c.off, 1, c.R * c.S * c.Cin
+            c.wf = self.fold_w[wo:wo + c.Cout * K].view(c.Cout, c.R, c.S, K // (c.R * c.S))
+            c.bf = self.fold_b[bo:bo + c.Cout]
+            rec += struct.pack("<7q2qfi", src, bn.gamma.data_ptr(), bn.beta.data_ptr(), bn.rm.data_ptr(), bn.rv.data_ptr(),
+                               c.wf.data_ptr(), c.bf.data_ptr(), c.Cout, K, float(bn.eps), f32)
+            wo += (c.Cout * K + _ALIGN - 1) // _ALIGN * _ALIGN
+            bo += c.Cout
+        assert len(rec) == 80 * len(pairs)
+        self.fold_desc = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.device)
+        self.fold_n = len(pairs)
+        self.ident = torch.cat([torch.ones(self.stem[0].Cout), torch.zeros(self.stem[0].Cout)]).to(self.device)
+
+    def build_eval_plan(self, N, H, W):
+        """Embedding extraction (no gradient): every eval-mode BN is folded into its conv (pfr_fold_bn, one launch per
+        forward), so a bottleneck is three conv launches: bias + ReLU, and for the last one + shortcut, in the epilogue."""
+        if getattr(self, "fold_w", None) is None:
+            self._fold_setup()
+        plan = _Plan()
+        ops = plan.ops
+        st, _ = self.stem
+
+        def conv(x, xshape, c, relu, residual=None):
+            Nn, Hh, Ww, C = xshape
+            OH, OW = conv_out_hw(Hh, Ww, c.R, c.S, c.stride, c.pad)
+            y = self._A(plan, (Nn, OH, OW, c.Cout))
+            ops.append((lib.pfr_conv2d_fwd, (x.data_ptr(), c.wf.data_ptr(), y.data_ptr(), self.did, self.did, Nn, Hh, Ww, C, c.Cout,
+                                             c.R, c.S, c.stride, c.pad, 0, OH, OW, c.Cout, c.bf.data_ptr(),
+                                             0 if residual is None else residual.data_ptr(), 0, int(relu), 0, 0, 0, 0)))
+            return y, (Nn, OH, OW, c.Cout)
+
+        x_nhwc = self._A(plan, (N, H, W, self.cp))
+        plan.meta["x_nhwc"] = x_nhwc
+        c1, s1 = conv(x_nhwc, (N, H, W, self.cp), st, True)
+        _, H1, W1, _ = s1
+        PH, PW = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        cur = self._A(plan, (N, PH, PW, st.Cout))
+        ops.append((lib.pfr_bn_relu_maxpool_fwd, (c1.data_ptr(), self.ident.data_ptr(), self.ident.data_ptr() + 4 * st.Cout,
+                                                  cur.data_ptr(), 0, self.did, N, H1, W1, st.Cout, 0)))
+        cshape = (N, PH, PW, st.Cout)
+        for convs, down in self.blocks:
+            xin, xshape = cur, cshape
+            short = xin
+            if down is not None:
+                short, _ = conv(xin, xshape, down[0], False)
+            z, zs = xin, xshape
+            for ci, (c, _) in enumerate(convs):
+                last = ci + 1 == len(convs)
+                z, zs = conv(z, zs, c, True, residual=short if last else None)
+            cur, cshape = z, zs
+        Nn, Hh, Ww, Cf = cshape
+        gap = self._A(plan, (N, Cf))
+        ops.append((lib.pfr_avgpool_fwd, (cur.data_ptr(), gap.data_ptr(), self.did, N, Hh * Ww, Cf)))
+        emb = self._A(plan, (N, self.emb_dim), torch.float32)
+        f = self.fc
+        self._conv_fwd(ops, gap, (N, 1, 1, Cf), f.w, emb, f, 1, 0, 1, 1, bias=f.bias)
+        plan.meta["emb"] = emb
+        plan.meta["fwd"] = ops
+        plan.meta["folded"] = True
+        return plan
 
     # ------------------------------------------------------------------------------------------ plan building
     def _A(self, plan, shape, dtype=None):
@@ -550,8 +628,11 @@ class FEEngine:
         if p is None:
             if len(self.plans) >= 6:
                 self.plans.pop(next(iter(self.plans)))
-            p = self.build_plan(N, H, W, train, with_backward)
-            self._finalize_plan(p)
+            if not train and not with_backward and self.fold_eval:
+                p = self.build_eval_plan(N, H, W)
+            else:
+                p = self.build_plan(N, H, W, train, with_backward)
+                self._finalize_plan(p)
             self.plans[key] = p
         return p
 
@@ -597,6 +678,8 @@ class FEEngine:
             self._finalize_plan(plan)
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh_weights(stream, for_backward=with_backward)
+        if plan.meta.get("folded"):
+            lib.pfr_fold_bn(self.fold_desc.data_ptr(), self.fold_n, self.did, stream)
         lib.pfr_nchw_to_nhwc(x.data_ptr(), plan.meta["x_nhwc"].data_ptr(), self.did, N, x.shape[1], H, W, self.cp, stream)
         for fn, args in plan.meta["fwd"]:
             fn(*args, stream)

@@ -105,6 +105,15 @@ def test_backbone_fwd_bwd_vs_oracle(arch, dtype, tol_emb, grad_factor):
     ps2.update(new)
     ev_ref = resnet_ref.forward(ps2, x, arch, train=False)
     assert rel(ev, ev_ref) < tol_emb
+    # the inference plan folds BN into the convolutions; the unfolded eval plan (conv → BN-apply passes) must agree
+    eng = m.hip_engine()
+    assert eng.fold_eval and any(p.meta.get("folded") for p in eng.plans.values())
+    eng.fold_eval = False
+    eng.plans.clear()
+    with torch.no_grad():
+        ev2 = m(x.to(DEV))
+    assert rel(ev2, ev_ref) < tol_emb
+    assert rel(ev, ev2) < (1e-4 if dtype == torch.float32 else 3e-2)
 
 
 def test_fused_head_vs_reference_golden():
