@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # main + side + comm + RCCL streams must not share hardware queues (see package __init__)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -11,6 +11,13 @@ Layout
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# The train step uses up to four HIP streams at once (main, weight-gradient side stream, gradient all-reduce, RCCL's own).
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; ask for 8 so that none of them share a queue.
+# Only effective if set before the HIP runtime creates its queues, hence at package import.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def install_reference_aliases():
     """Expose the sub-packages under the reference's top-level names (`losses`, `models`, `engine`, `utils`,

@@ -43,6 +43,15 @@ class _BN:
 _SIDE, _FORK, _SREC, _WAIT = 1, 2, 3, 4
 
 
+def _side_with_ddp():
+    """main + side + communication stream + RCCL's internal stream need more than HIP's default 4 hardware queues: with
+    4, two of them share a queue and serialise (measured 9.05 k vs 9.70 k img/s); the package asks for 8 at import."""
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8
+    except ValueError:
+        return False
+
+
 class _Plan:
     __slots__ = ("ops", "bufs", "meta")
 
@@ -250,9 +259,8 @@ class FEEngine:
 
     def _side_ok(self):
         """Side stream off: PFR_SIDE_STREAM=0; a launch tracer is active (it brackets launches with events on ONE stream);
-        or gradients are being all-reduced (DDP): with a third (communication) stream in play the three-way overlap
-        measured 4 % SLOWER than main + comm alone, while main + comm costs nothing over the single-GPU serial step."""
-        return self.side_stream_enabled and _TRACER[0] is None and self.grad_ready_hook is None
+        or gradients are being all-reduced (DDP) while fewer than 8 hardware queues are available (see _side_with_ddp)."""
+        return self.side_stream_enabled and _TRACER[0] is None and (self.grad_ready_hook is None or _side_with_ddp())
 
     # ------------------------------------------------------------------------------------------ weights
     def refresh_weights(self, stream, for_backward=True):

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .._hip import lib, dtype_id, PfrError
 from .._hip.lib import _TRACER
-from ._fe_engine import default_compute_dtype, _ALIGN, _SIDE, _FORK, _SREC, _WAIT
+from ._fe_engine import default_compute_dtype, _ALIGN, _SIDE, _FORK, _SREC, _WAIT, _side_with_ddp
 
 
 class _Lin:
@@ -175,7 +175,7 @@ class SwinEngine:
             return
         # data-gradient layouts are first needed by backward(): build them on the side stream, concurrent with forward
         sptr = stream
-        use_side = self.side_stream_enabled and _TRACER[0] is None and self.grad_ready_hook is None
+        use_side = self.side_stream_enabled and _TRACER[0] is None and (self.grad_ready_hook is None or _side_with_ddp())
         if use_side:
             if self.side is None:
                 self.side = torch.cuda.Stream(device=self.device)
@@ -487,7 +487,7 @@ class SwinEngine:
             main.wait_event(self.wt_ready)
             self.wt_pending = False
         # side stream off: PFR_SIDE_STREAM=0, a launch tracer is active, or gradients are all-reduced (see FEEngine._side_ok)
-        use_side = self.side_stream_enabled and _TRACER[0] is None and hook is None
+        use_side = self.side_stream_enabled and _TRACER[0] is None and (hook is None or _side_with_ddp())
         if use_side:
             if self.side is None:
                 self.side = torch.cuda.Stream(device=self.device)
