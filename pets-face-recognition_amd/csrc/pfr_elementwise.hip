@@ -105,8 +105,7 @@ struct ColGeom {
 };
 static ColGeom col_geom(int C, int kp, size_t rows, size_t target = 512) {
   ColGeom g;
-  static const int env_t = getenv("PFR_COLT") ? atoi(getenv("PFR_COLT")) : 0;   // tuning override
-  if (env_t > 0) target = (size_t)env_t;
+
   g.cpr = C / kp;
   int cw = 1;
   while (cw < g.cpr && cw < 256) cw <<= 1;

@@ -548,9 +548,6 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
 template <typename T, typename TO, int BQ, int BP>
 static int launch_tile(IgemmParams& p, hipStream_t st) {
   if (p.K >= 512 && p.C % (8 * DT<T>::KPACK) == 0) return launch_tile_k<T, TO, BQ, BP, 8, 4, 2>(p, st);
-  static const int nst4 = getenv("PFR_IGEMM_NST4") ? atoi(getenv("PFR_IGEMM_NST4")) : 2;
-  if (nst4 == 3) return launch_tile_k<T, TO, BQ, BP, 4, 4, 2, 3>(p, st);
-  if (nst4 == 4) return launch_tile_k<T, TO, BQ, BP, 4, 4, 2, 4>(p, st);
   return launch_tile_k<T, TO, BQ, BP, 4, 4, 2>(p, st);
 }
 
@@ -580,15 +577,6 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
   int bq;
   const int v = pick_tile(p.M, p.Cout, p.K, dtype, out_dtype, &bq);
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
-    const char* big = getenv("PFR_IGEMM_BIGCFG");   // experiment switch: "k4n4" = 64-byte rows, 4-slot ring
-    if (big && big[0] == 'w') {   // 4-wave variants: 128x128 / 128x64 register tiles per wave
-      if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 8, 4, 2>(p, st);
-      if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 8, 4, 2>(p, st);
-    }
-    if (big && big[0] == 'k') {
-      if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 4, 8, 2, 4>(p, st);
-      if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 4, 8, 2, 4>(p, st);
-    }
     if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 8, 8, 2>(p, st);
     if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 8, 8, 2>(p, st);
   }
