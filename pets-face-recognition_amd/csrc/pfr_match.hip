@@ -42,6 +42,29 @@ __device__ void bitonic_desc(unsigned long long* a, int n) {
   __syncthreads();
 }
 
+// visits every score of a row with 16-byte loads (rows are 16-byte aligned: ld % 4 == 0), 4 loads in flight per thread
+template <typename F>
+__device__ __forceinline__ void for_each_score(const float* __restrict__ sr, int n, F&& f) {
+  const int n4 = n >> 2;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(sr);
+  int q = threadIdx.x;
+  for (; q + 3 * 256 < n4; q += 4 * 256) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = s4[q + u * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f(4 * (q + u * 256) + e, v[u][e]);
+  }
+  for (; q < n4; q += 256) {
+    const f32x4 v = s4[q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f(4 * q + e, v[e]);
+  }
+  for (int j = 4 * n4 + threadIdx.x; j < n; j += 256) f(j, sr[j]);
+}
+
 // scores: [rows][ld] fp32 of this gallery chunk (n valid columns, global gallery index = col0 + column).
 // cur: running list [rows][K] of u64 entries (key<<32 | ~idx), sorted descending; cur_n[rows] valid counts.
 __global__ __launch_bounds__(256) void rowselect_kernel(const float* __restrict__ scores, int ld, int n, int col0, int K,
@@ -60,14 +83,24 @@ __global__ __launch_bounds__(256) void rowselect_kernel(const float* __restrict_
   if (have == K) tkey = (uint32_t)(cl[K - 1] >> 32);
   if (threadIdx.x == 0) { s_cnt = 0; s_eq = 0; }
   __syncthreads();
-  int mine = 0;
-  for (int j = threadIdx.x; j < n; j += 256) {
-    if (col0 + j == self) continue;
-    if (fkey(sr[j]) > tkey || have < K) ++mine;
+  // Full running list (every chunk but the first ones): ONE pass appends the few scores above the current K-th best; only
+  // if more than SEL_CAP pass does the radix path below re-read the row.  List not full yet: everything is a candidate.
+  bool collected = false;
+  int cnt;
+  if (have == K) {
+    for_each_score(sr, n, [&](int j, float sc) {
+      const uint32_t k = fkey(sc);
+      if (k > tkey && col0 + j != self) {
+        const int p = atomicAdd(&s_cnt, 1);
+        if (p < SEL_CAP) list[p] = ((unsigned long long)k << 32) | (uint32_t)(~(uint32_t)(col0 + j));
+      }
+    });
+    __syncthreads();
+    cnt = s_cnt;
+    collected = cnt <= SEL_CAP;
+  } else {
+    cnt = n - ((self >= col0 && self < col0 + n) ? 1 : 0);
   }
-  atomicAdd(&s_cnt, mine);
-  __syncthreads();
-  const int cnt = s_cnt;
   __syncthreads();
   uint32_t lo_key = tkey;      // collect keys > lo_key ...
   bool strict = (have == K);   // ... (or all when the list is not full yet and no radix bound was needed)
@@ -82,12 +115,11 @@ __global__ __launch_bounds__(256) void rowselect_kernel(const float* __restrict_
       const int bits = pass == 2 ? 10 : 11;
       for (int i = threadIdx.x; i < 2048; i += 256) hist[i] = 0;
       __syncthreads();
-      for (int j = threadIdx.x; j < n; j += 256) {
-        if (col0 + j == self) continue;
-        const uint32_t k = fkey(sr[j]);
+      for_each_score(sr, n, [&](int j, float sc) {
+        const uint32_t k = fkey(sc);
         const bool match = pass == 0 ? true : (pass == 1 ? (k >> 21) == prefix : (k >> 10) == prefix);
-        if (match) atomicAdd(&hist[(k >> shift) & ((1u << bits) - 1)], 1u);
-      }
+        if (match && col0 + j != self) atomicAdd(&hist[(k >> shift) & ((1u << bits) - 1)], 1u);
+      });
       __syncthreads();
       if (threadIdx.x == 0) {
         int acc = 0, b = (1 << bits) - 1;
@@ -108,23 +140,25 @@ __global__ __launch_bounds__(256) void rowselect_kernel(const float* __restrict_
     lo_key = eq_key;
     strict = true;
   }
-  // ---- collect
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
-  for (int j = threadIdx.x; j < n; j += 256) {
-    if (col0 + j == self) continue;
-    const uint32_t k = fkey(sr[j]);
-    const bool take = strict ? (k > lo_key) : true;
-    const unsigned long long e = ((unsigned long long)k << 32) | (uint32_t)(~(uint32_t)(col0 + j));
-    if (take) {
-      const int p = atomicAdd(&s_cnt, 1);
-      if (p < SEL_CAP) list[p] = e;
-    } else if (need_eq > 0 && k == eq_key) {
-      const int p = atomicAdd(&s_eq, 1);
-      if (p < SEL_EQCAP) reinterpret_cast<unsigned long long*>(hist)[p] = e;  // hist (8 KB) reused as the tie buffer
-    }
+  // ---- collect (unless the single pass above already did)
+  if (!collected) {
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for_each_score(sr, n, [&](int j, float sc) {
+      if (col0 + j == self) return;
+      const uint32_t k = fkey(sc);
+      const bool take = strict ? (k > lo_key) : true;
+      const unsigned long long e = ((unsigned long long)k << 32) | (uint32_t)(~(uint32_t)(col0 + j));
+      if (take) {
+        const int p = atomicAdd(&s_cnt, 1);
+        if (p < SEL_CAP) list[p] = e;
+      } else if (need_eq > 0 && k == eq_key) {
+        const int p = atomicAdd(&s_eq, 1);
+        if (p < SEL_EQCAP) reinterpret_cast<unsigned long long*>(hist)[p] = e;  // hist (8 KB) reused as the tie buffer
+      }
+    });
+    __syncthreads();
   }
-  __syncthreads();
   int total = min(s_cnt, SEL_CAP);
   if (need_eq > 0) {
     const int neq = min(s_eq, SEL_EQCAP);
@@ -187,6 +221,7 @@ extern "C" int pfr_topk_update(const float* scores, int rows, int ld, int n, int
                                hipStream_t st) {
   PFR_CHECK_ARG(scores && state && rows > 0 && n > 0, "pfr_topk_update: bad args");
   PFR_CHECK_ARG(K >= 1 && K <= 512, "pfr_topk_update: K must be in [1,512]");
+  PFR_CHECK_ARG(ld % 4 == 0 && (reinterpret_cast<size_t>(scores) & 15) == 0, "pfr_topk_update: score rows must be 16-byte aligned (ld %% 4 == 0)");
   unsigned long long* cur = reinterpret_cast<unsigned long long*>(state);
   int* cur_n = reinterpret_cast<int*>(reinterpret_cast<char*>(state) + (size_t)rows * K * 8);
   int* flags = cur_n + rows;
