@@ -171,6 +171,15 @@ int pfr_topk_reset(void* state, int rows, int K, pfr_stream_t stream);
  * self_idx [rows] int32 or NULL: gallery index to skip per query (all-vs-all evaluation excludes the query itself) */
 int pfr_topk_update(const float* scores, int rows, int ld, int n, int col0, int K, void* state, const int* self_idx,
                     pfr_stream_t stream);
+/* fused form for every chunk after the first (all running lists full): the match GEMM q[Q][D] x g[n][D]^T with the top-K
+ * filter in its epilogue — a score is appended to query r's candidate list cand[r][0..cap) (u64 key<<32 | ~index) iff it
+ * beats r's current K-th best; the fp32 score matrix is never written.  pfr_topk_merge then folds the candidates into
+ * the running lists.  exclude_self: skip gallery index == query row.  Overflow of a candidate list sets bit 1 of
+ * pfr_topk_flags: the caller must redo the match with pfr_topk_update. */
+int pfr_match_scores_filter(const void* q, const void* g, int dtype, int Q, int n, int D, int col0, int K, void* state,
+                            void* cand, int cap, int exclude_self, pfr_stream_t stream);
+int pfr_topk_merge(const void* cand, int cap, int rows, int K, void* state, pfr_stream_t stream);
+int pfr_topk_flags(const void* state, int rows, int K, int* out_host, pfr_stream_t stream);
 int pfr_topk_finish(const void* state, int rows, int K, float* out_scores, int* out_idx, pfr_stream_t stream);
 /* exact fp32 re-scoring of KC candidates per query (q, g: L2-normalised fp32 rows), keeps the best K */
 int pfr_topk_rescore(const float* q, const float* g, int rows, int D, const int* cand, int KC, int K, float* out_scores,

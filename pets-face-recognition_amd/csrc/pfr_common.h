@@ -98,6 +98,35 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
+// order-preserving float -> uint32 key (larger score = larger key) used by the top-K selection
+__device__ __forceinline__ uint32_t fkey(float s) {
+  const uint32_t u = __float_as_uint(s);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+// running top-K state layout (pfr_topk_state_bytes): cur u64 [rows][K] | cur_n int [rows] | flags (64 B) |
+// thrk u32 [rows] (key of the current K-th best, 0 while the list is not full) | ccnt int [rows] (candidate counters)
+struct TopkState {
+  unsigned long long* cur;
+  int* cur_n;
+  int* flags;
+  uint32_t* thrk;
+  int* ccnt;
+};
+__host__ __device__ __forceinline__ TopkState topk_state(void* state, int rows, int K) {
+  TopkState t;
+  char* b = reinterpret_cast<char*>(state);
+  t.cur = reinterpret_cast<unsigned long long*>(b);
+  t.cur_n = reinterpret_cast<int*>(b + (size_t)rows * K * 8);
+  t.flags = t.cur_n + rows;
+  t.thrk = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(t.flags) + 64);
+  t.ccnt = reinterpret_cast<int*>(t.thrk + rows);
+  return t;
+}
+
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 

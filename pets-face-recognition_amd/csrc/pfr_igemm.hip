@@ -36,7 +36,11 @@ struct IgemmParams {
   int pro_relu;
   int out_relu;
   int act;     // 0 none; 2: y2 = z (pre-activation), y = gelu(z); 3: y = z ∘ gelu'(y2)   (y2: [M][ldy] of TO; needs 16-B rows)
+               // 4: top-K filter (gallery match): nothing is stored; scores above the row's threshold key are appended
+               //    to the row's candidate list  (y = cand u64 [M][cap], y2 = thrk u32 [M])
   void* y2;
+  int* ccnt;   // act 4: candidate counters [M]
+  int cap, col0, self_excl;   // act 4: list capacity, gallery index of column 0, skip column == row (all-vs-all evaluation)
   FastDiv div_ohow, div_ow;
   int tilesM, tilesN;
   // parity-class mode (data gradient of a stride-2 conv, FAST path): output rows are processed per (oh%2, ow%2) class so
@@ -69,7 +73,7 @@ extern "C" void pfr_debug_igemm_flags(int f) { g_igemm_dbg = f; }
 #define PFR_IGEMM_NST 2
 #endif
 
-template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_>
+template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_, bool FILT = false>
 __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && sizeof(T) == 2) ? PFR_IGEMM_OCC4 : 1) void igemm_kernel(IgemmParams p) {
   constexpr int KP = DT<T>::KPACK;
   constexpr int KCH = KCH_;                    // 16-byte chunks per LDS row per k-step (4: 64-B rows, 8: 128-B rows)
@@ -90,7 +94,8 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   constexpr int EPI = BQ * OROWB;
   constexpr int RED = NW * BP * 2 * 4;
   constexpr int PROB = PRO ? 2 * 2048 * 4 : 0;  // fused-prologue coefficients (scale, shift) of up to 2048 channels
-  constexpr int SMEM = (NST * STAGE + PROB > EPI + RED) ? NST * STAGE + PROB : EPI + RED;
+  // FILT (top-K filter epilogue, act 4): scores are compared straight from the accumulators — no transpose buffer
+  constexpr int SMEM = FILT ? NST * STAGE : ((NST * STAGE + PROB > EPI + RED) ? NST * STAGE + PROB : EPI + RED);
   static_assert(SMEM <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
@@ -358,6 +363,29 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   }
 
   TSTAMP(3);
+  if constexpr (FILT) {
+    // ---- top-K filter epilogue (gallery match): a lane owns query row m of each 32x32 tile and 16 gallery columns of it
+    const uint32_t* thrk = reinterpret_cast<const uint32_t*>(p.y2);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(p.y);
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int m = m0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
+      if (m >= p.M) continue;
+      const uint32_t tk = thrk[m];
+#pragma unroll
+      for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int col = n0 + wp * (BP / WP) + i * 32 + acc_row(r, lane);
+          const uint32_t key = fkey(acc[i][j][r]);
+          if (key > tk && col < p.Cout && !(p.self_excl && p.col0 + col == m)) {
+            const int slot = atomicAdd(&p.ccnt[m], 1);
+            if (slot < p.cap) cand[(size_t)m * p.cap + slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)(p.col0 + col));
+          }
+        }
+    }
+    return;
+  }
   // ---- epilogue phase 1: accumulators -> LDS tile [BQ rows m][BP couts] of TO
 #pragma unroll
   for (int i = 0; i < TP; ++i)
@@ -615,7 +643,7 @@ extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, 
   p.Cout = Cout; p.ldy = ldy > 0 ? ldy : Cout;
   p.M = N * OH * OW; p.K = R * S * C;
   p.stats_part = stats_part; p.bias = bias; p.residual = residual; p.accumulate = accumulate; p.out_relu = out_relu;
-  p.act = 0; p.y2 = nullptr;
+  p.act = 0; p.y2 = nullptr; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0;
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
@@ -649,7 +677,7 @@ extern "C" int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, lo
   p.M = (int)M; p.K = K;
   p.stats_part = nullptr; p.bias = bias; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
   p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
-  p.act = act; p.y2 = y2;
+  p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0;
   p.div_ohow = make_fastdiv(1u);
   p.div_ow = make_fastdiv(1u);
 #ifdef PFR_IGEMM_TRACE
@@ -658,4 +686,49 @@ extern "C" int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, lo
 #endif
   if (dtype == PFR_BF16) return launch_igemm<bf16_t, bf16_t>(p, dtype, dtype, stream);
   return launch_igemm<float, float>(p, dtype, dtype, stream);
+}
+
+// Gallery match with the running top-K filter fused into the GEMM epilogue (replaces the score
+// chunk + pfr_topk_update pair for every chunk after the first): scores = q·gᵀ (q [Q][D], g [n][D], L2-normalised rows of
+// `dtype`), a score enters query r's candidate list iff its key exceeds the key of r's current K-th best.
+template <typename T, int BQ, int BP, int KCH, int NW, int WP>
+static int launch_filter_k(IgemmParams& p, hipStream_t st) {
+  p.pclass = 0; p.mclass = 0; p.tpc = 1;
+  p.div_chw = make_fastdiv(1u); p.div_cw = make_fastdiv(1u);
+  p.tilesM = (p.M + BQ - 1) / BQ;
+  p.tilesN = (p.Cout + BP - 1) / BP;
+  const dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(NW * 64);
+  hipLaunchKernelGGL((igemm_kernel<T, float, BQ, BP, false, true, KCH, NW, WP, 2, true>), grid, block, 0, st, p);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+extern "C" int pfr_match_scores_filter(const void* q, const void* g, int dtype, int Q, int n, int D, int col0, int K,
+                                       void* state, void* cand, int cap, int exclude_self, hipStream_t stream) {
+  PFR_CHECK_ARG(q && g && state && cand, "pfr_match_scores_filter: null pointer");
+  PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_match_scores_filter: bad dtype %d", dtype);
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(D % kp == 0 && Q > 0 && n > 0 && K >= 1 && K <= 512 && cap >= 1, "pfr_match_scores_filter: bad geometry");
+  const TopkState t = topk_state(state, Q, K);
+  IgemmParams p;
+  p.x = q; p.w = g; p.y = cand;
+  p.N = Q; p.H = 1; p.W = 1; p.C = D;
+  p.R = 1; p.S = 1; p.OH = 1; p.OW = 1; p.ostride = 1; p.pad = 0; p.idil_log2 = 0;
+  p.Cout = n; p.ldy = n;
+  p.M = Q; p.K = D;
+  p.stats_part = nullptr; p.bias = nullptr; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
+  p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
+  p.act = 4; p.y2 = t.thrk; p.ccnt = t.ccnt; p.cap = cap; p.col0 = col0; p.self_excl = exclude_self;
+  p.div_ohow = make_fastdiv(1u);
+  p.div_ow = make_fastdiv(1u);
+#ifdef PFR_IGEMM_TRACE
+  p.trace = g_igemm_trace;
+  p.dbg = g_igemm_dbg;
+#endif
+  PFR_CHECK_ARG(D % (8 * kp) == 0, "pfr_match_scores_filter: D must be a multiple of %d (128-byte k-steps)", 8 * kp);
+  if (dtype == PFR_BF16) {
+    if ((long)((Q + 255) / 256) * ((n + 255) / 256) >= 160) return launch_filter_k<bf16_t, 256, 256, 8, 8, 2>(p, stream);
+    return launch_filter_k<bf16_t, 128, 128, 8, 4, 2>(p, stream);
+  }
+  return launch_filter_k<float, 128, 128, 8, 4, 2>(p, stream);
 }

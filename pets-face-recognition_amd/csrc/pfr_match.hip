@@ -16,15 +16,6 @@
 #define SEL_CAP 1536    // direct-collect capacity; above it the K-th value of the chunk is found by radix select
 #define SEL_EQCAP 1024  // capacity for entries tied with the K-th value
 
-__device__ __forceinline__ uint32_t fkey(float s) {
-  const uint32_t u = __float_as_uint(s);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float fkey_inv(uint32_t k) {
-  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-  return __uint_as_float(u);
-}
-
 // descending bitonic sort of n (power of two) u64 keys in LDS by a 256-thread block
 __device__ void bitonic_desc(unsigned long long* a, int n) {
   for (int k = 2; k <= n; k <<= 1)
@@ -69,7 +60,8 @@ __device__ __forceinline__ void for_each_score(const float* __restrict__ sr, int
 // cur: running list [rows][K] of u64 entries (key<<32 | ~idx), sorted descending; cur_n[rows] valid counts.
 __global__ __launch_bounds__(256) void rowselect_kernel(const float* __restrict__ scores, int ld, int n, int col0, int K,
                                                         unsigned long long* __restrict__ cur, int* __restrict__ cur_n,
-                                                        const int* __restrict__ self_idx, int* __restrict__ flags) {
+                                                        const int* __restrict__ self_idx, int* __restrict__ flags,
+                                                        uint32_t* __restrict__ thrk) {
   __shared__ unsigned long long list[SEL_LIST];
   __shared__ unsigned int hist[2048];
   __shared__ int s_cnt, s_eq, s_bin, s_need;
@@ -186,7 +178,42 @@ __global__ __launch_bounds__(256) void rowselect_kernel(const float* __restrict_
   bitonic_desc(list, p2);
   const int keep = min(K, total);
   for (int i = threadIdx.x; i < keep; i += 256) cl[i] = list[i];
-  if (threadIdx.x == 0) cur_n[row] = keep;
+  if (threadIdx.x == 0) {
+    cur_n[row] = keep;
+    thrk[row] = keep == K ? (uint32_t)(list[K - 1] >> 32) : 0u;   // what the fused filter epilogue compares against
+  }
+}
+
+// merge the candidate list a filter-epilogue GEMM (pfr_match_scores_filter) appended for this query with its running list
+__global__ __launch_bounds__(256) void rowmerge_kernel(const unsigned long long* __restrict__ cand, int cap, int K,
+                                                       unsigned long long* __restrict__ cur, int* __restrict__ cur_n,
+                                                       uint32_t* __restrict__ thrk, int* __restrict__ ccnt,
+                                                       int* __restrict__ flags) {
+  __shared__ unsigned long long list[SEL_LIST];
+  const int row = blockIdx.x;
+  int c = ccnt[row];
+  if (c == 0) return;
+  if (c > cap) {            // more candidates than the buffer holds: the caller must redo this match on the unfused path
+    if (threadIdx.x == 0) atomicOr(flags, 2);
+    c = cap;
+  }
+  unsigned long long* cl = cur + (size_t)row * K;
+  const int have = cur_n[row];
+  for (int i = threadIdx.x; i < c; i += 256) list[i] = cand[(size_t)row * cap + i];
+  for (int i = threadIdx.x; i < have; i += 256) list[c + i] = cl[i];
+  const int total = c + have;
+  int p2 = 1;
+  while (p2 < total) p2 <<= 1;
+  for (int i = total + threadIdx.x; i < p2; i += 256) list[i] = 0ull;
+  __syncthreads();
+  bitonic_desc(list, p2);
+  const int keep = min(K, total);
+  for (int i = threadIdx.x; i < keep; i += 256) cl[i] = list[i];
+  if (threadIdx.x == 0) {
+    cur_n[row] = keep;
+    thrk[row] = keep == K ? (uint32_t)(list[K - 1] >> 32) : 0u;
+    ccnt[row] = 0;
+  }
 }
 
 __global__ void topk_unpack_kernel(const unsigned long long* __restrict__ cur, const int* __restrict__ cur_n, int rows, int K,
@@ -204,7 +231,7 @@ __global__ void topk_unpack_kernel(const unsigned long long* __restrict__ cur, c
   }
 }
 
-extern "C" long pfr_topk_state_bytes(int rows, int K) { return (long)rows * K * 8 + (long)rows * 4 + 64; }
+extern "C" long pfr_topk_state_bytes(int rows, int K) { return (long)rows * K * 8 + (long)rows * 4 + 64 + (long)rows * 8; }
 
 // state: pfr_topk_state_bytes(rows, K) bytes, zeroed by pfr_topk_reset before the first chunk
 extern "C" int pfr_topk_reset(void* state, int rows, int K, hipStream_t st) {
@@ -222,11 +249,29 @@ extern "C" int pfr_topk_update(const float* scores, int rows, int ld, int n, int
   PFR_CHECK_ARG(scores && state && rows > 0 && n > 0, "pfr_topk_update: bad args");
   PFR_CHECK_ARG(K >= 1 && K <= 512, "pfr_topk_update: K must be in [1,512]");
   PFR_CHECK_ARG(ld % 4 == 0 && (reinterpret_cast<size_t>(scores) & 15) == 0, "pfr_topk_update: score rows must be 16-byte aligned (ld %% 4 == 0)");
-  unsigned long long* cur = reinterpret_cast<unsigned long long*>(state);
-  int* cur_n = reinterpret_cast<int*>(reinterpret_cast<char*>(state) + (size_t)rows * K * 8);
-  int* flags = cur_n + rows;
-  hipLaunchKernelGGL(rowselect_kernel, dim3(rows), dim3(256), 0, st, scores, ld, n, col0, K, cur, cur_n, self_idx, flags);
+  const TopkState t = topk_state(state, rows, K);
+  hipLaunchKernelGGL(rowselect_kernel, dim3(rows), dim3(256), 0, st, scores, ld, n, col0, K, t.cur, t.cur_n, self_idx, t.flags, t.thrk);
   PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// merge the candidates appended by pfr_match_scores_filter (cand u64 [rows][cap], cap <= 1536)
+extern "C" int pfr_topk_merge(const void* cand, int cap, int rows, int K, void* state, hipStream_t st) {
+  PFR_CHECK_ARG(cand && state && rows > 0 && K >= 1 && K <= 512 && cap >= 1 && cap + K <= SEL_LIST, "pfr_topk_merge: bad args");
+  const TopkState t = topk_state(state, rows, K);
+  hipLaunchKernelGGL(rowmerge_kernel, dim3(rows), dim3(256), 0, st, (const unsigned long long*)cand, cap, K, t.cur, t.cur_n, t.thrk,
+                     t.ccnt, t.flags);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+// overflow / tie-buffer flags of the running state (device int: bit 0 tie buffer, bit 1 candidate buffer)
+extern "C" int pfr_topk_flags(const void* state, int rows, int K, int* out_host, hipStream_t st) {
+  PFR_CHECK_ARG(state && out_host, "pfr_topk_flags: null pointer");
+  const TopkState t = topk_state(const_cast<void*>(state), rows, K);
+  if (hipMemcpyAsync(out_host, t.flags, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    pfr_set_error("pfr_topk_flags: copy failed");
+    return PFR_ERR_HIP;
+  }
   return PFR_OK;
 }
 

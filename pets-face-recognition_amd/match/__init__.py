@@ -7,6 +7,9 @@ CUDA tensors run on the gfx950 kernels (normalise → MFMA GEMM per gallery chun
 optional exact fp32 re-scoring of the candidate lists); CPU tensors use plain torch (the reference's own device
 behaviour, used by the CPU plumbing config).  Ordering everywhere: score descending, ties → lower index.
 """
+import ctypes
+import os
+
 import torch
 
 from .._hip import lib, dtype_id
@@ -17,8 +20,11 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_FUSED_DEFAULT = os.environ.get("PFR_MATCH_FUSED", "1") != "0"
+
+
 def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self=False, rescore=None, slack=None,
-                normalize=True):
+                normalize=True, fused_filter=_FUSED_DEFAULT):
     """Top-k gallery rows per query by cosine similarity.  q [Q,D], g [G,D] (any scale; rows are L2-normalised here).
     → (scores [Q,k] fp32 cosine, idx [Q,k] int32, −1 / −inf padded when fewer than k exist).
     exclude_self: q and g are the same set, the diagonal is skipped (the reference excludes the query itself).
@@ -50,13 +56,32 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     ld = (chunk + 3) // 4 * 4
     sbuf = torch.empty((Q, 1, 1, ld), dtype=torch.float32, device=q.device)
     state = torch.empty(lib.pfr_topk_state_bytes(Q, kc), dtype=torch.uint8, device=q.device)
-    lib.pfr_topk_reset(state.data_ptr(), Q, kc, _stream())
     self_idx = torch.arange(Q, dtype=torch.int32, device=q.device) if exclude_self else None
-    for c0 in range(0, G, chunk):
-        n = min(chunk, G - c0)
-        ops.conv2d_fwd(qn.view(Q, 1, 1, D), gn[c0:c0 + n].view(n, 1, 1, D), out=sbuf)
-        lib.pfr_topk_update(sbuf.data_ptr(), Q, ld, n, c0, kc, state.data_ptr(), 0 if self_idx is None else self_idx.data_ptr(),
-                            _stream())
+    # Chunks after the first (every running list is full by then) use the GEMM with the top-K filter in its epilogue: the
+    # fp32 score chunk is never written.  A candidate-list overflow (adversarially ordered gallery) is flagged on the
+    # device and the whole match is redone on the unfused path.
+    fused = fused_filter and G > chunk and chunk >= kc + 1 and D % (64 if T == torch.bfloat16 else 32) == 0
+    cap = 1536
+    cand = torch.empty((Q, cap), dtype=torch.int64, device=q.device) if fused else None
+    while True:
+        lib.pfr_topk_reset(state.data_ptr(), Q, kc, _stream())
+        for c0 in range(0, G, chunk):
+            n = min(chunk, G - c0)
+            if fused and c0 > 0:
+                lib.pfr_match_scores_filter(qn.data_ptr(), gn[c0:c0 + n].data_ptr(), dtype_id(T), Q, n, D, c0, kc, state.data_ptr(),
+                                            cand.data_ptr(), cap, int(exclude_self), _stream())
+                lib.pfr_topk_merge(cand.data_ptr(), cap, Q, kc, state.data_ptr(), _stream())
+                continue
+            ops.conv2d_fwd(qn.view(Q, 1, 1, D), gn[c0:c0 + n].view(n, 1, 1, D), out=sbuf)
+            lib.pfr_topk_update(sbuf.data_ptr(), Q, ld, n, c0, kc, state.data_ptr(), 0 if self_idx is None else self_idx.data_ptr(),
+                                _stream())
+        if not fused:
+            break
+        flag = ctypes.c_int(0)
+        lib.pfr_topk_flags(state.data_ptr(), Q, kc, ctypes.addressof(flag), _stream())
+        if not (flag.value & 2):
+            break
+        fused = False   # candidate buffer overflow: redo without the fused filter
     sc = torch.empty((Q, kc), dtype=torch.float32, device=q.device)
     idx = torch.empty((Q, kc), dtype=torch.int32, device=q.device)
     lib.pfr_topk_finish(state.data_ptr(), Q, kc, sc.data_ptr(), idx.data_ptr(), _stream())

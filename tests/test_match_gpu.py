@@ -111,3 +111,31 @@ def test_match_edge_cases():
     sc, idx = cosine_topk(emb[:1].to(DEV), emb[1:].to(DEV), 1, compute_dtype=torch.float32)
     torch.cuda.synchronize()
     assert idx.cpu().long().tolist() == ri.tolist() and torch.allclose(sc.cpu(), rs, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_filter_exclude_self_and_overflow_fallback(dtype):
+    """The top-K filter fused into the match GEMM (chunks after the first): (1) all-vs-all with the diagonal excluded gives
+    the unfused result; (2) a gallery ordered by ASCENDING score overflows the candidate buffer → the match is redone on the
+    unfused path and is still exact."""
+    from oracle import match_ref
+    from pets_face_recognition_amd.match import cosine_topk
+    g = torch.Generator().manual_seed(21)
+    emb = torch.randn(700, 512, generator=g)
+    a = cosine_topk(emb.to(DEV), emb.to(DEV), 50, compute_dtype=dtype, chunk=128, exclude_self=True, fused_filter=True)
+    b = cosine_topk(emb.to(DEV), emb.to(DEV), 50, compute_dtype=dtype, chunk=128, exclude_self=True, fused_filter=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+    assert not (a[1].cpu().long() == torch.arange(700)[:, None]).any()
+    # ascending gallery: row i = cos(theta_i) q0 + sin(theta_i) r with theta decreasing → score vs q0 strictly increasing
+    q0 = torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=1)
+    r = torch.randn(1, 512, generator=g)
+    r = torch.nn.functional.normalize(r - (r * q0).sum() * q0, dim=1)
+    th = torch.linspace(1.5, 0.05, 9000)[:, None]
+    gal = torch.cos(th) * q0 + torch.sin(th) * r
+    qs = q0.repeat(3, 1)
+    sc, idx = cosine_topk(qs.to(DEV), gal.to(DEV), 10, compute_dtype=dtype, chunk=4096, fused_filter=True)
+    torch.cuda.synchronize()
+    rs, ri = match_ref.topk_query_gallery(qs, gal, 10)
+    assert idx.cpu().long().tolist() == ri.tolist()
+    assert torch.allclose(sc.cpu(), rs, rtol=1e-4, atol=1e-5)
