@@ -120,6 +120,10 @@ int pfr_avgpool_fwd(const void* x, void* y, int dtype, int N, int HW, int C, pfr
 int pfr_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int HW, int C, pfr_stream_t stream);
 
 /* ---- ArcFace / CosFace head + (focal) cross-entropy (losses/large_margin.py:30-40,69-84; losses/losses.py:22-28) */
+/* match preparation (F.normalize of query / gallery embeddings, engine/controller.py:77-90 via similarity_f): one pass
+ * over fp32 rows writes the L2-normalised row in bf16 (GEMM operand) and / or fp32 (exact re-scoring operand) */
+int pfr_l2norm_dual(const float* x, void* xn_bf16, float* xn_f32, float* inv_norm, int rows, int D, float eps,
+                    pfr_stream_t stream);
 int pfr_l2norm_fwd(const void* x, int in_dtype, void* xn, void* xnT, int out_dtype, float* inv_norm, int rows, int D,
                    int ldt, float eps, pfr_stream_t stream);
 int pfr_l2norm_bwd(const void* x, int in_dtype, const float* inv_norm, const float* dxn, void* dx, int out_dtype, int rows,

@@ -53,6 +53,53 @@ extern "C" int pfr_l2norm_fwd(const void* x, int in_dtype, void* xn, void* xnT, 
   return PFR_OK;
 }
 
+// gallery / query preparation of the match: ONE pass over fp32 rows (float4 loads kept in registers) writes the normalised
+// row in bf16 (GEMM operand) AND in fp32 (exact re-scoring operand).  D % 4 == 0, D <= 2048.
+__global__ __launch_bounds__(256) void l2norm_dual_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb, float* __restrict__ xf,
+                                                          float* __restrict__ inv_norm, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+  const int n4 = D >> 2;
+  f32x4 v[8];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      v[k] = xr[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss = fmaf(v[k][e], v[k][e], ss);
+    }
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.f / fmaxf(sqrtf(ss), eps);
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      f32x4 o = v[k] * inv;
+      if (xf) reinterpret_cast<f32x4*>(xf + (size_t)row * D)[i] = o;
+      if (xb) {
+        bf16x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (bf16_t)o[e];
+        reinterpret_cast<bf16x4*>(xb + (size_t)row * D)[i] = b;
+      }
+    }
+  }
+}
+extern "C" int pfr_l2norm_dual(const float* x, void* xn_bf16, float* xn_f32, float* inv_norm, int rows, int D, float eps,
+                               hipStream_t st) {
+  PFR_CHECK_ARG(x && (xn_bf16 || xn_f32) && rows > 0, "pfr_l2norm_dual: null pointer");
+  PFR_CHECK_ARG(D % 4 == 0 && D <= 2048, "pfr_l2norm_dual: D must be a multiple of 4 and <= 2048");
+  hipLaunchKernelGGL(l2norm_dual_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, (bf16_t*)xn_bf16, xn_f32, inv_norm, rows, D, eps);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 // dx = inv_norm · (dxn − xn · (xn·dxn)) ; xn is the normalised row recomputed in fp32 from x and inv_norm
 template <typename TI, typename TOo>
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const TI* __restrict__ x, const float* __restrict__ inv_norm,

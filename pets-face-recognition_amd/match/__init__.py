@@ -43,7 +43,16 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     kc = min(kc, 512)
     q32 = q.float().contiguous()
     g32 = g.float().contiguous()
-    if normalize:
+    if normalize and T == torch.bfloat16 and D % 4 == 0 and D <= 2048:
+        # one pass per matrix: bf16 GEMM operand + (when re-scoring) the fp32 copy
+        def prep(x):
+            xb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+            xf = torch.empty(x.shape, dtype=torch.float32, device=x.device) if rescore else None
+            lib.pfr_l2norm_dual(x.data_ptr(), xb.data_ptr(), 0 if xf is None else xf.data_ptr(), 0, x.shape[0], D, 1e-12, _stream())
+            return xb, xf
+        qn, qn32 = prep(q32)
+        gn, gn32 = prep(g32)
+    elif normalize:
         qn, _, _ = ops.l2norm_fwd(q32, T)
         gn, _, _ = ops.l2norm_fwd(g32, T)
         if rescore:
