@@ -90,20 +90,29 @@ class FlatDDP:
             dist.broadcast(p.data, 0, group=group)
         self.reducer = BucketReducer(eng.grad, bucket_elems=bucket_mb * 1024 * 1024 // 4, group=group)
         eng.grad_ready_hook = self.reducer.ready
-        self.extra_handles = []
+        # The head's gradient (ArcFace weight, 20 MB at 10 000 ids) is complete BEFORE the backbone's backward starts:
+        # its all-reduce is launched from a post-accumulate hook and overlaps the whole backbone backward.
+        self._extra_done = set()
+        for p in self.extra:
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._reduce_param)
+
+    def _reduce_param(self, p):
+        r = self.reducer
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        r.comm_stream.wait_event(ev)
+        with torch.cuda.stream(r.comm_stream):
+            h = dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        r.handles.append((h, 0, 0))
+        self._extra_done.add(id(p))
 
     def reduce_extra(self):
-        """all-reduce gradients that do not live in the engine's flat buffer (the ArcFace weight)"""
-        r = self.reducer
+        """all-reduce gradients outside the engine's flat buffer whose hook did not fire (e.g. gradient accumulation paths)"""
         for p in self.extra:
-            if p.grad is None:
-                continue
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            r.comm_stream.wait_event(ev)
-            with torch.cuda.stream(r.comm_stream):
-                h = dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            r.handles.append((h, 0, 0))
+            if p.grad is not None and id(p) not in self._extra_done:
+                self._reduce_param(p)
+        self._extra_done.clear()
 
     def finish_backward(self):
         self.reduce_extra()
