@@ -54,6 +54,14 @@ int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dty
                    int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int ldy,
                    const float* bias, const void* residual, int accumulate, int out_relu, const float* pro_scale,
                    const float* pro_shift, int pro_relu, float* stats_part, pfr_stream_t stream);
+/* data gradient of a block's first conv joined with the residual-branch gradient (autograd of torchvision
+ * Bottleneck/BasicBlock `out += identity; out = relu(out)`): dx = dgrad(dy) + (mask ? res : 0).  dy [N][H][W][C], wt the
+ * pfr_weight_dgrad_layout weights, dx / res [N][OH][OW][Cout]; res = gradient w.r.t. the block OUTPUT, res_mask = the ReLU
+ * bit mask pfr_bn_act_mask wrote in forward ([N*OH*OW][Cout / (8 bf16 | 4 f32)] bytes); pad / idil_log2 as for the plain
+ * data gradient through pfr_conv2d_fwd */
+int pfr_conv2d_dgrad_join(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int R,
+                          int S, int pad, int idil_log2, int OH, int OW, const void* res, const unsigned char* res_mask,
+                          pfr_stream_t stream);
 
 /* pfr_conv2d_wgrad replaces the autograd weight gradient of nn.Conv2d / nn.Linear / F.linear:
  *   dw[co][r][s][c] (fp32) = scale * sum_m dy[m][co] * act(x)[...]  (+ dw if accumulate)

@@ -40,6 +40,7 @@ struct IgemmParams {
                //    to the row's candidate list  (y = cand u64 [M][cap], y2 = thrk u32 [M])
   void* y2;
   int* ccnt;   // act 4: candidate counters [M]
+  const unsigned char* res_mask;   // optional bit mask of `residual` ([M][ldy / KPACK] bytes, pfr_bn_act_mask): masked-out elements add 0
   int cap, col0, self_excl;   // act 4: list capacity, gallery index of column 0, skip column == row (all-vs-all evaluation)
   FastDiv div_ohow, div_ow;
   int tilesM, tilesN;
@@ -454,6 +455,11 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
 #pragma unroll
           for (int e = 0; e < KPO; ++e) g[e] = (co + e < p.Cout) ? to_f32(reinterpret_cast<const TO*>(rsrc)[e]) : 0.f;
         }
+        if (p.res_mask) {   // residual-branch gradient join: only where the block's ReLU was active
+          const unsigned bits = p.res_mask[(size_t)m * (p.ldy / KPO) + co / KPO];
+#pragma unroll
+          for (int e = 0; e < KPO; ++e) g[e] = (bits >> e) & 1u ? g[e] : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < KPO; ++e) f[e] += g[e];
       }
@@ -622,11 +628,34 @@ extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int dtype, int out_dtype
   return bq;
 }
 
+static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
+                           int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
+                           int ldy, const float* bias, const void* residual, int accumulate, int out_relu,
+                           const float* pro_scale, const float* pro_shift, int pro_relu, float* stats_part,
+                           const unsigned char* res_mask, hipStream_t stream);
 extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
                               int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
                               int ldy, const float* bias, const void* residual, int accumulate, int out_relu,
                               const float* pro_scale, const float* pro_shift, int pro_relu, float* stats_part,
                               hipStream_t stream) {
+  return conv2d_fwd_impl(x, w, y, dtype, out_dtype, N, H, W, C, Cout, R, S, stride, pad, idil_log2, OH, OW, ldy, bias, residual,
+                         accumulate, out_relu, pro_scale, pro_shift, pro_relu, stats_part, nullptr, stream);
+}
+// data gradient joined with the residual-branch gradient of a block: dx = dgrad(dy) + (mask ? res : 0), where `res` is the
+// gradient that arrived at the block output and `res_mask` the ReLU bit mask the forward tail wrote (pfr_bn_act_mask)
+extern "C" int pfr_conv2d_dgrad_join(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout,
+                                     int R, int S, int pad, int idil_log2, int OH, int OW, const void* res,
+                                     const unsigned char* res_mask, hipStream_t stream) {
+  PFR_CHECK_ARG(res && res_mask, "pfr_conv2d_dgrad_join: null pointer");
+  PFR_CHECK_ARG(Cout % (dtype == PFR_BF16 ? 8 : 4) == 0, "pfr_conv2d_dgrad_join: Cout must be a multiple of the 16-byte chunk");
+  return conv2d_fwd_impl(dy, wt, dx, dtype, dtype, N, H, W, C, Cout, R, S, 1, pad, idil_log2, OH, OW, Cout, nullptr, res, 0, 0,
+                         nullptr, nullptr, 0, nullptr, res_mask, stream);
+}
+static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
+                           int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
+                           int ldy, const float* bias, const void* residual, int accumulate, int out_relu,
+                           const float* pro_scale, const float* pro_shift, int pro_relu, float* stats_part,
+                           const unsigned char* res_mask, hipStream_t stream) {
   PFR_CHECK_ARG(x && w && y, "pfr_conv2d_fwd: null pointer");
   PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_conv2d_fwd: bad dtype %d", dtype);
   PFR_CHECK_ARG(out_dtype == dtype || out_dtype == PFR_F32, "pfr_conv2d_fwd: out_dtype must be dtype or f32");
@@ -643,7 +672,7 @@ extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, 
   p.Cout = Cout; p.ldy = ldy > 0 ? ldy : Cout;
   p.M = N * OH * OW; p.K = R * S * C;
   p.stats_part = stats_part; p.bias = bias; p.residual = residual; p.accumulate = accumulate; p.out_relu = out_relu;
-  p.act = 0; p.y2 = nullptr; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0;
+  p.act = 0; p.y2 = nullptr; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = res_mask;
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
@@ -677,7 +706,7 @@ extern "C" int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, lo
   p.M = (int)M; p.K = K;
   p.stats_part = nullptr; p.bias = bias; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
   p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
-  p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0;
+  p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = nullptr;
   p.div_ohow = make_fastdiv(1u);
   p.div_ow = make_fastdiv(1u);
 #ifdef PFR_IGEMM_TRACE
@@ -718,7 +747,7 @@ extern "C" int pfr_match_scores_filter(const void* q, const void* g, int dtype, 
   p.M = Q; p.K = D;
   p.stats_part = nullptr; p.bias = nullptr; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
   p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
-  p.act = 4; p.y2 = t.thrk; p.ccnt = t.ccnt; p.cap = cap; p.col0 = col0; p.self_excl = exclude_self;
+  p.act = 4; p.y2 = t.thrk; p.ccnt = t.ccnt; p.cap = cap; p.col0 = col0; p.self_excl = exclude_self; p.res_mask = nullptr;
   p.div_ohow = make_fastdiv(1u);
   p.div_ow = make_fastdiv(1u);
 #ifdef PFR_IGEMM_TRACE

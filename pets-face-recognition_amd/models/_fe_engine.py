@@ -573,10 +573,12 @@ class FEEngine:
         for (convs, down), (xin, xshape, raws, cd, out, oshape, acts) in zip(reversed(self.blocks), reversed(bsaved)):
             lastc, lastbn = convs[-1]
             ylast, _ = raws[-1]
-            gres = G(oshape)
-            # BN(last) + residual + ReLU backward; dx in place over dcur
-            bn_bwd(dcur, out, ylast, oshape, lastbn, 3, dcur, gres, acc)   # `out` here is the block's ReLU bit mask
-            dy, dyshape = dcur, oshape
+            # BN(last) + residual + ReLU backward.  `out` is the block's ReLU bit mask; dcur (the gradient that arrived at
+            # the block output) is KEPT: the residual branch consumes it through the same mask (no masked copy is written)
+            dz3 = G(oshape)
+            bn_bwd(dcur, out, ylast, oshape, lastbn, 3, dz3, None, acc)
+            rmask = out
+            dy, dyshape = dz3, oshape
             for i in range(len(convs) - 1, 0, -1):
                 c, bn = convs[i]
                 pc, pbn = convs[i - 1]
@@ -592,16 +594,23 @@ class FEEngine:
                 dy, dyshape = dz, xrs
             c0, bn0 = convs[0]
             wgrad(xin, xshape, dy, dyshape, c0)
+            dxin = G(xshape)
             if down is not None:
                 dc, dbn = down
-                bn_bwd(gres, None, cd, oshape, dbn, 0, gres, None, acc)
-                wgrad(xin, xshape, gres, oshape, dc)
-                dxin = G(xshape)
-                dgrad(gres, oshape, dc, dxin, xshape)
-                release(gres)
+                dgd = G(oshape)
+                bn_bwd(dcur, rmask, cd, oshape, dbn, 3, dgd, None, acc)      # projection-shortcut BN: g = dcur ∘ mask
+                release(dcur)
+                wgrad(xin, xshape, dgd, oshape, dc)
+                dgrad(dgd, oshape, dc, dxin, xshape)
+                release(dgd)
+                dgrad(dy, dyshape, c0, dxin, xshape, accumulate=1)
             else:
-                dxin = gres
-            dgrad(dy, dyshape, c0, dxin, xshape, accumulate=1)
+                # identity shortcut: dxin = dgrad(conv1) + dcur ∘ mask in the data-gradient epilogue
+                log2 = {1: 0, 2: 1}[c0.stride]
+                ops.append((lib.pfr_conv2d_dgrad_join, (dy.data_ptr(), c0.wt.data_ptr(), dxin.data_ptr(), self.did, dyshape[0],
+                                                        dyshape[1], dyshape[2], dyshape[3], c0.Cin, c0.R, c0.S, c0.R - 1 - c0.pad,
+                                                        log2, xshape[1], xshape[2], dcur.data_ptr(), rmask.data_ptr())))
+                release(dcur)
             self._mark(ops, c0.off)  # conv1.weight is the block's first parameter: flat grads [c0.off, end) are final
             release(dy)
             dcur = dxin
