@@ -118,6 +118,15 @@ class FlatDDP:
         self.reduce_extra()
         self.reducer.finish()
 
+    def sync_buffers(self):
+        """Rank 0's BatchNorm running statistics → every rank.  torch's DistributedDataParallel (the reference's wrapper,
+        utils/__init__.py:114-119) broadcasts module buffers from rank 0 (`broadcast_buffers=True`), so every rank evaluates
+        with rank 0's statistics; here the statistics of a step never feed the next train step (train-mode BN uses batch
+        statistics), so one broadcast before an evaluation pass gives the same evaluation-time state."""
+        if hasattr(self.eng, "stats"):
+            dist.broadcast(self.eng.stats, 0, group=self.group)
+            dist.broadcast(self.eng.nbt, 0, group=self.group)
+
 
 class GenericDDP:
     """Gradient averaging for the torch (CPU) execution path: the same replicate-all / mean-reduce semantics on
@@ -128,9 +137,9 @@ class GenericDDP:
         self.group = group
         for p in self.params:
             dist.broadcast(p.data, 0, group=group)
-        for b in module.buffers():
-            if b.dtype.is_floating_point:
-                dist.broadcast(b.data, 0, group=group)
+        self.buffers = [b for b in module.buffers() if b.dtype.is_floating_point]
+        for b in self.buffers:
+            dist.broadcast(b.data, 0, group=group)
 
     def finish_backward(self):
         world = dist.get_world_size(self.group)
@@ -145,3 +154,7 @@ class GenericDDP:
             n = g.numel()
             g.copy_(flat[off:off + n].view_as(g))
             off += n
+
+    def sync_buffers(self):
+        for b in self.buffers:
+            dist.broadcast(b.data, 0, group=self.group)

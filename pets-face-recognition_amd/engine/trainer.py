@@ -118,6 +118,8 @@ class Trainer:
         return controller
 
     def _run_eval(self, controller, device, kind):
+        if self.ddp is not None:
+            self.ddp.sync_buffers()   # every rank evaluates with rank 0's BN statistics (torch DDP's broadcast_buffers)
         controller.eval()
         loaders = controller.val_dataloader() if kind == 'val' else controller.test_dataloader()
         if not isinstance(loaders, (list, tuple)):
