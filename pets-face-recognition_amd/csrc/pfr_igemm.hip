@@ -593,13 +593,23 @@ static int launch_tile(IgemmParams& p, hipStream_t st) {
 // Returns the m-tile height (also what the caller sizes stats_part with) and the variant id.
 enum { TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x256, TILE_256x128 };
 static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) {
+  static const int forced = getenv("PFR_IGEMM_TILE") ? atoi(getenv("PFR_IGEMM_TILE")) : -1;   // tuning: tools/tile_sweep.py
+  if (forced >= 0) {
+    const bool big_ok = dtype == PFR_BF16 && out_dtype == PFR_BF16 && K >= 64 && (K % 64) == 0;
+    if ((forced == TILE_256x256 || forced == TILE_256x128) && !big_ok) { /* fall through to the heuristic */ }
+    else {
+      *bq = (forced == TILE_256x256 || forced == TILE_256x128) ? 256 : ((forced == TILE_128x128 || forced == TILE_128x64) ? 128 : 64);
+      return forced;
+    }
+  }
   const char* force = getenv("PFR_IGEMM_BIG");
   const bool allow_big = !(force && force[0] == '0');
   // (8-wave tiles for K < 512 and 64-row tiles for the short-K layers were measured: no gain / slower)
   if (allow_big && dtype == PFR_BF16 && out_dtype == PFR_BF16 && K >= 512 && (K % 64) == 0) {
     const long t256 = (long)((M + 255) / 256);
     if (Cout >= 256 && t256 * ((Cout + 255) / 256) >= 160) { *bq = 256; return TILE_256x256; }
-    if (Cout >= 128 && t256 * ((Cout + 127) / 128) >= 320) { *bq = 256; return TILE_256x128; }
+    // (Cout = 128, a single column of 256x128 tiles, loses 10-17 % to the 128x128 tile: tools/tile_sweep.py)
+    if (Cout >= 256 && t256 * ((Cout + 127) / 128) >= 320) { *bq = 256; return TILE_256x128; }
   }
   const int bp = Cout >= 128 ? 128 : 64;
   const long tiles128 = (long)((M + 127) / 128) * ((Cout + bp - 1) / bp);
