@@ -607,17 +607,17 @@ static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) 
   // (8-wave tiles for K < 512 and 64-row tiles for the short-K layers were measured: no gain / slower)
   if (allow_big && dtype == PFR_BF16 && out_dtype == PFR_BF16 && K >= 512 && (K % 64) == 0) {
     const long t256 = (long)((M + 255) / 256);
-    if (Cout >= 256 && t256 * ((Cout + 255) / 256) >= 160) { *bq = 256; return TILE_256x256; }
+    if (Cout >= 192 && t256 * ((Cout + 255) / 256) >= 160) { *bq = 256; return TILE_256x256; }
     // (Cout = 128, a single column of 256x128 tiles, loses 10-17 % to the 128x128 tile: tools/tile_sweep.py)
     if (Cout >= 256 && t256 * ((Cout + 127) / 128) >= 320) { *bq = 256; return TILE_256x128; }
   }
-  const int bp = Cout >= 128 ? 128 : 64;
+  const int bp = Cout > 64 ? 128 : 64;   // (Cout = 96: the 128-wide tile with a quarter of its columns idle still wins by ~10 %)
   const long tiles128 = (long)((M + 127) / 128) * ((Cout + bp - 1) / bp);
   // 64-row tiles only when 128-row tiles would leave most CUs idle; at ~1.5 workgroups per CU (the 7x7 layers: 392 tiles)
   // the 128-row tile still wins by 20-30 %: it re-fetches the 4.7 MB weight matrix half as often (measured)
   const int b = tiles128 >= 384 ? 128 : 64;
   *bq = b;
-  if (Cout >= 128) return b == 128 ? TILE_128x128 : TILE_64x128;
+  if (bp == 128) return b == 128 ? TILE_128x128 : TILE_64x128;
   return b == 128 ? TILE_128x64 : TILE_64x64;
 }
 
