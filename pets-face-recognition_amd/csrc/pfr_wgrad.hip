@@ -458,6 +458,8 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
 static void wgrad_tiles(int Cout, int KK, int* bp, int* bq) {
   *bp = Cout >= 128 ? 128 : 64;
   *bq = KK >= 128 ? 128 : 64;
+  static const int forced = getenv("PFR_WGRAD_TILE") ? atoi(getenv("PFR_WGRAD_TILE")) : -1;   // tuning: tools/tile_sweep.py
+  if (forced >= 0) { *bp = (forced & 1) ? 64 : 128; *bq = (forced & 2) ? 64 : 128; }
 }
 
 // number of m-splits the launcher uses (the caller sizes the workspace as splits*Cout*KK floats)

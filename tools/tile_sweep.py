@@ -5,11 +5,19 @@ Prints, per geometry, the cold time of every tile variant and of the built-in he
 import sys, os, re, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TILES = {-1: "heur", 0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64", 4: "256x256", 5: "256x128"}
+WTILES = {-1: "heur", 0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64"}   # (Cout tile) x (K-column tile)
+WGRAD = len(sys.argv) > 2 and "--wgrad" in sys.argv[2:]
 
 
 def shapes(path):
     out = []
     for r in json.load(open(path)):
+        if WGRAD:
+            m = re.match(r"wgrad N(\d+) H(\d+) W(\d+) C(\d+) Co(\d+) R(\d+) s(\d+) OH(\d+) pro0", r["op"])
+            if m and r["ms_per_step"] > 0.05:
+                g = [int(v) for v in m.groups()]
+                out.append((g[0], g[1], g[2], g[3], g[4], g[5], g[6], 0, g[7], r["launches_per_step"]))
+            continue
         m = re.match(r"fwd N(\d+) H(\d+) W(\d+) C(\d+) Co(\d+) R(\d+) s(\d+) dil(\d+) OH(\d+) pro0", r["op"])
         if m and r["ms_per_step"] > 0.05:
             out.append(tuple(int(v) for v in m.groups()) + (r["launches_per_step"],))
@@ -28,28 +36,37 @@ def worker(path):
         x = torch.randn(N, H, W, C, device="cuda").bfloat16()
         w = (torch.randn(Co, R, R, C, device="cuda") / (C * R * R) ** 0.5).bfloat16()
         pad = {1: 0, 3: 1, 7: 3}[R]
-        kw = dict(stride=s, pad=pad, idil_log2=dil, out_hw=(OH, OH), stats=(dil == 0))
-        y, part = ops.conv2d_fwd(x, w, **kw)
         t = 0.0
+        if WGRAD:
+            dy = torch.randn(N, OH, OH, Co, device="cuda").bfloat16()
+            ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
+            out = ops.conv2d_wgrad(x, dy, R, R, s, pad, workspace=ws)
+            run = lambda: ops.conv2d_wgrad(x, dy, R, R, s, pad, out=out, workspace=ws)
+        else:
+            kw = dict(stride=s, pad=pad, idil_log2=dil, out_hw=(OH, OH), stats=(dil == 0))
+            y, part = ops.conv2d_fwd(x, w, **kw)
+            run = lambda: ops.conv2d_fwd(x, w, out=y, stats_buf=part, **kw)
         for _ in range(4):
             big.add_(1.0)
             a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-            a.record(); ops.conv2d_fwd(x, w, out=y, stats_buf=part, **kw); b.record()
+            a.record(); run(); b.record()
             torch.cuda.synchronize(); t += a.elapsed_time(b) / 4
         res[f"H{H} C{C} Co{Co} R{R} s{s} dil{dil} x{n}"] = t * 1e3
     print("RESULT " + json.dumps(res))
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "--worker":
+    if "--worker" in sys.argv[2:]:
         worker(sys.argv[1])
         sys.exit(0)
     table = {}
-    for tid, name in TILES.items():
+    tiles = WTILES if WGRAD else TILES
+    for tid, name in tiles.items():
         env = dict(os.environ)
         if tid >= 0:
-            env["PFR_IGEMM_TILE"] = str(tid)
-        o = subprocess.run([sys.executable, __file__, sys.argv[1], "--worker"], env=env, capture_output=True, text=True).stdout
+            env["PFR_WGRAD_TILE" if WGRAD else "PFR_IGEMM_TILE"] = str(tid)
+        o = subprocess.run([sys.executable, __file__, sys.argv[1], "--worker"] + (["--wgrad"] if WGRAD else []), env=env,
+                           capture_output=True, text=True).stdout
         line = [l for l in o.splitlines() if l.startswith("RESULT ")]
         if line:
             for k, v in json.loads(line[0][7:]).items():
@@ -59,5 +76,5 @@ if __name__ == "__main__":
         n = int(k.split("x")[-1])
         best = min((v, t) for t, v in row.items() if t != "heur")
         tot_h += row["heur"] * n; tot_b += best[0] * n
-        print(f"{k:34s} " + " ".join(f"{t}:{row.get(t, float('nan')):7.1f}" for t in TILES.values()) + f"   best {best[1]} ({row['heur'] / best[0]:.2f}x)")
+        print(f"{k:34s} " + " ".join(f"{t}:{row.get(t, float('nan')):7.1f}" for t in tiles.values()) + f"   best {best[1]} ({row['heur'] / best[0]:.2f}x)")
     print(f"per step: heuristic {tot_h / 1e3:.3f} ms, best-per-layer {tot_b / 1e3:.3f} ms")
