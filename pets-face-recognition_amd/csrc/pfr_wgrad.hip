@@ -472,7 +472,8 @@ extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   if (want > maxs) want = maxs;
   // the fp32 partial slabs are written and re-read once: keep them well below the activation traffic of the layer
   const long slab = (long)Cout * KK * 4;
-  const long cap = (24L << 20) / slab;
+  static const long slab_mb = getenv("PFR_WGRAD_SLAB_MB") ? atol(getenv("PFR_WGRAD_SLAB_MB")) : 24;
+  const long cap = (slab_mb << 20) / slab;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   return (int)want;

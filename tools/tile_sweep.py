@@ -39,7 +39,7 @@ def worker(path):
         t = 0.0
         if WGRAD:
             dy = torch.randn(N, OH, OH, Co, device="cuda").bfloat16()
-            ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
+            ws = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda")
             out = ops.conv2d_wgrad(x, dy, R, R, s, pad, workspace=ws)
             run = lambda: ops.conv2d_wgrad(x, dy, R, R, s, pad, out=out, workspace=ws)
         else:
