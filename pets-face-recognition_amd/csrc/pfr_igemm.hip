@@ -584,6 +584,9 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
 // (K = 64 … 256) run better with 64-byte rows and more resident workgroups.
 template <typename T, typename TO, int BQ, int BP>
 static int launch_tile(IgemmParams& p, hipStream_t st) {
+  static const int kch = getenv("PFR_IGEMM_KCH") ? atoi(getenv("PFR_IGEMM_KCH")) : 0;   // tuning: force 64-/128-byte k-steps
+  if (kch == 4) return launch_tile_k<T, TO, BQ, BP, 4, 4, 2>(p, st);
+  if (kch == 8 && p.C % (8 * DT<T>::KPACK) == 0) return launch_tile_k<T, TO, BQ, BP, 8, 4, 2>(p, st);
   if (p.K >= 512 && p.C % (8 * DT<T>::KPACK) == 0) return launch_tile_k<T, TO, BQ, BP, 8, 4, 2>(p, st);
   return launch_tile_k<T, TO, BQ, BP, 4, 4, 2>(p, st);
 }
