@@ -31,6 +31,12 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROA
 PEAK_HBM_GBS = 8000.0
 
 
+# every C-ABI entry point whose launches execute the FLOPs counted by conv_flops_per_img (conv / Linear forward, data and
+# weight gradients incl. the fused-epilogue variants, windowed attention)
+CONV_FAMILY = ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_conv2d_dgrad_join", "pfr_gemm_act", "pfr_window_attn_fwd",
+               "pfr_window_attn_bwd")
+
+
 def conv_flops_per_img(arch):
     if arch in SWIN_GMAC:
         return 2.0 * 3.0 * SWIN_GMAC[arch] * 1e9
@@ -205,8 +211,7 @@ def main():
             with open(args.detail, "w") as f:
                 json.dump([{"op": k, "launches_per_step": n, "ms_per_step": round(ms_, 4),
                             "tflops": round(fl * n / (ms_ * 1e-3) / 1e12, 1) if fl else None} for k, n, ms_, fl in rows], f, indent=1)
-        conv_ms = sum(v[1] for k, v in summ.items() if k in ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_window_attn_fwd",
-                                                             "pfr_window_attn_bwd")) / nprof
+        conv_ms = sum(v[1] for k, v in summ.items() if k in CONV_FAMILY) / nprof
         total_ms = sum(v[1] for v in summ.values()) / nprof
         flops = conv_flops_per_img(args.arch) * args.batch
         ach = flops / (conv_ms * 1e-3) / 1e12
