@@ -85,6 +85,7 @@ class FEEngine:
         self.side_events = []
         self.fold_eval = os.environ.get("PFR_FOLD_BN", "1") != "0"   # inference: BN folded into the convs
         self.fold_w = None
+        self.graph_eval = os.environ.get("PFR_GRAPH_EVAL", "0") == "1"   # opt-in: inference plans replayed as hipGraphs
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
@@ -693,6 +694,8 @@ class FEEngine:
         plan = self.get_plan(N, H, W, train, with_backward)
         if with_backward and plan.meta.get("ws_ptr", 0) != (self.ws.data_ptr() if self.ws is not None else 0):
             self._finalize_plan(plan)
+        if plan.meta.get("folded") and self.graph_eval and _TRACER[0] is None:
+            return self._forward_graphed(plan, x)
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh_weights(stream, for_backward=with_backward)
         if plan.meta.get("folded"):
@@ -704,6 +707,43 @@ class FEEngine:
             self.nbt.add_(1)
         self._last_plan = plan
         return plan.meta["emb"]
+
+    def _eval_launches(self, plan, xin):
+        """weight refresh + BN fold + input layout + every launch of the inference plan, on the current stream"""
+        N, _, H, W = xin.shape
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh_weights(stream, for_backward=False)
+        lib.pfr_fold_bn(self.fold_desc.data_ptr(), self.fold_n, self.did, stream)
+        lib.pfr_nchw_to_nhwc(xin.data_ptr(), plan.meta["x_nhwc"].data_ptr(), self.did, N, xin.shape[1], H, W, self.cp, stream)
+        for fn, args in plan.meta["fwd"]:
+            fn(*args, stream)
+
+    def _forward_graphed(self, plan, x):
+        """Opt-in (PFR_GRAPH_EVAL=1): the inference plan replayed as ONE hipGraph, captured on the second call (the first
+        runs eagerly and warms every kernel up); pointers are fixed (the input is copied into a static buffer) and the
+        weights are re-read from the master buffer inside the graph, so optimizer steps / checkpoint loads between calls
+        are honoured.  Measured: no gain — 1.38 ms per batch of 20 and 0.96 ms per single image either way, because the
+        ~60 dependent launches are bound by their own k-loop latency, not by the 4 µs host cost of a launch."""
+        m = plan.meta
+        if "x_in" not in m:
+            m["x_in"] = torch.empty_like(x)
+        xin = m["x_in"]
+        xin.copy_(x)
+        g = m.get("graph")
+        if g is None:
+            if m.get("warm", 0) < 1:
+                m["warm"] = 1
+                self._eval_launches(plan, xin)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._eval_launches(plan, xin)
+                m["graph"] = g
+                g.replay()
+        else:
+            g.replay()
+        self._last_plan = plan
+        return m["emb"]
 
     def backward(self, demb):
         plan = self._last_plan

@@ -197,3 +197,25 @@ def test_train_trace_r18_vs_reference_golden():
     # after 5 ill-conditioned steps (see test_backbone_fwd_bwd_vs_oracle) the weights agree to a few per cent
     assert rel(got["bn1.running_mean"], torch.tensor(G["rm_bn1"])) < 0.15
     assert rel(got["fc.bias"], torch.tensor(G["fc_bias_final"])) < 0.15
+
+
+def test_inference_plan_graph_replay_matches_eager():
+    """PFR_GRAPH_EVAL: the BN-folded inference plan captured into a hipGraph gives the eager result, also after the weights
+    changed between replays."""
+    from oracle import resnet_ref
+    sd = resnet_ref.init_state_dict("resnet18", 512, seed=5)
+    m = build("resnet18", torch.float32, sd).eval()
+    x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+    with torch.no_grad():
+        ref = m(x).clone()
+        eng = m.hip_engine()
+        eng.graph_eval = True
+        a = m(x).clone()     # warm (eager)
+        b = m(x).clone()     # capture + replay
+        c = m(x).clone()     # replay
+        assert any("graph" in p.meta for p in eng.plans.values())
+        assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)
+        m.fc.weight.mul_(2.0)
+        m.fc.bias.mul_(2.0)
+        d = m(x).clone()
+        assert rel(d, 2.0 * ref) < 1e-6
