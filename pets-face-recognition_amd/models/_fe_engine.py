@@ -745,17 +745,9 @@ class FEEngine:
         self._last_plan = plan
         return m["emb"]
 
-    def backward(self, demb):
-        plan = self._last_plan
-        stream = torch.cuda.current_stream().cuda_stream
-        demb = demb.contiguous()
-        lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan.meta["demb"].data_ptr(), self.did, demb.numel(), stream)
-        acc = 1 if self.first_param.grad is not None else 0
-        hook = self.grad_ready_hook
+    def _run_bwd_ops(self, plan, acc, hook):
         main = torch.cuda.current_stream()
-        if self.wt_pending:
-            main.wait_event(self.wt_ready)
-            self.wt_pending = False
+        stream = main.cuda_stream
         use_side = self._side_ok()
         if use_side:
             if self.side is None:
@@ -784,6 +776,19 @@ class FEEngine:
                     main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)
+
+    def backward(self, demb):
+        plan = self._last_plan
+        stream = torch.cuda.current_stream().cuda_stream
+        demb = demb.contiguous()
+        lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan.meta["demb"].data_ptr(), self.did, demb.numel(), stream)
+        acc = 1 if self.first_param.grad is not None else 0
+        hook = self.grad_ready_hook
+        main = torch.cuda.current_stream()
+        if self.wt_pending:
+            main.wait_event(self.wt_ready)
+            self.wt_pending = False
+        self._run_bwd_ops(plan, acc, hook)
         if not acc:
             self.attach_grads()
 
