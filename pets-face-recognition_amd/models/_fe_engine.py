@@ -40,7 +40,7 @@ class _BN:
 
 
 # op codes of the backward list besides plain (ctypes function, args) launches on the main stream
-_SIDE, _FORK, _SREC, _WAIT = 1, 2, 3, 4
+_SIDE, _FORK, _SREC, _WAIT, _MWAIT = 1, 2, 3, 4, 5   # _MWAIT: a wait that only a grad-ready hook (DDP bucket) needs
 
 
 def _side_with_ddp():
@@ -636,7 +636,8 @@ class FEEngine:
         # gradients of flat offsets >= off are final once main has also seen the side stream's latest wgrad
         last = max((a[0] for f, a in ops if f == "srec"), default=None)
         if last is not None:
-            ops.append(("wait", (last,)))
+            # off == 0 is the end of the backward pass: always joined.  Intermediate marks only matter to a bucket hook.
+            ops.append(("wait" if off == 0 else "mwait", (last,)))
         ops.append((None, (off,)))
 
     # ------------------------------------------------------------------------------------------ execution
@@ -673,6 +674,8 @@ class FEEngine:
                     res.append((_SREC, args[0]))
                 elif fn == "wait":
                     res.append((_WAIT, args[0]))
+                elif fn == "mwait":
+                    res.append((_MWAIT, args[0]))
                 elif fn == "colsum":
                     res.append((lib.pfr_colsum, tuple(args[:-1]) + (acc, 0)))
                 elif fn == "copy2d":
@@ -772,7 +775,7 @@ class FEEngine:
                     side.wait_event(e)
                 elif fn == _SREC:
                     ev[2 * args + 1].record(side)
-                else:
+                elif fn == _WAIT or hook is not None:
                     main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)

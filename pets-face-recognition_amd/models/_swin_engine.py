@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .._hip import lib, dtype_id, PfrError
 from .._hip.lib import _TRACER
-from ._fe_engine import default_compute_dtype, _ALIGN, _SIDE, _FORK, _SREC, _WAIT, _side_with_ddp
+from ._fe_engine import default_compute_dtype, _ALIGN, _SIDE, _FORK, _SREC, _WAIT, _MWAIT, _side_with_ddp
 
 
 class _Lin:
@@ -415,8 +415,8 @@ class SwinEngine:
                                                  f - 1, {2: 1, 4: 2}[f], Hi, Wi, Ci, 0, 0, 0, 0, 0, 0, 0, 0)))
                 release(dz)
                 dz = din
-            if nside[0]:
-                bwd.append(("wait", (nside[0] - 1,)))   # everything the side stream was given so far is final
+            if nside[0]:   # everything the side stream was given so far is final (end of backward, or a DDP bucket boundary)
+                bwd.append(("wait" if si == 0 else "mwait", (nside[0] - 1,)))
             bwd.append((None, (st["off"],)))
         plan["n_side"] = nside[0]
         if self.ws is None or self.ws.numel() < ws_need[0]:
@@ -443,6 +443,8 @@ class SwinEngine:
                 res.append((_SREC, args[0]))
             elif fn == "wait":
                 res.append((_WAIT, args[0]))
+            elif fn == "mwait":
+                res.append((_MWAIT, args[0]))
             else:
                 res.append((fn, args))
         plan["bwd"] = res
@@ -511,7 +513,7 @@ class SwinEngine:
                     side.wait_event(e)
                 elif fn == _SREC:
                     ev[2 * args + 1].record(side)
-                else:
+                elif fn == _WAIT or hook is not None:
                     main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)
