@@ -128,6 +128,9 @@ int pfr_avgpool_fwd(const void* x, void* y, int dtype, int N, int HW, int C, pfr
 int pfr_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int HW, int C, pfr_stream_t stream);
 
 /* ---- ArcFace / CosFace head + (focal) cross-entropy (losses/large_margin.py:30-40,69-84; losses/losses.py:22-28) */
+/* y [cols][rows] = transpose of x [rows][cols] (the head's data gradient runs as a split-K GEMM over the class dimension:
+ * autograd of F.linear in losses/large_margin.py:71, see losses/_head_hip.py) */
+int pfr_transpose2d(const void* x, void* y, int dtype, int rows, int cols, pfr_stream_t stream);
 /* match preparation (F.normalize of query / gallery embeddings, engine/controller.py:77-90 via similarity_f): one pass
  * over fp32 rows writes the L2-normalised row in bf16 (GEMM operand) and / or fp32 (exact re-scoring operand) */
 int pfr_l2norm_dual(const float* x, void* xn_bf16, float* xn_f32, float* inv_norm, int rows, int D, float eps,

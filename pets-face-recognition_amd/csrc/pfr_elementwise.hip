@@ -674,6 +674,27 @@ extern "C" int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x
   return PFR_OK;
 }
 
+// y[c][r] = x[r][c]  (row-major [rows][cols] → [cols][rows]); 64x64 tiles through LDS, 2- or 4-byte elements
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const T* __restrict__ x, T* __restrict__ y, int rows, int cols) {
+  __shared__ T tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = x[(size_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (c0 + i < cols && r0 + tx < rows) y[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+extern "C" int pfr_transpose2d(const void* x, void* y, int dtype, int rows, int cols, hipStream_t st) {
+  PFR_CHECK_ARG(x && y && rows > 0 && cols > 0, "pfr_transpose2d: bad args");
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dtype == PFR_BF16) hipLaunchKernelGGL(transpose2d_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, cols);
+  else hipLaunchKernelGGL(transpose2d_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, rows, cols);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 // elementwise y = a + b (gradient joins of the residual graph)
 template <typename T>
 __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t nchunks) {

@@ -19,20 +19,31 @@ def _cosine_fwd(emb, weight, T):
     C = weight.shape[0]
     Cp = _cpad(C, T)
     xn, _, inv_x = ops.l2norm_fwd(emb, T)
-    wn, wnT, inv_w = ops.l2norm_fwd(weight, T, want_t=True, ldt=Cp)
+    wn_full = torch.zeros((Cp, D), dtype=T, device=emb.device) if Cp != C else torch.empty((C, D), dtype=T, device=emb.device)
+    wn, wnT, inv_w = ops.l2norm_fwd(weight, T, want_t=True, ldt=Cp, xn=wn_full[:C])
     cos = torch.empty((B, 1, 1, Cp), dtype=torch.float32, device=emb.device)
     ops.conv2d_fwd(xn.view(B, 1, 1, D), wn.view(C, 1, 1, D), out=cos)
-    return cos.view(B, Cp), (xn, wnT, inv_x, inv_w)
+    return cos.view(B, Cp), (xn, wnT, inv_x, inv_w, wn_full)
 
 
 def _cosine_bwd(dcos, emb, weight, saved, T):
     """dcos [B, Cpad] (compute dtype) → (demb f32 [B,D], dweight f32 [C,D])"""
-    xn, wnT, inv_x, inv_w = saved
+    xn, wnT, inv_x, inv_w, wn_full = saved
     B, D = emb.shape
     C = weight.shape[0]
     Cp = dcos.shape[1]
-    dxn = torch.empty((B, 1, 1, D), dtype=torch.float32, device=emb.device)
-    ops.conv2d_fwd(dcos.view(B, 1, 1, Cp), wnT.view(D, 1, 1, Cp), out=dxn)
+    kp = 8 if T == torch.bfloat16 else 4
+    if B % kp == 0 and Cp >= 2048:
+        # dxn[b][d] = Σ_c dcos[b][c]·wn[c][d]: the reduction runs over the CLASS dimension (10 000), the output is only B x D —
+        # as a plain GEMM that is 8-16 tiles with a 10 000-long k-loop (0.2 ms on 8 CUs); as a "weight gradient" over the rows
+        # of (wn, dcosᵀ) it is split over ~40 row ranges and takes ~20 µs
+        from .._hip import lib, dtype_id
+        dcosT = torch.empty((Cp, B), dtype=dcos.dtype, device=dcos.device)
+        lib.pfr_transpose2d(dcos.data_ptr(), dcosT.data_ptr(), dtype_id(dcos.dtype), B, Cp, torch.cuda.current_stream().cuda_stream)
+        dxn = ops.conv2d_wgrad(wn_full.view(Cp, 1, 1, D), dcosT.view(Cp, 1, 1, B), 1, 1, 1, 0)   # [B,1,1,D] f32
+    else:
+        dxn = torch.empty((B, 1, 1, D), dtype=torch.float32, device=emb.device)
+        ops.conv2d_fwd(dcos.view(B, 1, 1, Cp), wnT.view(D, 1, 1, Cp), out=dxn)
     dwn = ops.conv2d_wgrad(xn.view(B, 1, 1, D), dcos.view(B, 1, 1, Cp), 1, 1, 1, 0)  # [Cp,1,1,D] f32
     demb = ops.l2norm_bwd(emb, inv_x, dxn.view(B, D), torch.float32)
     dw = ops.l2norm_bwd(weight, inv_w, dwn.view(Cp, D), torch.float32, out=torch.empty_like(weight))

@@ -219,3 +219,28 @@ def test_inference_plan_graph_replay_matches_eager():
         m.fc.bias.mul_(2.0)
         d = m(x).clone()
         assert rel(d, 2.0 * ref) < 1e-6
+
+
+def test_fused_head_large_class_count_split_dgrad():
+    """C = 4096 ids: the head's data gradient runs as a split reduction over the class dimension (transpose + weight-gradient
+    kernel); loss and both gradients must match the CPU (reference-formula) path."""
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    g = torch.Generator().manual_seed(31)
+    B, C = 16, 4096
+    x = torch.randn(B, 512, generator=g)
+    label = torch.randint(0, C, (B,), generator=g)
+    ref = SoftmaxBasedMetricLearning(torch.nn.Identity(), C, 512, is_focal=True, arc_margin=True)
+    hip = SoftmaxBasedMetricLearning(torch.nn.Identity(), C, 512, is_focal=True, arc_margin=True)
+    hip.load_state_dict(ref.state_dict())
+    hip.add_margin.compute_dtype = torch.float32
+    hip = hip.to(DEV)
+    xr = x.clone().requires_grad_(True)
+    lr = ref(xr, label)["loss"]
+    lr.backward()
+    xh = x.to(DEV).requires_grad_(True)
+    lh = hip(xh, label.to(DEV))["loss"]
+    lh.backward()
+    torch.cuda.synchronize()
+    assert abs(lh.item() - lr.item()) < 1e-4 * abs(lr.item())
+    assert rel(xh.grad, xr.grad) < 1e-4
+    assert rel(hip.add_margin.weight.grad, ref.add_margin.weight.grad) < 1e-4
