@@ -430,8 +430,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, c
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t off = (r + u * step) * C + cglob * KP;
-      v1[u] = ld16(x1 + off);
-      if (x2) v2[u] = ld16(x2 + off);
+      v1[u] = ld16_nt(x1 + off);   // the conv output is not needed again before the backward pass
+      if (x2) v2[u] = ld16_nt(x2 + off);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) body(v1[u], v2[u], r + u * step);
@@ -643,8 +643,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t off = (r + u * step) * C + cglob * KP;
-      vg[u] = ld16(dout + off);
-      vx[u] = ld16(x + off);
+      vg[u] = ld16_nt(dout + off);
+      vx[u] = ld16_nt(x + off);
       if (mask_mode == 1) vo[u] = ld16(out + off);
       if (mask_mode == 3) bits[u] = mk[(r + u * step) * cpr + cglob];
     }
