@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
     for (int k = 0; k < CPL; ++k) {
       if (okc[k]) {
         const size_t off = (size_t)row * C + (sub + G * k) * KP;
-        Chunk<T>::unpack(ld16(x + off), xh[k]);
-        Chunk<T>::unpack(ld16(dy + off), dv[k]);
+        Chunk<T>::unpack(ld16_nt(x + off), xh[k]);   // last uses of the saved activation and of dy
+        Chunk<T>::unpack(ld16_nt(dy + off), dv[k]);
       }
 #pragma unroll
       for (int e = 0; e < KP; ++e) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
       if (okc[k]) {
         const size_t off = (size_t)row * C + (sub + G * k) * KP;
         float r[KP], o[KP];
-        if (dres) Chunk<T>::unpack(ld16(dres + off), r);
+        if (dres) Chunk<T>::unpack(ld16_nt(dres + off), r);
 #pragma unroll
         for (int e = 0; e < KP; ++e) {
           float v = rs * (dv[k][e] * gm[k][e] - a - xh[k][e] * b);
