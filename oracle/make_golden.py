@@ -8,6 +8,8 @@ this script are committed.  What is imported / executed from the reference:
   engine/controller.py  Controller.test_epoch_end                (with sys.modules stubs for pytorch_lightning /
                                                                   torchmetrics, which are not installed)
   configs/dog_fe/fe_dogs_config.py  similarity_f                 (that one function, extracted with ast)
+The ResNet backbone is third-party to the reference (torchvision, not installable here); `resnet_hf.npz` pins its
+restatement against the independent implementation in Hugging Face transformers (`python oracle/make_golden.py resnet_hf`).
 """
 import ast
 import contextlib
@@ -243,10 +245,81 @@ def gen_train_trace(L):
     print("train_trace_r18.npz: losses", [round(v, 5) for v in losses])
 
 
+def hf_resnet(arch, sd):
+    """the state dict `sd` (torchvision names) loaded into Hugging Face transformers' ResNetModel"""
+    from transformers import ResNetConfig, ResNetModel
+    if arch == "resnet50":
+        cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048], depths=[3, 4, 6, 3],
+                           layer_type="bottleneck", hidden_act="relu", downsample_in_first_stage=False,
+                           downsample_in_bottleneck=False)
+        nconv = 3
+    else:
+        cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[64, 128, 256, 512], depths=[2, 2, 2, 2],
+                           layer_type="basic", hidden_act="relu", downsample_in_first_stage=False)
+        nconv = 2
+    hf = ResNetModel(cfg)
+    new = {}
+
+    def put(dst, src_conv, src_bn):
+        new[dst + ".convolution.weight"] = sd[src_conv + ".weight"]
+        for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            new[dst + ".normalization." + k] = sd[src_bn + "." + k]
+
+    put("embedder.embedder", "conv1", "bn1")
+    for Lx, depth in enumerate(cfg.depths):
+        for b in range(depth):
+            tv, h = f"layer{Lx + 1}.{b}", f"encoder.stages.{Lx}.layers.{b}"
+            for i in range(nconv):
+                put(f"{h}.layer.{i}", f"{tv}.conv{i + 1}", f"{tv}.bn{i + 1}")
+            if f"{tv}.downsample.0.weight" in sd:
+                put(f"{h}.shortcut", f"{tv}.downsample.0", f"{tv}.downsample.1")
+    hf.load_state_dict(new, strict=True)
+    return hf
+
+
+def resnet_hf_inputs(arch):
+    """seeded weights (non-trivial running statistics) + input of the ResNet cross-check fixture"""
+    sd = resnet_ref.init_state_dict(arch, 512, seed=4)
+    g = torch.Generator().manual_seed(9)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    x = torch.rand(3, 3, 96, 96, generator=g)
+    return sd, x
+
+
+def gen_resnet_hf():
+    """torchvision (the reference's backbone provider) cannot be installed here; Hugging Face transformers ships an
+    independent implementation of the same published architecture (ResNet v1.5).  Its outputs for seeded weights — which the
+    restatement regenerates from the seed — pin the backbone oracle: eval mode, train mode, updated running statistics."""
+    out = {}
+    for arch in ("resnet18", "resnet50"):
+        sd, x = resnet_hf_inputs(arch)
+        hf = hf_resnet(arch, sd)
+        for train in (False, True):
+            hf.train(train)
+            with torch.no_grad():
+                pooled = hf(x).pooler_output.flatten(1)
+                emb = pooled @ sd["fc.weight"].t() + sd["fc.bias"]
+            ref = resnet_ref.forward(sd, x, arch, train=train)
+            assert torch.allclose(ref, emb, rtol=2e-4, atol=2e-5), (arch, train)
+            out[f"{arch}_{'train' if train else 'eval'}_emb"] = emb.numpy()
+            out[f"{arch}_{'train' if train else 'eval'}_pooled"] = pooled.numpy()
+        out[f"{arch}_bn1_running_mean_after"] = hf.state_dict()["embedder.embedder.normalization.running_mean"].numpy()
+    np.savez_compressed(os.path.join(OUT, "resnet_hf.npz"), **out)
+    print("resnet_hf.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "resnet_hf":
+        gen_resnet_hf()
+        sys.exit(0)
     L = ref_losses()
     gen_arcface(L)
     gen_recall(ref_controller(), ref_similarity_f())
     gen_swin()
     gen_train_trace(L)
+    gen_resnet_hf()

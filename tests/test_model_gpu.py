@@ -244,3 +244,20 @@ def test_fused_head_large_class_count_split_dgrad():
     assert abs(lh.item() - lr.item()) < 1e-4 * abs(lr.item())
     assert rel(xh.grad, xr.grad) < 1e-4
     assert rel(hip.add_margin.weight.grad, ref.add_margin.weight.grad) < 1e-4
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_hip_backbone_vs_independent_resnet_fixture(arch):
+    """fp32 HIP path vs tests/golden/resnet_hf.npz — embeddings an independent third-party ResNet v1.5 implementation
+    (Hugging Face transformers) produced for the same seeded weights: eval mode (BN folded into the convs) and train mode
+    (batch statistics), within the 1e-3 relative bound of north_star."""
+    from oracle.make_golden import resnet_hf_inputs
+    G = np.load(os.path.join(GOLD, "resnet_hf.npz"))
+    sd, x = resnet_hf_inputs(arch)
+    m = build(arch, torch.float32, sd)
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        with torch.no_grad():
+            emb = m(x.to(DEV))
+        e = rel(emb, torch.tensor(G[f"{arch}_{mode}_emb"]))
+        assert e < 1e-3, (arch, mode, e)

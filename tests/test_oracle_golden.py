@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -113,3 +114,101 @@ def test_resnet_restatement_self_checks():
     got = m(x)
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5)
     assert torch.allclose(m.bn1.running_mean, new["bn1.running_mean"], atol=1e-6)
+
+
+def _hf_resnet(arch, sd):
+    """The same weights loaded into Hugging Face transformers' ResNetModel — an independent third-party implementation of
+    the published ResNet v1.5 architecture (the one torchvision.models.resnet* implements; stride on the 3x3 conv)."""
+    from transformers import ResNetConfig, ResNetModel
+    if arch == "resnet50":
+        cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048], depths=[3, 4, 6, 3],
+                           layer_type="bottleneck", hidden_act="relu", downsample_in_first_stage=False,
+                           downsample_in_bottleneck=False)
+        nconv = 3
+    else:
+        cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[64, 128, 256, 512], depths=[2, 2, 2, 2],
+                           layer_type="basic", hidden_act="relu", downsample_in_first_stage=False)
+        nconv = 2
+    hf = ResNetModel(cfg)
+    new = {}
+
+    def put(dst, src_conv, src_bn):
+        new[dst + ".convolution.weight"] = sd[src_conv + ".weight"]
+        for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            new[dst + ".normalization." + k] = sd[src_bn + "." + k]
+
+    put("embedder.embedder", "conv1", "bn1")
+    for L, depth in enumerate(cfg.depths):
+        for b in range(depth):
+            tv, h = f"layer{L + 1}.{b}", f"encoder.stages.{L}.layers.{b}"
+            for i in range(nconv):
+                put(f"{h}.layer.{i}", f"{tv}.conv{i + 1}", f"{tv}.bn{i + 1}")
+            if f"{tv}.downsample.0.weight" in sd:
+                put(f"{h}.shortcut", f"{tv}.downsample.0", f"{tv}.downsample.1")
+    missing, unexpected = hf.load_state_dict(new, strict=True), None
+    return hf
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_resnet_restatement_matches_hf_transformers_resnet(arch):
+    """torchvision is not installable here, so the restated backbone is additionally cross-checked against the ResNet of
+    Hugging Face transformers (installed in this image): same seeded weights → same pooled features → same embedding,
+    in eval mode and in train mode (batch statistics + running-statistics update)."""
+    pytest.importorskip("transformers")
+    from oracle import resnet_ref
+    import pets_face_recognition_amd.models as M
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = resnet_ref.init_state_dict(arch, 512, seed=4)
+    g = torch.Generator().manual_seed(9)
+    for k in list(sd):                       # non-trivial running statistics for the eval-mode comparison
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    x = torch.rand(3, 3, 96, 96, generator=g)
+    hf = _hf_resnet(arch, sd)
+    prod = getattr(M, arch)()
+    prod.fc = torch.nn.Linear(prod.fc.in_features, 512)
+    prod.load_state_dict(sd)
+    for train in (False, True):
+        hf.train(train)
+        prod.train(train)
+        new = {}
+        with torch.no_grad():
+            pooled = hf(x).pooler_output.flatten(1)
+            emb_hf = pooled @ sd["fc.weight"].t() + sd["fc.bias"]
+            emb_or = resnet_ref.forward(sd, x, arch, train=train, new_stats=new)
+            emb_pr = prod(x)
+        assert torch.allclose(emb_or, emb_hf, rtol=2e-4, atol=2e-5), (arch, train, (emb_or - emb_hf).abs().max())
+        assert torch.allclose(emb_pr, emb_hf, rtol=2e-4, atol=2e-5), (arch, train)
+        if train:
+            h = hf.state_dict()
+            assert torch.allclose(new["bn1.running_mean"], h["embedder.embedder.normalization.running_mean"], atol=1e-6)
+            last = f"layer4.{1 if arch == 'resnet18' else 2}.bn{2 if arch == 'resnet18' else 3}.running_var"
+            hl = f"encoder.stages.3.layers.{1 if arch == 'resnet18' else 2}.layer.{1 if arch == 'resnet18' else 2}.normalization.running_var"
+            assert torch.allclose(new[last], h[hl], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_resnet_restatement_matches_hf_fixture(arch):
+    """tests/golden/resnet_hf.npz (oracle/make_golden.py resnet_hf): embeddings an INDEPENDENT ResNet v1.5 implementation
+    (Hugging Face transformers) produced for seeded weights; the oracle and the product's CPU path regenerate the weights
+    from the seed and must reproduce them — no transformers import needed here."""
+    from oracle import resnet_ref
+    from oracle.make_golden import resnet_hf_inputs
+    import pets_face_recognition_amd.models as M
+    G = np.load(os.path.join(GOLD, "resnet_hf.npz"))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd, x = resnet_hf_inputs(arch)
+    prod = getattr(M, arch)()
+    prod.fc = torch.nn.Linear(prod.fc.in_features, 512)
+    prod.load_state_dict(sd)
+    for mode in ("eval", "train"):
+        want = torch.tensor(G[f"{arch}_{mode}_emb"])
+        new = {}
+        with torch.no_grad():
+            got_o = resnet_ref.forward(sd, x, arch, train=(mode == "train"), new_stats=new)
+            got_p = prod.train(mode == "train")(x)
+        assert torch.allclose(got_o, want, rtol=2e-4, atol=2e-5), (arch, mode)
+        assert torch.allclose(got_p, want, rtol=2e-4, atol=2e-5), (arch, mode)
+    assert torch.allclose(new["bn1.running_mean"], torch.tensor(G[f"{arch}_bn1_running_mean_after"]), atol=1e-6)
