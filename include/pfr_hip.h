@@ -165,7 +165,8 @@ int pfr_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
 int pfr_gelu_fwd(const void* x, void* y, int dtype, size_t n, pfr_stream_t stream);
 int pfr_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, size_t n, pfr_stream_t stream);
 /* bias(+mask) table of one attention block: tab fp32 [4][64][64] (-inf outside w*w x w*w); variant 2*(last window row)+(last window
- * column); built from the (2w-1)x(2w-1) relative-position table `pos`; rebuild whenever pos changed */
+ * column); built from the (2w-1)x(2w-1) relative-position table `pos` (models/swin.py:65-70,93-95,117-118) and the shifted-window
+ * masks (create_mask, models/swin.py:49-62,86-90,122-124); rebuild whenever pos changed */
 long pfr_window_bias_table_floats(int window);
 int pfr_window_bias_table(const float* pos, float* tab, int window, int shift, pfr_stream_t stream);
 /* qkv [B][H][W][3*heads*head_dim] (q|k|v, each (head, d)); pos: the TABLE built by pfr_window_bias_table;
