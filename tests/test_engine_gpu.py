@@ -78,6 +78,14 @@ for arch, hw in (("resnet18", 64), ("swin_t", 224)):
     assert torch.isfinite(a).all() and a.abs().sum() > 0
     assert torch.equal(a, b), (arch, (a - b).abs().max().item())
     print("OK", arch, a.numel())
+# gallery-sharded match over RCCL (one all-gather of the per-rank top-K lists) == unsharded match
+from pets_face_recognition_amd.match import cosine_topk, cosine_topk_sharded
+g = torch.Generator(device="cuda").manual_seed(1)
+q = torch.randn(64, 512, device=dev, generator=g); gal = torch.randn(5000, 512, device=dev, generator=g)
+s0, i0 = cosine_topk(q, gal, 20)
+s1, i1 = cosine_topk_sharded(q, gal, 20, 0)
+assert torch.equal(i0.long(), i1.long()) and torch.equal(s0, s1)
+print("OK sharded match")
 dist.destroy_process_group()
 """
 
@@ -90,4 +98,4 @@ def test_flat_ddp_world1_rccl_path_equals_single_gpu(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "OK resnet18" in r.stdout and "OK swin_t" in r.stdout
+    assert "OK resnet18" in r.stdout and "OK swin_t" in r.stdout and "OK sharded match" in r.stdout
