@@ -128,6 +128,16 @@ int pfr_avgpool_fwd(const void* x, void* y, int dtype, int N, int HW, int C, pfr
 int pfr_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int HW, int C, pfr_stream_t stream);
 
 /* ---- ArcFace / CosFace head + (focal) cross-entropy (losses/large_margin.py:30-40,69-84; losses/losses.py:22-28) */
+/* Space-to-depth form of the ResNet stem `conv1 = Conv2d(3, 64, 7, stride 2, padding 3)` (torchvision resnet, built at
+ * configs/dog_fe/fe_dogs_config.py:102): the same sums as a 4x4 stride-1 pad-2 convolution over the half-resolution image
+ * xs [N][H/2][W/2][Cp], channel (p*2+q)*C + c = x[c][2i+p][2j+q] (H, W even; Cp >= 4*C, zero padded), with weights
+ * ws [Cout][4][4][Cp], ws[a][b][(p*2+q)*C + c] = w[2a+p-1][2b+q-1][c] (zero outside the 7x7 kernel).  Run it through
+ * pfr_conv2d_fwd / pfr_conv2d_wgrad with R = S = 4, stride 1, pad 2, OH = H/2, OW = W/2.
+ *   pfr_s2d_input : x fp32 NCHW -> xs (`dtype`)          pfr_s2d_weight: w fp32 [Cout][7][7][C] -> ws (`dtype`)
+ *   pfr_s2d_wgrad : dws fp32 [Cout][4][4][Cp] -> dw fp32 [Cout][7][7][C] (+= if accumulate) */
+int pfr_s2d_input(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, pfr_stream_t stream);
+int pfr_s2d_weight(const float* w, void* ws, int dtype, int Cout, int C, int Cp, pfr_stream_t stream);
+int pfr_s2d_wgrad(const float* dws, float* dw, int Cout, int C, int Cp, int accumulate, pfr_stream_t stream);
 /* y [cols][rows] = transpose of x [rows][cols] (the head's data gradient runs as a split-K GEMM over the class dimension:
  * autograd of F.linear in losses/large_margin.py:71, see losses/_head_hip.py) */
 int pfr_transpose2d(const void* x, void* y, int dtype, int rows, int cols, pfr_stream_t stream);

@@ -190,6 +190,20 @@ class FEEngine:
         self.cp = (st.Cin + self.kp - 1) // self.kp * self.kp
         st.w_pad = torch.zeros((st.Cout, st.R, st.S, self.cp), dtype=self.dtype, device=dev)
         st.g_pad = torch.zeros((st.Cout, st.R, st.S, self.cp), dtype=torch.float32, device=dev)
+        # space-to-depth form of a 7x7 / stride-2 / pad-3 stem (pfr_s2d_*): 4x4 stride-1 pad-2 conv over [H/2][W/2][cs2d]
+        self.s2d = None
+        # Used on the bf16 (throughput) path.  The fp32 (parity) path keeps the plain 7x7 form: the space-to-depth sums are
+        # just as exact (tests/test_kernels_gpu.py::test_stem_space_to_depth_exact), but their different rounding order moves
+        # a handful of ReLU / max-pool near-ties, which the end-to-end fp32 gradient and loss-trace tests are sensitive to.
+        want = os.environ.get("PFR_STEM_S2D", "auto")
+        if (st.R, st.S, st.stride, st.pad) == (7, 7, 2, 3) and (want == "1" or (want == "auto" and self.dtype == torch.bfloat16)):
+            q = _Conv()
+            q.name = st.name + "(s2d)"
+            q.Cout, q.Cin, q.R, q.S, q.stride, q.pad = st.Cout, (4 * st.Cin + self.kp - 1) // self.kp * self.kp, 4, 4, 1, 2
+            q.w = torch.zeros((q.Cout, 4, 4, q.Cin), dtype=self.dtype, device=dev)
+            q.g = torch.zeros((q.Cout, 4, 4, q.Cin), dtype=torch.float32, device=dev)
+            q.off, q.need_wt = st.off, False
+            self.s2d = q
         self.stem = (st, self._bn_of[id(model.bn1)])
         # blocks
         self.blocks = []
@@ -271,6 +285,9 @@ class FEEngine:
         st = self.stem[0]
         lib.pfr_nchw_to_nhwc(self.master.data_ptr() + 4 * st.off, st.w_pad.data_ptr(), self.did, st.Cout * st.R * st.S,
                              st.Cin, 1, 1, self.cp, stream)
+        if self.s2d is not None:
+            lib.pfr_s2d_weight(self.master.data_ptr() + 4 * st.off, self.s2d.w.data_ptr(), self.did, st.Cout, st.Cin, self.s2d.Cin,
+                               stream)
         if for_backward:
             # the flipped / transposed copies are first needed by the backward pass: build them on the side stream,
             # concurrent with the forward pass (backward() waits for wt_ready)
@@ -291,11 +308,24 @@ class FEEngine:
             if use_side:
                 self.wt_ready.record(self.side)
 
+    def _use_s2d(self, H, W):
+        return self.s2d is not None and H % 2 == 0 and W % 2 == 0
+
+    def _input_layout(self, plan, x, stream):
+        """fp32 NCHW batch of the reference's dataloaders → the stem's operand layout (compute dtype)"""
+        N, C, H, W = x.shape
+        if plan.meta.get("s2d"):
+            lib.pfr_s2d_input(x.data_ptr(), plan.meta["x_nhwc"].data_ptr(), self.did, N, C, H, W, self.s2d.Cin, stream)
+        else:
+            lib.pfr_nchw_to_nhwc(x.data_ptr(), plan.meta["x_nhwc"].data_ptr(), self.did, N, C, H, W, self.cp, stream)
+
     # ------------------------------------------------------------------------------------------ inference (BN folded)
     def _fold_setup(self):
         """Folded-weight buffers + the descriptor table of pfr_fold_bn (one record per conv/BN pair)."""
         import struct
         pairs = [self.stem] + [cb for convs, down in self.blocks for cb in convs] + [down for _, down in self.blocks if down]
+        if self.s2d is not None:
+            pairs.append((self.s2d, self.stem[1]))
         nw = sum((c.w_pad.numel() if c is self.stem[0] else c.w.numel()) for c, _ in pairs)
         nb = sum(c.Cout for c, _ in pairs)
         self.fold_w = torch.empty(nw + _ALIGN * len(pairs), dtype=self.dtype, device=self.device)
@@ -306,6 +336,8 @@ class FEEngine:
         for c, bn in pairs:
             if c is self.stem[0]:
                 src, f32, K = c.w_pad.data_ptr(), 0, c.R * c.S * self.cp   # padded compute-dtype copy (refresh_weights)
+            elif c is self.s2d:
+                src, f32, K = c.w.data_ptr(), 0, c.R * c.S * c.Cin         # space-to-depth copy (refresh_weights)
             else:
                 src, f32, K = self.master.data_ptr() + 4 * c.off, 1, c.R * c.S * c.Cin
             c.wf = self.fold_w[wo:wo + c.Cout * K].view(c.Cout, c.R, c.S, K // (c.R * c.S))
@@ -328,18 +360,23 @@ class FEEngine:
         ops = plan.ops
         st, _ = self.stem
 
-        def conv(x, xshape, c, relu, residual=None):
+        def conv(x, xshape, c, relu, residual=None, out_hw=None):
             Nn, Hh, Ww, C = xshape
-            OH, OW = conv_out_hw(Hh, Ww, c.R, c.S, c.stride, c.pad)
+            OH, OW = out_hw or conv_out_hw(Hh, Ww, c.R, c.S, c.stride, c.pad)
             y = self._A(plan, (Nn, OH, OW, c.Cout))
             ops.append((lib.pfr_conv2d_fwd, (x.data_ptr(), c.wf.data_ptr(), y.data_ptr(), self.did, self.did, Nn, Hh, Ww, C, c.Cout,
                                              c.R, c.S, c.stride, c.pad, 0, OH, OW, c.Cout, c.bf.data_ptr(),
                                              0 if residual is None else residual.data_ptr(), 0, int(relu), 0, 0, 0, 0)))
             return y, (Nn, OH, OW, c.Cout)
 
-        x_nhwc = self._A(plan, (N, H, W, self.cp))
+        if self._use_s2d(H, W):
+            x_nhwc = self._A(plan, (N, H // 2, W // 2, self.s2d.Cin))
+            plan.meta["s2d"] = True
+            c1, s1 = conv(x_nhwc, (N, H // 2, W // 2, self.s2d.Cin), self.s2d, True, out_hw=(H // 2, W // 2))
+        else:
+            x_nhwc = self._A(plan, (N, H, W, self.cp))
+            c1, s1 = conv(x_nhwc, (N, H, W, self.cp), st, True)
         plan.meta["x_nhwc"] = x_nhwc
-        c1, s1 = conv(x_nhwc, (N, H, W, self.cp), st, True)
         _, H1, W1, _ = s1
         PH, PW = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         cur = self._A(plan, (N, PH, PW, st.Cout))
@@ -407,9 +444,9 @@ class FEEngine:
                                                 bn.rv.data_ptr(), float(bn.eps), bn.coef[2].data_ptr(),
                                                 bn.coef[3].data_ptr())))
 
-    def _conv_bn(self, plan, ops, x, xshape, c, bn, train, pro=None, w=None):
+    def _conv_bn(self, plan, ops, x, xshape, c, bn, train, pro=None, w=None, out_hw=None):
         N, H, W, C = xshape
-        OH, OW = conv_out_hw(H, W, c.R, c.S, c.stride, c.pad)
+        OH, OW = out_hw or conv_out_hw(H, W, c.R, c.S, c.stride, c.pad)
         y = self._A(plan, (N, OH, OW, c.Cout))
         part, nt, mt = (None, 0, 0)
         if train:
@@ -423,11 +460,20 @@ class FEEngine:
         ops = plan.ops
         T = self.dtype
         st, stbn = self.stem
-        x_nhwc = self._A(plan, (N, H, W, self.cp))
+        use_s2d = self._use_s2d(H, W)
+        if use_s2d:
+            xin_shape = (N, H // 2, W // 2, self.s2d.Cin)
+            plan.meta["s2d"] = True
+        else:
+            xin_shape = (N, H, W, self.cp)
+        x_nhwc = self._A(plan, xin_shape)
         plan.meta["x_nhwc"] = x_nhwc
         saved = {}
-        # ---- stem: conv 7x7/2 → (BN+ReLU+MaxPool fused)
-        c1, s1 = self._conv_bn(plan, ops, x_nhwc, (N, H, W, self.cp), st, stbn, train, w=st.w_pad)
+        # ---- stem: conv 7x7/2 (space-to-depth form when H, W are even) → (BN+ReLU+MaxPool fused)
+        if use_s2d:
+            c1, s1 = self._conv_bn(plan, ops, x_nhwc, xin_shape, self.s2d, stbn, train, w=self.s2d.w, out_hw=(H // 2, W // 2))
+        else:
+            c1, s1 = self._conv_bn(plan, ops, x_nhwc, xin_shape, st, stbn, train, w=st.w_pad)
         _, H1, W1, _ = s1
         PH, PW = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         pooled = self._A(plan, (N, PH, PW, st.Cout))
@@ -621,9 +667,14 @@ class FEEngine:
         ops.append((lib.pfr_maxpool_bwd, (dcur.data_ptr(), idx.data_ptr(), dz.data_ptr(), self.did, N, s1[1], s1[2], s1[3])))
         release(dcur)
         bn_bwd(dz, None, c1, s1, stbn, 2, dz, None, acc)
-        wgrad(x_nhwc, (N, H, W, self.cp), dz, s1, st, out=st.g_pad)
-        ops.append(("wait", (nside[0] - 1,)))   # the un-padding copy below reads what the stem wgrad wrote
-        ops.append(("copy2d", (st.g_pad.data_ptr(), self.cp, st.g.data_ptr(), st.Cin, st.Cout * st.R * st.S, st.Cin, 1.0, acc)))
+        if use_s2d:
+            wgrad(x_nhwc, xin_shape, dz, s1, self.s2d, out=self.s2d.g)
+            ops.append(("wait", (nside[0] - 1,)))   # the un-packing below reads what the stem wgrad wrote
+            ops.append(("s2dunpack", (self.s2d.g.data_ptr(), st.g.data_ptr(), st.Cout, st.Cin, self.s2d.Cin, acc)))
+        else:
+            wgrad(x_nhwc, xin_shape, dz, s1, st, out=st.g_pad)
+            ops.append(("wait", (nside[0] - 1,)))   # the un-padding copy below reads what the stem wgrad wrote
+            ops.append(("copy2d", (st.g_pad.data_ptr(), self.cp, st.g.data_ptr(), st.Cin, st.Cout * st.R * st.S, st.Cin, 1.0, acc)))
         self._mark(ops, 0)
         plan.meta["n_side"] = nside[0]
         # workspace
@@ -680,6 +731,8 @@ class FEEngine:
                     res.append((lib.pfr_colsum, tuple(args[:-1]) + (acc, 0)))
                 elif fn == "copy2d":
                     res.append((lib.pfr_copy2d_f32, tuple(args[:-1]) + (acc,)))
+                elif fn == "s2dunpack":
+                    res.append((lib.pfr_s2d_wgrad, tuple(args[:-1]) + (acc,)))
                 elif fn is lib.pfr_bn_bwd_finalize:
                     res.append((fn, tuple(args[:-1]) + (acc,)))
                 else:
@@ -703,7 +756,7 @@ class FEEngine:
         self.refresh_weights(stream, for_backward=with_backward)
         if plan.meta.get("folded"):
             lib.pfr_fold_bn(self.fold_desc.data_ptr(), self.fold_n, self.did, stream)
-        lib.pfr_nchw_to_nhwc(x.data_ptr(), plan.meta["x_nhwc"].data_ptr(), self.did, N, x.shape[1], H, W, self.cp, stream)
+        self._input_layout(plan, x, stream)
         for fn, args in plan.meta["fwd"]:
             fn(*args, stream)
         if train:
@@ -717,7 +770,7 @@ class FEEngine:
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh_weights(stream, for_backward=False)
         lib.pfr_fold_bn(self.fold_desc.data_ptr(), self.fold_n, self.did, stream)
-        lib.pfr_nchw_to_nhwc(xin.data_ptr(), plan.meta["x_nhwc"].data_ptr(), self.did, N, xin.shape[1], H, W, self.cp, stream)
+        self._input_layout(plan, xin, stream)
         for fn, args in plan.meta["fwd"]:
             fn(*args, stream)
 

@@ -324,3 +324,47 @@ def test_sgd_and_adamw_steps():
         o.adamw_step(pd, gr.to(DEV), m1, v1, None, 1e-3, 0.9, 0.999, 1e-8, 1e-2, i + 1)
     torch.cuda.synchronize()
     assert torch.allclose(pd.cpu(), pr.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_space_to_depth_exact(dtype):
+    """pfr_s2d_input / pfr_s2d_weight / pfr_s2d_wgrad: the 7x7 / stride-2 / pad-3 stem evaluated as a 4x4 stride-1 pad-2
+    convolution over the space-to-depth image gives the torch result (forward and weight gradient), fp32 to 1e-6."""
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    o = ops()
+    g = torch.Generator().manual_seed(12)
+    N, H, W, C, Co = 4, 64, 48, 3, 64
+    x = torch.rand(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, 7, 7, generator=g) * 0.1
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    if dtype == torch.bfloat16:
+        xr, wr = x.bfloat16().double(), w.bfloat16().double().requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=2, padding=3)
+    dy = torch.randn(y.shape, generator=g).double()
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().double()
+    y.backward(dy)
+    st = torch.cuda.current_stream().cuda_stream
+    kp = 8 if dtype == torch.bfloat16 else 4
+    Cp = (4 * C + kp - 1) // kp * kp
+    xs = torch.empty(N, H // 2, W // 2, Cp, dtype=dtype, device=DEV)
+    xd = x.to(DEV)
+    lib.pfr_s2d_input(xd.data_ptr(), xs.data_ptr(), dtype_id(dtype), N, C, H, W, Cp, st)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ws = torch.empty(Co, 4, 4, Cp, dtype=dtype, device=DEV)
+    lib.pfr_s2d_weight(w_ohwi.data_ptr(), ws.data_ptr(), dtype_id(dtype), Co, C, Cp, st)
+    yh, _ = o.conv2d_fwd(xs, ws, stride=1, pad=2, out_hw=(H // 2, W // 2), out_dtype=torch.float32)
+    dyh = dy.float().permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wsp = torch.empty(lib.pfr_conv2d_wgrad_splits(N * (H // 2) * (W // 2), Co, 16 * Cp) * Co * 16 * Cp, dtype=torch.float32, device=DEV)
+    dws = torch.empty(Co, 4, 4, Cp, dtype=torch.float32, device=DEV)
+    lib.pfr_conv2d_wgrad(xs.data_ptr(), dyh.data_ptr(), dws.data_ptr(), wsp.data_ptr(), dtype_id(dtype), N, H // 2, W // 2, Cp, Co,
+                         4, 4, 1, 2, H // 2, W // 2, Co, 0, 0, 0, 1.0, 0, st)
+    dw = torch.full((Co, 7, 7, C), 7.0, dtype=torch.float32, device=DEV)
+    lib.pfr_s2d_wgrad(dws.data_ptr(), dw.data_ptr(), Co, C, Cp, 0, st)
+    dw2 = dw.clone()
+    lib.pfr_s2d_wgrad(dws.data_ptr(), dw2.data_ptr(), Co, C, Cp, 1, st)       # accumulate
+    torch.cuda.synchronize()
+    t = 1e-6 if dtype == torch.float32 else 1e-5     # bf16 inputs are exactly representable: only the fp32 sum order differs
+    assert rel_err(yh.cpu().double().permute(0, 3, 1, 2), y.detach()) < t
+    assert rel_err(dw.cpu().double(), wr.grad.permute(0, 2, 3, 1)) < t
+    assert torch.allclose(dw2, 2 * dw)
