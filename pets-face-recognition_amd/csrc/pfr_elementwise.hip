@@ -897,29 +897,34 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     float acc[KP];
 #pragma unroll
     for (int e = 0; e < KP; ++e) acc[e] = 0.f;
-    // windows: oh with oh*2-1+r == h, r in 0..2
+    // An input pixel (h, w) belongs to at most 2 x 2 windows: oh ∈ {(h+1)/2 (tap r = h+1-2oh ∈ {0,1}...)}.  Enumerate them
+    // branch-free: window rows oh0 = (h+1)>>1 (tap r0 = h+1-2*oh0 ∈ {0,1}) and oh0-1 (tap r0+2, only if r0 == 0); same for
+    // columns.  All four (clamped) loads are issued before any of them is used.
+    const int oh0 = (h + 1) >> 1, r0 = h + 1 - 2 * oh0, ow0 = (w + 1) >> 1, s0 = w + 1 - 2 * ow0;
+    u32x4 gv[4];
+    uint64_t pk[4];
+    int tap[4];
+    bool ok[4];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int t = h + 1 - r;
-      if (t < 0 || (t & 1)) continue;
-      const int oh = t >> 1;
-      if (oh >= OH) continue;
+    for (int q = 0; q < 4; ++q) {
+      const int dh = q >> 1, dw = q & 1;
+      const int oh = oh0 - dh, ow = ow0 - dw;
+      const int r = r0 + 2 * dh, sx = s0 + 2 * dw;
+      ok[q] = oh >= 0 && oh < OH && ow >= 0 && ow < OW && r < 3 && sx < 3;
+      tap[q] = r * 3 + sx;
+      const int ohc = min(max(oh, 0), OH - 1), owc = min(max(ow, 0), OW - 1);
+      const size_t o = (((size_t)n * OH + ohc) * OW + owc) * cpr + cc;
+      gv[q] = ld16(dy + o * KP);
+      if constexpr (KP == 8) pk[q] = *reinterpret_cast<const uint64_t*>(idx + o * 8);
+      else pk[q] = *reinterpret_cast<const uint32_t*>(idx + o * 4);
+    }
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int u = w + 1 - s;
-        if (u < 0 || (u & 1)) continue;
-        const int ow = u >> 1;
-        if (ow >= OW) continue;
-        const size_t o = (((size_t)n * OH + oh) * OW + ow) * cpr + cc;
-        float g[KP];
-        Chunk<T>::unpack(ld16(dy + o * KP), g);
-        uint64_t pk;
-        if constexpr (KP == 8) pk = *reinterpret_cast<const uint64_t*>(idx + o * 8);
-        else pk = *reinterpret_cast<const uint32_t*>(idx + o * 4);
+    for (int q = 0; q < 4; ++q) {
+      float g[KP];
+      Chunk<T>::unpack(gv[q], g);
 #pragma unroll
-        for (int e = 0; e < KP; ++e)
-          if ((int)((pk >> (8 * e)) & 0xff) == r * 3 + s) acc[e] += g[e];
-      }
+      for (int e = 0; e < KP; ++e)
+        if (ok[q] && (int)((pk[q] >> (8 * e)) & 0xff) == tap[q]) acc[e] += g[e];
     }
     st16(dz + i * KP, Chunk<T>::pack(acc));
   }
