@@ -829,22 +829,28 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
       sc[e] = scale ? scale[cc * KP + e] : 1.f;
       sh[e] = shift ? shift[cc * KP + e] : 0.f;
     }
+    // the nine (clamped) loads are issued before any is consumed; out-of-range taps are skipped by a flag
+    u32x4 tv[9];
+    bool tok[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int t = 0; t < 9; ++t) {
+      const int ih = oh * 2 - 1 + t / 3, iw = ow * 2 - 1 + t % 3;
+      tok[t] = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+      tv[t] = ld16(x + (((size_t)n * H + ihc) * W + iwc) * C + cc * KP);
+    }
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int ih = oh * 2 - 1 + r, iw = ow * 2 - 1 + s;
-        if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
-        float f[KP];
-        Chunk<T>::unpack(ld16(x + (((size_t)n * H + ih) * W + iw) * C + cc * KP), f);
+    for (int t = 0; t < 9; ++t) {
+      float f[KP];
+      Chunk<T>::unpack(tv[t], f);
 #pragma unroll
-        for (int e = 0; e < KP; ++e) {
-          float z = fmaf(f[e], sc[e], sh[e]);
-          if (relu) z = fmaxf(z, 0.f);
-          z = to_f32(from_f32<T>(z));
-          if (z > best[e]) { best[e] = z; bi[e] = r * 3 + s; }
-        }
+      for (int e = 0; e < KP; ++e) {
+        float z = fmaf(f[e], sc[e], sh[e]);
+        if (relu) z = fmaxf(z, 0.f);
+        z = to_f32(from_f32<T>(z));
+        if (tok[t] && z > best[e]) { best[e] = z; bi[e] = t; }
       }
+    }
     st16(y + i * KP, Chunk<T>::pack(best));
     if (idx) {
       if constexpr (KP == 8) {
