@@ -342,9 +342,9 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(WgradParams p) {
     if constexpr (sizeof(T) == 2) {
       // lane l: g = l>>4 ; fragment column (channel) = (g&1)*16 + (l&15) = l&31 ; k-half = g>>1 = l>>5
       const int g = lane >> 4, s4 = lane & 15;
-#pragma unroll
-      for (int kg = 0; kg < BMR / 16; ++kg) {
-        bf16x8 fp[TP], fq[TQ];
+      // fragments of k-group kg+1 are fetched (ds_read_b64_tr_b16) while the MFMAs of k-group kg run: register double buffer
+      bf16x8 fp[2][TP], fq[2][TQ];
+      auto rd = [&](int kg, int bsel) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int r = kg * 16 + (g >> 1) * 8 + q * 4 + (s4 >> 2);
@@ -354,9 +354,9 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(WgradParams p) {
             const char* a = bp + r * RSP + ((gran ^ gran_swz<GPRP>(r)) << 5) + (s4 & 3) * 8;
             s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
             u32x2 v2 = __builtin_bit_cast(u32x2, v);
-            u32x4 u = __builtin_bit_cast(u32x4, fp[i]);
+            u32x4 u = __builtin_bit_cast(u32x4, fp[bsel][i]);
             u[2 * q] = v2[0]; u[2 * q + 1] = v2[1];
-            fp[i] = __builtin_bit_cast(bf16x8, u);
+            fp[bsel][i] = __builtin_bit_cast(bf16x8, u);
           }
 #pragma unroll
           for (int j = 0; j < TQ; ++j) {
@@ -364,16 +364,22 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(WgradParams p) {
             const char* a = bq + r * RSQ + ((gran ^ gran_swz<GPRQ>(r)) << 5) + (s4 & 3) * 8;
             s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
             u32x2 v2 = __builtin_bit_cast(u32x2, v);
-            u32x4 u = __builtin_bit_cast(u32x4, fq[j]);
+            u32x4 u = __builtin_bit_cast(u32x4, fq[bsel][j]);
             u[2 * q] = v2[0]; u[2 * q + 1] = v2[1];
-            fq[j] = __builtin_bit_cast(bf16x8, u);
+            fq[bsel][j] = __builtin_bit_cast(bf16x8, u);
           }
         }
+      };
+      rd(0, 0);
+#pragma unroll
+      for (int kg = 0; kg < BMR / 16; ++kg) {
+        const int bsel = kg & 1;
+        if (kg + 1 < BMR / 16) rd(kg + 1, bsel ^ 1);
 #pragma unroll
         for (int i = 0; i < TP; ++i)
 #pragma unroll
           for (int j = 0; j < TQ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[i], fq[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[bsel][i], fq[bsel][j], acc[i][j], 0, 0, 0);
         if (kg == 0) mid();
       }
     } else {
