@@ -20,6 +20,16 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   if (i >= (size_t)N * HW) return;
   const size_t n = i / HW, pix = i % HW;
   T* dst = y + i * Cp;
+  constexpr int KP = DT<T>::KPACK;
+  if (Cp % KP == 0) {   // 16-byte stores
+    for (int c0 = 0; c0 < Cp; c0 += KP) {
+      float v[KP];
+#pragma unroll
+      for (int e = 0; e < KP; ++e) v[e] = (c0 + e < C) ? x[(n * C + c0 + e) * HW + pix] : 0.f;
+      st16(dst + c0, Chunk<T>::pack(v));
+    }
+    return;
+  }
   for (int c = 0; c < Cp; ++c) {
     float v = c < C ? x[(n * C + c) * HW + pix] : 0.f;
     dst[c] = from_f32<T>(v);
