@@ -95,6 +95,7 @@ def gen_arcface(L):
         for gamma in ((0,) if C > 100 else (0, 2)):
             x = torch.randn(B, 512, generator=g)
             label = torch.randint(0, C, (B,), generator=g)
+            torch.manual_seed(1000 + 7 * len(out))   # the head weight is drawn from the GLOBAL generator (xavier_uniform_): pin it
             wrap = L.SoftmaxBasedMetricLearning(torch.nn.Identity(), C, 512, is_focal=True, loss_kwargs=dict(gamma=gamma), **kw)
             w = wrap.add_margin.weight.detach().clone()
             if name == "arc_hard" and gamma == 0:
@@ -179,6 +180,47 @@ def gen_recall(ctrl_mod, sim_f):
         out[f"{name}_pair_scores"] = sc.numpy()
         print(f"recall {name}: ref R@10={vals['Recall@K=10']:.4f} R@100={vals['Recall@K=100']:.4f} counts={ours}")
     np.savez_compressed(os.path.join(OUT, "recall.npz"), **out)
+
+
+def gen_pairs():
+    """The reference's PairGenerator (data_loading/pairs.py:10-108) run on seeded identity tables: pairs + correction table.
+    `data_loading/dataset.py` needs PIL / torchvision-free imports only for file scanning; a stub module stands in for it."""
+    ds_stub = types.ModuleType("ref_data_loading.dataset")
+    ds_stub.RecDataset = object
+    pkg = types.ModuleType("ref_data_loading")
+    pkg.__path__ = [os.path.join(REF, "data_loading")]
+    sys.modules["ref_data_loading"] = pkg
+    sys.modules["ref_data_loading.dataset"] = ds_stub
+    ref = load_ref_module("ref_data_loading.pairs", "data_loading/pairs.py")
+    out = {}
+    for name, n_id, seed, gen_number, ratio in [("a", 30, 3, 60, 1), ("b", 57, 11, None, 0.5), ("c", 120, 42, 400, 2)]:
+        rs = np.random.RandomState(100 + seed)
+        counts = rs.randint(1, 6, size=n_id)
+        perm = rs.permutation(int(counts.sum()))          # dataset indices of an identity are not contiguous in general
+        u2i, o = {}, 0
+        for u in range(n_id):
+            u2i[u] = sorted(int(v) for v in perm[o:o + counts[u]])
+            o += counts[u]
+        users = [u for u in range(n_id) if rs.rand() < 0.6]
+
+        class DS:
+            uid_to_indices = u2i
+
+            def __len__(self):
+                return int(counts.sum())
+
+        pg = ref.PairGenerator(DS(), gen_number, ratio, None, seed, users)
+        out[f"{name}_counts"] = counts; out[f"{name}_perm"] = perm; out[f"{name}_users"] = np.array(users)
+        out[f"{name}_args"] = np.array([-1 if gen_number is None else gen_number, seed], dtype=np.int64)
+        out[f"{name}_ratio"] = np.float64(ratio)
+        out[f"{name}_pairs"] = np.array(pg.pairs, dtype=np.int64)
+        ck = sorted(pg.correction)
+        out[f"{name}_corr_keys"] = np.array(ck, dtype=np.int64)
+        out[f"{name}_corr_vals"] = np.array([pg.correction[k] for k in ck], dtype=np.int64)
+        out[f"{name}_corrected"] = np.array(pg.corrected_indices, dtype=np.int64)
+        out[f"{name}_labels"] = np.asarray(pg.labels)
+        print(f"pairs {name}: {len(pg.pairs)} pairs ({int(np.sum(pg.labels))} genuine), {len(ck)} indices")
+    np.savez_compressed(os.path.join(OUT, "pairs.npz"), **out)
 
 
 def gen_swin():
@@ -317,9 +359,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "resnet_hf":
         gen_resnet_hf()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pairs":
+        gen_pairs()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "arcface":
+        gen_arcface(ref_losses())
+        sys.exit(0)
     L = ref_losses()
     gen_arcface(L)
     gen_recall(ref_controller(), ref_similarity_f())
+    gen_pairs()
     gen_swin()
     gen_train_trace(L)
     gen_resnet_hf()

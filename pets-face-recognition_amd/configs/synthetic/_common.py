@@ -25,6 +25,7 @@ def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs
     val_idx = [i for i, u in enumerate(labels) if u >= n_train_ids]
     assert not (set(train_users) & set(val_users))
     train, val = RecSubset(dataset, train_idx), RecSubset(dataset, val_idx)
+    n_pairs = min(n_pairs, n_val_ids * photos * (photos - 1))   # the reference asserts gen_number <= #ordered genuine pairs
     pair_gen = PairGenerator(dataset, n_pairs, 1, None, seed, val_users)
 
     def pair_generator(idx):

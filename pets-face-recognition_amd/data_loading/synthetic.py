@@ -12,6 +12,8 @@ class SyntheticRecDataset(Dataset):
         self.n_id, self.ppi, self.size, self.seed, self.noise = n_identities, photos_per_identity, image_size, seed, noise
         self.labels = torch.arange(n_identities).repeat_interleave(photos_per_identity)
         self.label_map = {u: u for u in range(n_identities)}
+        # identity -> dataset indices, the attribute the reference's PairGenerator samples from (dataset.py:93-96)
+        self.uid_to_indices = {u: list(range(u * photos_per_identity, (u + 1) * photos_per_identity)) for u in range(n_identities)}
 
     def __len__(self):
         return self.n_id * self.ppi

@@ -59,8 +59,10 @@ class Controller(nn.Module):
         ia = [a for a, _ in ci]
         ib = [b for _, b in ci]
         sim = getattr(self.config, 'similarity_f', None)
-        if sim is not None and not getattr(sim, '_is_default_cosine', False) and not emb.is_cuda:
-            scores = sim([(emb[a], emb[b]) for a, b in ci])           # honour a custom similarity on the CPU path
+        if sim is not None and not getattr(sim, '_is_default_cosine', False):
+            # a custom similarity is always honoured (the reference calls config.similarity_f unconditionally,
+            # controller.py:62) — on CUDA embeddings too; only the flagged default (cos+1)/2 takes the fused kernel
+            scores = sim([(emb[a], emb[b]) for a, b in ci])
         else:
             scores = pair_similarity(emb, ia, ib)                       # (cos + 1) / 2, fe_dogs_config.py:89-93
         return scores.float().cpu(), torch.as_tensor(pair_generator.labels)

@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from .._hip import lib, dtype_id
+from .._hip import lib, dtype_id, PfrError
 from .._hip import ops
 
 
@@ -37,10 +37,13 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     T = compute_dtype
     if rescore is None:
         rescore = T != torch.float32
+    if k > 512:
+        # the running lists of the top-K kernels hold at most 512 entries per query (pfr_match.hip); silently returning
+        # fewer columns, or re-scoring past the candidate list, would be wrong answers
+        raise PfrError(f"cosine_topk: k={k} exceeds the 512-entry running list of the gfx950 top-K kernels")
     kc = k
     if rescore:
-        kc = min(512, k + (slack if slack is not None else max(28, k // 2 + k)))
-    kc = min(kc, 512)
+        kc = max(k, min(512, k + (slack if slack is not None else max(28, k // 2 + k))))
     q32 = q.float().contiguous()
     g32 = g.float().contiguous()
     if normalize and T == torch.bfloat16 and D % 4 == 0 and D <= 2048:

@@ -212,3 +212,47 @@ def test_resnet_restatement_matches_hf_fixture(arch):
         assert torch.allclose(got_o, want, rtol=2e-4, atol=2e-5), (arch, mode)
         assert torch.allclose(got_p, want, rtol=2e-4, atol=2e-5), (arch, mode)
     assert torch.allclose(new["bn1.running_mean"], torch.tensor(G[f"{arch}_bn1_running_mean_after"]), atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["n256", "n400", "ties"])
+def test_roc_auc_and_accuracy_equal_reference_controller(name):
+    """'ROC AUC' and 'Accuracy' printed by the reference's Controller.test_epoch_end (controller.py:67-75, 206-211) on the
+    fixture's pairs vs engine/metrics.py (a12 / a14), through Controller.compute_accuracy's own signature too."""
+    from pets_face_recognition_amd.engine import metrics as M
+    from pets_face_recognition_amd.engine.controller import Controller
+    G = np.load(os.path.join(GOLD, "recall.npz"))
+    scores = torch.tensor(G[f"{name}_pair_scores"])
+    labels = torch.tensor(G[f"{name}_plabels"])
+    fpr, tpr, thr = M.roc_curve(scores, labels)
+    assert abs(M.auroc(scores, labels) - float(G[f"{name}_auc_ref"])) < 1e-6   # the reference prints a float32 tensor
+    acc = Controller.compute_accuracy(scores, labels, thr, fpr, 1 - tpr)
+    assert abs(acc - float(G[f"{name}_acc_ref"])) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_pair_generator_seeded_equivalent_to_reference(name):
+    """PairGenerator(dataset, gen_number, gen_ratio, None, seed, users): same pairs, labels, correction table and
+    corrected_indices as the reference's class produced for the same arguments (tests/golden/pairs.npz)."""
+    from pets_face_recognition_amd.data_loading import PairGenerator
+    G = np.load(os.path.join(GOLD, "pairs.npz"))
+    counts, perm = G[f"{name}_counts"], G[f"{name}_perm"]
+    u2i, o = {}, 0
+    for u, c in enumerate(counts):
+        u2i[u] = sorted(int(v) for v in perm[o:o + c])
+        o += int(c)
+
+    class DS:
+        uid_to_indices = u2i
+
+        def __len__(self):
+            return int(counts.sum())
+
+    gen_number, seed = (int(v) for v in G[f"{name}_args"])
+    pg = PairGenerator(DS(), None if gen_number < 0 else gen_number, float(G[f"{name}_ratio"]), None, seed,
+                       [int(u) for u in G[f"{name}_users"]])
+    assert np.array_equal(np.array(pg.pairs), G[f"{name}_pairs"])
+    assert np.array_equal(np.asarray(pg.labels), G[f"{name}_labels"])
+    assert sorted(pg.correction) == G[f"{name}_corr_keys"].tolist()
+    assert [pg.correction[k] for k in sorted(pg.correction)] == G[f"{name}_corr_vals"].tolist()
+    assert np.array_equal(np.array(pg.corrected_indices), G[f"{name}_corrected"])
+    assert pg.indices == [tuple(r[:2]) for r in G[f"{name}_pairs"].tolist()]
