@@ -93,9 +93,22 @@ class FlatDDP:
         # The head's gradient (ArcFace weight, 20 MB at 10 000 ids) is complete BEFORE the backbone's backward starts:
         # its all-reduce is launched from a post-accumulate hook and overlaps the whole backbone backward.
         self._extra_done = set()
-        for p in self.extra:
-            if p.requires_grad:
-                p.register_post_accumulate_grad_hook(self._reduce_param)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._reduce_param) for p in self.extra if p.requires_grad]
+
+    def detach(self):
+        """unhook from the model (the trainer builds a new FlatDDP when the model got a new engine)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self.eng.grad_ready_hook == self.reducer.ready:
+            self.eng.grad_ready_hook = None
+
+    def check(self):
+        """the reducer must be bound to the engine that is actually executing the model"""
+        cur = self.model_loss.module.hip_engine()
+        if cur is not self.eng or cur.grad_ready_hook != self.reducer.ready or cur.grad.data_ptr() != self.reducer.flat.data_ptr():
+            raise RuntimeError("FlatDDP is bound to a stale engine (the model was moved / re-adopted): gradients of this rank "
+                               "would not be all-reduced — rebuild FlatDDP (Trainer._setup does)")
 
     def _reduce_param(self, p):
         r = self.reducer
@@ -115,6 +128,7 @@ class FlatDDP:
         self._extra_done.clear()
 
     def finish_backward(self):
+        self.check()
         self.reduce_extra()
         self.reducer.finish()
 

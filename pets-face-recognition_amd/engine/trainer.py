@@ -61,18 +61,24 @@ class Trainer:
         device = self._device()
         if device.type == 'cuda':
             torch.cuda.set_device(device)
-        controller.to(device)
+        p0 = next(controller.parameters(), None)
+        if p0 is None or p0.device != device:
+            controller.to(device)      # (a redundant .to() would make the HIP models drop and rebuild their engines)
         controller.logger = self.logger
-        if self.is_distributed_run and self.ddp is None:
+        if self.is_distributed_run:
             import torch.distributed as dist
             if not dist.is_initialized():
                 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
                 dist.init_process_group('nccl' if device.type == 'cuda' else 'gloo')
             if device.type == 'cuda':
                 from .ddp import FlatDDP
-                controller.model_loss.module.hip_engine(device)
-                self.ddp = FlatDDP(controller.model_loss, bucket_mb=self.strategy.get('bucket_mb', 25))
-            else:
+                eng = controller.model_loss.module.hip_engine(device)
+                if self.ddp is None or self.ddp.eng is not eng:
+                    # (re)bind: a new engine means new flat gradient buffers — the old reducer would all-reduce stale memory
+                    if self.ddp is not None:
+                        self.ddp.detach()
+                    self.ddp = FlatDDP(controller.model_loss, bucket_mb=self.strategy.get('bucket_mb', 25))
+            elif self.ddp is None:
                 from .ddp import GenericDDP
                 self.ddp = GenericDDP(controller.model_loss)
         return device

@@ -15,6 +15,7 @@ resnet (/root/reference/losses/__init__.py:38-41 called from engine/controller.p
     (BN + residual add + ReLU) is one pass, backward recomputes the ReLU masks instead of storing them.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -50,6 +51,12 @@ def _side_with_ddp():
         return int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8
     except ValueError:
         return False
+
+
+class PlanTicket:
+    """Held by the autograd node of one forward pass: while it is alive (and its backward has not run) the plan that
+    produced the saved activations is not handed to another forward pass."""
+    __slots__ = ("__weakref__",)
 
 
 class _Plan:
@@ -468,6 +475,12 @@ class FEEngine:
             xin_shape = (N, H, W, self.cp)
         x_nhwc = self._A(plan, xin_shape)
         plan.meta["x_nhwc"] = x_nhwc
+        # batch-statistics coefficients are part of what a forward pass SAVES for its backward: one set per plan (pointers are
+        # baked into the op lists below), so that a second forward before the first backward cannot overwrite them
+        for b in self.bn_list:
+            b.coef = torch.zeros((4, b.C), dtype=torch.float32, device=self.device)    # mean, invstd, scale, shift
+            b.bcoef = torch.zeros((3, b.C), dtype=torch.float32, device=self.device)   # backward coefficients
+            plan.bufs[len(plan.bufs)] = (b.coef, b.bcoef)
         saved = {}
         # ---- stem: conv 7x7/2 (space-to-depth form when H, W are even) → (BN+ReLU+MaxPool fused)
         if use_s2d:
@@ -692,12 +705,16 @@ class FEEngine:
         ops.append((None, (off,)))
 
     # ------------------------------------------------------------------------------------------ execution
-    def get_plan(self, N, H, W, train, with_backward):
-        key = (N, H, W, train, with_backward)
+    def get_plan(self, N, H, W, train, with_backward, slot=0):
+        key = (N, H, W, train, with_backward) + ((slot,) if slot else ())
         p = self.plans.get(key)
         if p is None:
-            if len(self.plans) >= 6:
-                self.plans.pop(next(iter(self.plans)))
+            if len(self.plans) >= 8:
+                # evict the oldest plan that no forward pass in flight still owns
+                for k, q in list(self.plans.items()):
+                    if not self._plan_busy(q):
+                        self.plans.pop(k)
+                        break
             if not train and not with_backward and self.fold_eval:
                 p = self.build_eval_plan(N, H, W)
             else:
@@ -705,6 +722,27 @@ class FEEngine:
                 self._finalize_plan(p)
             self.plans[key] = p
         return p
+
+    @staticmethod
+    def _plan_busy(plan):
+        own = plan.meta.get("owner")
+        return own is not None and own() is not None
+
+    def acquire_plan(self, N, H, W, train, with_backward, ticket):
+        """A plan owns the activation buffers its backward pass reads.  Two training forwards before a backward (list input of
+        SoftmaxBasedMetricLearning — reference losses/__init__.py:39 — or any two-view step) therefore get DIFFERENT plan
+        instances ("slots"); a slot is free again when its backward ran or its autograd node died."""
+        slot = 0
+        while True:
+            plan = self.get_plan(N, H, W, train, with_backward, slot)
+            if ticket is None or not self._plan_busy(plan):
+                break
+            slot += 1
+            if slot >= 8:
+                raise PfrError("more than 8 forward passes of one shape are waiting for their backward pass")
+        if ticket is not None:
+            plan.meta["owner"] = weakref.ref(ticket)
+        return plan
 
     def _finalize_plan(self, plan):
         """Resolve symbolic ops (workspace pointer, accumulate flag) into two concrete op lists."""
@@ -740,14 +778,14 @@ class FEEngine:
             plan.meta["bwd%d" % acc] = res
         plan.meta["ws_ptr"] = self.ws.data_ptr() if self.ws is not None else 0
 
-    def forward(self, x, train, with_backward):
+    def forward(self, x, train, with_backward, ticket=None):
         if x.dim() != 4 or x.shape[1] != self.stem[0].Cin:
             raise PfrError(f"expected NCHW input with {self.stem[0].Cin} channels, got {tuple(x.shape)}")
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
         N, _, H, W = x.shape
-        plan = self.get_plan(N, H, W, train, with_backward)
+        plan = self.acquire_plan(N, H, W, train, with_backward, ticket if with_backward else None)
         if with_backward and plan.meta.get("ws_ptr", 0) != (self.ws.data_ptr() if self.ws is not None else 0):
             self._finalize_plan(plan)
         if plan.meta.get("folded") and self.graph_eval and _TRACER[0] is None:
@@ -833,13 +871,20 @@ class FEEngine:
             else:
                 fn(*args, stream)
 
-    def backward(self, demb):
-        plan = self._last_plan
+    def backward(self, demb, plan=None):
+        plan = plan if plan is not None else self._last_plan
         stream = torch.cuda.current_stream().cuda_stream
         demb = demb.contiguous()
+        if demb.numel() != plan.meta["demb"].numel():
+            raise PfrError(f"backward: gradient of {tuple(demb.shape)} does not match the plan's embedding buffer "
+                           f"{tuple(plan.meta['demb'].shape)}")
+        if plan.meta.get("ws_ptr", 0) != (self.ws.data_ptr() if self.ws is not None else 0):
+            self._finalize_plan(plan)   # the shared weight-gradient workspace grew after this plan was resolved
         lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan.meta["demb"].data_ptr(), self.did, demb.numel(), stream)
         acc = 1 if self.first_param.grad is not None else 0
-        hook = self.grad_ready_hook
+        plan.meta["owner"] = None
+        # gradients are final (DDP bucket hook) only when no other forward pass still waits for its backward
+        hook = self.grad_ready_hook if not any(self._plan_busy(q) for q in self.plans.values()) else None
         main = torch.cuda.current_stream()
         if self.wt_pending:
             main.wait_event(self.wt_ready)
@@ -853,14 +898,18 @@ class _FEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, *params):
         eng = model.hip_engine(x.device)
-        emb = eng.forward(x, model.training, True)  # only reached when a backward pass can follow (see fe_forward)
+        ctx.ticket = PlanTicket()
+        emb = eng.forward(x, model.training, True, ctx.ticket)  # only reached when a backward pass can follow (see fe_forward)
         ctx.eng = eng
+        ctx.plan = eng._last_plan
         ctx.nparams = len(params)
         return emb.clone()
 
     @staticmethod
     def backward(ctx, demb):
-        ctx.eng.backward(demb)
+        if ctx.plan.meta.get("owner") is None or ctx.plan.meta["owner"]() is not ctx.ticket:
+            raise PfrError("backward: the activations of this forward pass were released (double backward?)")
+        ctx.eng.backward(demb, ctx.plan)
         # parameter gradients are delivered by side effect into the flat gradient buffer (p.grad views)
         return (None, None) + (None,) * ctx.nparams
 

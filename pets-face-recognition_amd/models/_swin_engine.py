@@ -12,13 +12,14 @@ Mapping (tokens are kept NHWC = [B, H, W, C] end to end; the reference's NCHW↔
   cyclic shift, window partition, masks            → addressing / analytic mask inside the attention kernel
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
 
 from .._hip import lib, dtype_id, PfrError
 from .._hip.lib import _TRACER
-from ._fe_engine import default_compute_dtype, _ALIGN, _SIDE, _FORK, _SREC, _WAIT, _MWAIT, _side_with_ddp
+from ._fe_engine import default_compute_dtype, _ALIGN, _SIDE, _FORK, _SREC, _WAIT, _MWAIT, _side_with_ddp, PlanTicket
 
 
 class _Lin:
@@ -450,12 +451,15 @@ class SwinEngine:
         plan["bwd"] = res
         plan["ws_ptr"] = (self.ws.data_ptr(), self.cs_ws.data_ptr())
 
-    def get_plan(self, N, H, W, with_backward):
-        key = (N, H, W, with_backward)
+    def get_plan(self, N, H, W, with_backward, slot=0):
+        key = (N, H, W, with_backward) + ((slot,) if slot else ())
         p = self.plans.get(key)
         if p is None:
-            if len(self.plans) >= 4:
-                self.plans.pop(next(iter(self.plans)))
+            if len(self.plans) >= 6:
+                for k, q in list(self.plans.items()):
+                    if not self._plan_busy(q):
+                        self.plans.pop(k)
+                        break
             p = self.build_plan(N, H, W, with_backward)
             if with_backward:
                 self._finalize(p)
@@ -464,12 +468,31 @@ class SwinEngine:
             self._finalize(p)
         return p
 
-    def forward(self, x, with_backward):
+    @staticmethod
+    def _plan_busy(plan):
+        own = plan.get("owner")
+        return own is not None and own() is not None
+
+    def acquire_plan(self, N, H, W, with_backward, ticket):
+        """one plan instance ("slot") per forward pass that still waits for its backward — see FEEngine.acquire_plan"""
+        slot = 0
+        while True:
+            plan = self.get_plan(N, H, W, with_backward, slot)
+            if ticket is None or not self._plan_busy(plan):
+                break
+            slot += 1
+            if slot >= 8:
+                raise PfrError("more than 8 forward passes of one shape are waiting for their backward pass")
+        if ticket is not None:
+            plan["owner"] = weakref.ref(ticket)
+        return plan
+
+    def forward(self, x, with_backward, ticket=None):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise PfrError(f"expected NCHW input with {self.in_channels} channels, got {tuple(x.shape)}")
         x = x.float().contiguous()
         N, _, H, W = x.shape
-        plan = self.get_plan(N, H, W, with_backward)
+        plan = self.acquire_plan(N, H, W, with_backward, ticket if with_backward else None)
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh_weights(stream, for_backward=with_backward)
         lib.pfr_nchw_to_nhwc(x.data_ptr(), plan["x_nhwc"].data_ptr(), self.did, N, x.shape[1], H, W, self.cp, stream)
@@ -478,12 +501,24 @@ class SwinEngine:
         self._last = plan
         return plan["emb"]
 
-    def backward(self, demb):
-        plan = self._last
+    def backward(self, demb, plan=None):
+        plan = plan if plan is not None else self._last
         stream = torch.cuda.current_stream().cuda_stream
         demb = demb.contiguous()
+        if demb.numel() != plan["demb"].numel():
+            raise PfrError(f"backward: gradient of {tuple(demb.shape)} does not match the plan's embedding buffer "
+                           f"{tuple(plan['demb'].shape)}")
+        if plan["ws_ptr"] != (self.ws.data_ptr(), self.cs_ws.data_ptr()):
+            self._finalize(plan)
+        # Every gradient kernel of this engine OVERWRITES its slice of the flat buffer.  When gradients are already present
+        # (a second backward before zero_grad: gradient accumulation, list inputs) the previous sum is set aside and added
+        # back afterwards — two extra passes over the 110 MB buffer, only on that path.
+        prev = self.grad.clone() if self.first_param.grad is not None else None
+        plan["owner"] = None
         lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan["demb"].data_ptr(), self.did, demb.numel(), stream)
         hook = self.grad_ready_hook
+        if prev is not None or any(self._plan_busy(q) for q in self.plans.values()):
+            hook = None   # not final yet (accumulating, or another forward pass still waits for its backward)
         main = torch.cuda.current_stream()
         if self.wt_pending:
             main.wait_event(self.wt_ready)
@@ -517,6 +552,8 @@ class SwinEngine:
                     main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)
+        if prev is not None:
+            self.grad.add_(prev)
         self.attach_grads()
 
 
@@ -524,14 +561,18 @@ class _SwinFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, *params):
         eng = model.hip_engine(x.device)
-        emb = eng.forward(x, True)
+        ctx.ticket = PlanTicket()
+        emb = eng.forward(x, True, ctx.ticket)
         ctx.eng = eng
+        ctx.plan = eng._last
         ctx.nparams = len(params)
         return emb.clone()
 
     @staticmethod
     def backward(ctx, demb):
-        ctx.eng.backward(demb)
+        if ctx.plan.get("owner") is None or ctx.plan["owner"]() is not ctx.ticket:
+            raise PfrError("backward: the activations of this forward pass were released (double backward?)")
+        ctx.eng.backward(demb, ctx.plan)
         return (None, None) + (None,) * ctx.nparams
 
 

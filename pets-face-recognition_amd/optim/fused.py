@@ -7,52 +7,83 @@ import torch
 from .._hip import ops, PfrError
 
 
-def _segments(params):
-    """Group CUDA fp32 parameters into maximal runs that are contiguous in memory (flat-buffer neighbours)."""
-    items = []
-    for p in params:
-        if p.grad is None:
-            continue
-        if not (p.is_cuda and p.dtype == torch.float32):
-            raise PfrError("fused optimizers need CUDA fp32 parameters")
-        items.append(p)
-    return items
-
-
 class _FusedBase(torch.optim.Optimizer):
-    def _flat_views(self, group):
-        """→ list of (param_flat, grad_flat, key) covering the group's parameters with as few tensors as possible."""
-        runs = []
+    """State lives in `self.state[p]` like in torch.optim (so `state_dict()` / `load_state_dict()` round-trip and follow the
+    parameters through `model.to()`): each entry is a VIEW, with the parameter's logical shape and strides, into one flat
+    buffer per contiguous run of the group, which is what the kernels update."""
+    _STATE_KEYS = ()
+
+    def __init__(self, params, defaults):
+        super().__init__(params, defaults)
+        self._runs = {}      # group index -> (signature, [run, ...])
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._runs = {}      # loaded tensors are private copies: re-pack them into flat run buffers at the next step
+
+    def _group_runs(self, gi, group):
+        params = [p for p in group["params"] if p.grad is not None]
+        sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr()) for p in params)
+        cached = self._runs.get(gi)
+        if cached is not None and cached[0] == sig:
+            return cached[1]
+        if any(not p.is_cuda for p in params):
+            raise PfrError("fused optimizers need CUDA parameters (use torch.optim on the CPU path)")
+        runs = self._build_runs(params)
+        for r in runs:
+            n = r["n"]
+            dev = r["pf"].device
+            r["state"] = {k: torch.zeros(n, dtype=torch.float32, device=dev) for k in self._STATE_KEYS}
+            for p, off in r["members"]:
+                st = self.state[p]
+                for k in self._STATE_KEYS:
+                    view = torch.as_strided(r["state"][k], p.shape, p.stride(), off)
+                    old = st.get(k)
+                    if old is not None:
+                        view.copy_(old.to(dev))     # carried over (loaded checkpoint, or a previous buffer layout)
+                    st[k] = view
+        self._runs[gi] = (sig, runs)
+        return runs
+
+    def _build_runs(self, params):
+        """→ runs covering `params` with as few flat tensors as possible.  Neighbours are merged only across the engine's
+        ALIGNMENT PADDING (< 64 floats): a gap of a whole 64-element parameter (e.g. a BN bias of another param group lying
+        between two weights) must not be swallowed into this group's update."""
         dense = []
-        for p in group["params"]:
-            if p.grad is None:
-                continue
+        for p in params:
+            if p.dtype != torch.float32:
+                raise PfrError("fused optimizers need fp32 parameters")
             st_p = self._storage_span(p.data)
             st_g = self._storage_span(p.grad)
             if st_p is None or st_g is None:
                 raise PfrError("fused optimizers need parameters/gradients that are dense in memory")
             dense.append((st_p, st_g, p))
         dense.sort(key=lambda t: t[0][0])
+        runs = []
         for (pa, pn), (ga, gn), p in dense:
-            # extend the previous run when both param and grad continue it (allowing the engine's alignment padding)
-            if runs and 0 <= pa - runs[-1]["pe"] <= 256 and (ga - runs[-1]["ge"]) == (pa - runs[-1]["pe"]) \
-                    and runs[-1]["pbase"] == p.data.untyped_storage().data_ptr() \
-                    and runs[-1]["gbase"] == p.grad.untyped_storage().data_ptr():
-                runs[-1]["pe"] = pa + 4 * pn
-                runs[-1]["ge"] = ga + 4 * pn
+            r = runs[-1] if runs else None
+            if r is not None and 0 <= pa - r["pe"] < 256 and (ga - r["ge"]) == (pa - r["pe"]) \
+                    and r["pbase"] == p.data.untyped_storage().data_ptr() \
+                    and r["gbase"] == p.grad.untyped_storage().data_ptr():
+                r["members"].append((p, (pa - r["ps"]) // 4))
+                r["pe"] = pa + 4 * pn
+                r["ge"] = ga + 4 * pn
             else:
-                runs.append({"ps": pa, "pe": pa + 4 * pn, "gs": ga, "ge": ga + 4 * pn, "p": p,
+                runs.append({"ps": pa, "pe": pa + 4 * pn, "gs": ga, "ge": ga + 4 * pn, "p": p, "members": [(p, 0)],
                              "pbase": p.data.untyped_storage().data_ptr(), "gbase": p.grad.untyped_storage().data_ptr()})
-        out = []
         for r in runs:
             n = (r["pe"] - r["ps"]) // 4
             p = r["p"]
             poff = (r["ps"] - r["pbase"]) // 4
             goff = (r["gs"] - r["gbase"]) // 4
-            pf = torch.empty(0, dtype=torch.float32, device=p.device).set_(p.data.untyped_storage(), poff, (n,), (1,))
-            gf = torch.empty(0, dtype=torch.float32, device=p.device).set_(p.grad.untyped_storage(), goff, (n,), (1,))
-            out.append((pf, gf, (r["ps"], n)))
-        return out
+            r["n"] = n
+            r["pf"] = torch.empty(0, dtype=torch.float32, device=p.device).set_(p.data.untyped_storage(), poff, (n,), (1,))
+            r["gf"] = torch.empty(0, dtype=torch.float32, device=p.device).set_(p.grad.untyped_storage(), goff, (n,), (1,))
+        return runs
+
+    def _flat_views(self, group):
+        """(param_flat, grad_flat, (address, numel)) per run — kept for tests / introspection"""
+        return [(r["pf"], r["gf"], (r["ps"], r["n"])) for r in self._build_runs([p for p in group["params"] if p.grad is not None])]
 
     @staticmethod
     def _storage_span(t):
@@ -71,44 +102,49 @@ class _FusedBase(torch.optim.Optimizer):
 
 
 class FusedSGD(_FusedBase):
+    _STATE_KEYS = ("momentum_buffer",)
+
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False):
         if dampening != 0 or nesterov:
             raise PfrError("FusedSGD supports dampening=0, nesterov=False (what the reference configs use)")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
-        self._bufs = {}
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for gi, group in enumerate(self.param_groups):
-            for pf, gf, key in self._flat_views(group):
-                k = (gi,) + key
-                buf = self._bufs.get(k)
-                first = buf is None
-                if first and group["momentum"] != 0:
-                    buf = torch.zeros_like(pf)
-                    self._bufs[k] = buf
-                ops.sgd_step(pf, gf, buf, None, group["lr"], group["momentum"], group["weight_decay"], first_step=first)
+            for r in self._group_runs(gi, group):
+                # a zero-initialised buffer makes torch's "first step: buf = d" the general rule buf = momentum*buf + d
+                buf = r["state"]["momentum_buffer"] if group["momentum"] != 0 else None
+                ops.sgd_step(r["pf"], r["gf"], buf, None, group["lr"], group["momentum"], group["weight_decay"], first_step=False)
         return loss
 
 
 class FusedAdamW(_FusedBase):
+    _STATE_KEYS = ("exp_avg", "exp_avg_sq")
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._bufs = {}
         self._t = 0
+
+    def state_dict(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p in self.state:
+                    self.state[p]["step"] = torch.tensor(float(self._t))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        self._t = int(max(steps)) if steps else 0
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         self._t += 1
         for gi, group in enumerate(self.param_groups):
-            for pf, gf, key in self._flat_views(group):
-                k = (gi,) + key
-                st = self._bufs.get(k)
-                if st is None:
-                    st = (torch.zeros_like(pf), torch.zeros_like(pf))
-                    self._bufs[k] = st
-                ops.adamw_step(pf, gf, st[0], st[1], None, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
-                               group["weight_decay"], self._t)
+            for r in self._group_runs(gi, group):
+                ops.adamw_step(r["pf"], r["gf"], r["state"]["exp_avg"], r["state"]["exp_avg_sq"], None, group["lr"],
+                               group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"], self._t)
         return loss

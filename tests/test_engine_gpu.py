@@ -5,6 +5,7 @@ import sys
 import textwrap
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -99,3 +100,121 @@ def test_flat_ddp_world1_rccl_path_equals_single_gpu(tmp_path):
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "OK resnet18" in r.stdout and "OK swin_t" in r.stdout and "OK sharded match" in r.stdout
+
+
+@pytest.mark.parametrize("arch,hw", [("resnet18", 64), ("swin_t", 224)])
+def test_list_input_two_forwards_before_backward(arch, hw):
+    """`SoftmaxBasedMetricLearning.forward` embeds a list/tuple input chunk by chunk
+    (/root/reference/losses/__init__.py:39) — two training forwards before one backward.  Each forward must keep its own
+    saved activations (plan slot) and the two backward passes must ACCUMULATE: gradients equal those of the CPU (torch)
+    execution of the same module, for chunks of equal and of different shape."""
+    import copy
+    import pets_face_recognition_amd.models as M
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    torch.manual_seed(5)
+    if arch == "swin_t":
+        bb = M.swin_t(num_classes=512, compute_dtype=torch.float32)
+    else:
+        bb = M.resnet18(compute_dtype=torch.float32)
+        bb.fc = torch.nn.Linear(512, 512)
+    cpu = SoftmaxBasedMetricLearning(bb, 50, 512, is_focal=True, arc_margin=True).train()
+    hip = copy.deepcopy(cpu)
+    hip.add_margin.compute_dtype = torch.float32
+    hip = hip.to("cuda").train()
+    g = torch.Generator().manual_seed(9)
+    for sizes in ((3, 3), (2, 4)):
+        xs = [torch.rand(n, 3, hw, hw, generator=g) for n in sizes]
+        y = torch.randint(0, 50, (sum(sizes),), generator=g)
+        for ml in (cpu, hip):
+            for p in ml.parameters():
+                p.grad = None
+        lc = cpu(xs, y)["loss"]
+        lc.backward()
+        lh = hip([x.to("cuda") for x in xs], y.to("cuda"))["loss"]
+        lh.backward()
+        torch.cuda.synchronize()
+        assert abs(lh.item() - lc.item()) < 2e-4 * abs(lc.item()), (sizes, lh.item(), lc.item())
+        gc = torch.cat([p.grad.flatten() for p in cpu.parameters() if p.requires_grad]).double()
+        gh = torch.cat([p.grad.flatten().cpu() for p in hip.parameters() if p.requires_grad]).double()
+        cos = torch.nn.functional.cosine_similarity(gc, gh, dim=0).item()
+        assert cos > 0.9995, (arch, sizes, cos)
+        assert abs(gh.norm().item() / gc.norm().item() - 1) < 2e-2
+    # a backward through released activations is an error, not silent garbage
+    e1 = hip.module(xs[0].to("cuda"))
+    e1.sum().backward()
+    with pytest.raises(Exception):
+        e1.sum().backward()
+
+
+def test_fused_optimizer_state_dict_roundtrip_and_group_isolation():
+    """optimizer state lives in `state[p]` (views into flat run buffers): state_dict()/load_state_dict()
+    round-trip the momentum, the state follows the parameters through a re-adoption of the engine, and parameters of another
+    param group lying between two tensors of a group in the flat buffer (layer1 bn biases, C = 64) are updated exactly once
+    with their own lr.  Reference recipe: /root/reference/configs/dog_fe/fe_dogs_config.py:123-133."""
+    import pets_face_recognition_amd.models as M
+    from pets_face_recognition_amd.optim import FusedSGD, FusedAdamW
+
+    def make(optcls):
+        torch.manual_seed(3)
+        m = M.resnet18(compute_dtype=torch.float32)
+        m.fc = torch.nn.Linear(512, 512)
+        m = m.to("cuda").train()
+        m.hip_engine()
+        w = [p for n, p in m.named_parameters() if p.dim() > 1]
+        b = [p for n, p in m.named_parameters() if p.dim() <= 1]
+        kw = dict(momentum=0.9) if optcls is FusedSGD else {}
+        ref_cls = torch.optim.SGD if optcls is FusedSGD else torch.optim.AdamW
+        return m, optcls([{"params": w, "lr": 0.05}, {"params": b, "lr": 0.2, "weight_decay": 0.0}], 0.05, **kw), ref_cls, kw
+
+    x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(1)).to("cuda")
+    for optcls in (FusedSGD, FusedAdamW):
+        m, opt, ref_cls, kw = make(optcls)
+        # reference: torch optimizer on detached copies with the same gradients
+        names = [n for n, _ in m.named_parameters()]
+        steps = []
+        for it in range(3):
+            opt.zero_grad()
+            m(x).square().mean().backward()
+            torch.cuda.synchronize()
+            steps.append({n: (p.detach().clone(), p.grad.detach().clone()) for n, p in m.named_parameters()})
+            opt.step()
+        final = {n: p.detach().clone() for n, p in m.named_parameters()}
+        # replay with torch.optim on plain tensors, feeding the recorded gradients
+        ps = {n: torch.nn.Parameter(steps[0][n][0].clone().contiguous()) for n in names}
+        ropt = ref_cls([{"params": [ps[n] for n in names if ps[n].dim() > 1], "lr": 0.05},
+                        {"params": [ps[n] for n in names if ps[n].dim() <= 1], "lr": 0.2, "weight_decay": 0.0}], 0.05, **kw)
+        for it in range(3):
+            for n in names:
+                ps[n].grad = steps[it][n][1].clone().contiguous()
+            ropt.step()
+            if it < 2:   # the HIP model's weights after step `it` are the recorded weights of step it+1
+                for n in names:
+                    assert torch.allclose(ps[n].detach(), steps[it + 1][n][0], rtol=2e-5, atol=1e-6), (optcls.__name__, it, n)
+        for n in names:
+            assert torch.allclose(ps[n].detach(), final[n], rtol=2e-5, atol=1e-6), (optcls.__name__, n)
+        # state_dict round trip into a fresh model/optimizer, then one more identical step on both
+        import copy
+        # (deep copy = what a checkpoint on disk is; load_state_dict itself does not copy same-device tensors)
+        sd_m, sd_o = {k: v.clone() for k, v in m.state_dict().items()}, copy.deepcopy(opt.state_dict())
+        key = "momentum_buffer" if optcls is FusedSGD else "exp_avg"
+        assert len(sd_o["state"]) == len(names) and all(key in st for st in sd_o["state"].values())
+        m2, opt2, _, _ = make(optcls)
+        m2.load_state_dict(sd_m)
+        opt2.load_state_dict(sd_o)
+        for mm, oo in ((m, opt), (m2, opt2)):
+            oo.zero_grad()
+            mm(x).square().mean().backward()
+            oo.step()
+        torch.cuda.synchronize()
+        for (n, a), (_, b2) in zip(m.named_parameters(), m2.named_parameters()):
+            assert torch.allclose(a, b2, rtol=1e-6, atol=1e-7), (optcls.__name__, "after reload", n)
+        # the engine is re-created by a device round trip: momentum must survive (keyed by parameter, not by address)
+        before = {n: opt.state[p][key].detach().clone() for n, p in m.named_parameters()}
+        m._apply(lambda t: t)
+        m.hip_engine()
+        opt.zero_grad()
+        m(x).square().mean().backward()
+        opt._group_runs(0, opt.param_groups[0])
+        for n, p in m.named_parameters():
+            if p.dim() > 1:
+                assert torch.equal(opt.state[p][key], before[n]), n

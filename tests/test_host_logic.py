@@ -54,6 +54,21 @@ def test_fused_optimizer_span_detection():
     a = flat[0:576].view(4, 3, 3, 16).permute(0, 3, 1, 2)      # channels-last view (engine parameter layout)
     assert _FusedBase._storage_span(a) == (a.data_ptr(), 576)
     assert _FusedBase._storage_span(flat[0:100:2]) is None       # strided: not dense
+    # run building: neighbours merge across alignment padding (< 64 floats) only — a 64-element parameter of
+    # ANOTHER group lying between two weights of this group (ResNet layer1: conv / bn.bias / conv) must not be swallowed
+    from pets_face_recognition_amd.optim import FusedSGD
+    master, grad = torch.zeros(1024), torch.zeros(1024)
+
+    def par(lo, n):
+        q = torch.nn.Parameter(master[lo:lo + n])
+        q.grad = grad[lo:lo + n]
+        return q
+    w1, b, w2, w3 = par(0, 128), par(128, 64), par(192, 100), par(320, 64)     # w2 is followed by 28 floats of padding
+    opt = FusedSGD([{"params": [w1, w2, w3], "lr": 0.1}, {"params": [b], "lr": 0.2}], 0.1, momentum=0.9)
+    runs = opt._build_runs([w1, w2, w3])
+    assert [(r["ps"] - master.data_ptr()) // 4 for r in runs] == [0, 192] and [r["n"] for r in runs] == [128, 192]
+    assert [(q is w2, off) for q, off in runs[1]["members"]] == [(True, 0), (False, 128)]
+    assert len(opt._build_runs([b])) == 1
 
 
 def test_main_cpu_config1_runs(tmp_path):

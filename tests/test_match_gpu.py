@@ -139,3 +139,59 @@ def test_fused_filter_exclude_self_and_overflow_fallback(dtype):
     rs, ri = match_ref.topk_query_gallery(qs, gal, 10)
     assert idx.cpu().long().tolist() == ri.tolist()
     assert torch.allclose(sc.cpu(), rs, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["n256", "n400", "ties"])
+def test_controller_eval_on_gpu_equals_reference_metrics(name):
+    """Controller.test_epoch_end on CUDA embeddings (fused pair-score kernel + GPU candR@K): 'ROC AUC', 'Accuracy' and
+    Recall@K equal to what the REFERENCE's Controller.test_epoch_end printed for the same embeddings (recall.npz); and a
+    custom config.similarity_f (not the flagged default cosine) is honoured on CUDA (reference controller.py:62)."""
+    from pets_face_recognition_amd.engine.controller import Controller
+    G = np.load(os.path.join(GOLD, "recall.npz"))
+    emb = torch.tensor(G[f"{name}_emb"])
+    classes = torch.tensor(G[f"{name}_classes"])
+    pairs = [tuple(p) for p in G[f"{name}_pairs"].tolist()]
+    plabels = G[f"{name}_plabels"].tolist()
+
+    class PG:
+        corrected_indices = pairs
+        labels = plabels
+
+    calls = []
+
+    def default_sim(ps):
+        t1 = torch.stack([p[0] for p in ps]); t2 = torch.stack([p[1] for p in ps])
+        return (torch.nn.functional.cosine_similarity(t1, t2) + 1) / 2
+    default_sim._is_default_cosine = True
+
+    def custom_sim(ps):
+        calls.append(len(ps))
+        t1 = torch.stack([p[0] for p in ps]); t2 = torch.stack([p[1] for p in ps])
+        return -(t1 - t2).norm(dim=1)
+
+    class Cfg(dict):
+        def pair_generator(self, i):
+            return "Val", PG
+        match_dtype = torch.float32
+
+    N = emb.shape[0]
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1))
+    batches = [{"emb": emb[perm][i:i + 20].to(DEV), "label": classes[perm][i:i + 20].to(DEV), "index": perm[i:i + 20].to(DEV)}
+               for i in range(0, N, 20)]
+    c = Controller.__new__(Controller)
+    torch.nn.Module.__init__(c)
+    c.logger, c.current_epoch, c.last_metrics = None, 0, {}
+    cfg = Cfg(); cfg.similarity_f = default_sim
+    c.config = cfg
+    m = c.test_epoch_end([batches])["Val"]
+    assert abs(m["ROC AUC"] - float(G[f"{name}_auc_ref"])) < 1e-6
+    assert abs(m["Accuracy"] - float(G[f"{name}_acc_ref"])) < 1e-9
+    if name != "ties":
+        for k in (10, 100):
+            assert abs(m[f"Recall@K={k}"] - float(G[f"{name}_recall{k}_ref"])) < 1e-12
+    cfg.similarity_f = custom_sim
+    m2 = c.test_epoch_end([batches])["Val"]
+    assert calls == [len(pairs)]
+    from pets_face_recognition_amd.engine import metrics as M
+    ref_scores = custom_sim([(emb[a], emb[b]) for a, b in pairs])
+    assert abs(m2["ROC AUC"] - M.auroc(ref_scores, torch.tensor(plabels))) < 1e-6
