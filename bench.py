@@ -137,6 +137,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    rccl_ranks = dist.get_world_size() if dist is not None else 0   # ranks the RCCL communicator actually has (0: no communicator)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     ml, opt = build(args, device)
     ddp = None
     if use_ddp:
@@ -244,7 +247,8 @@ def main():
                 "config": {"workload": f"{args.arch} FE + ArcFace(s=64,m=0.5) + CE, {args.classes} ids, 224x224x3, "
                                        f"fwd+bwd+SGD(momentum 0.9, param groups of the reference recipe)",
                            "global_batch": args.batch * world,
-                           "per_gpu_batch": args.batch, "parallelism": f"dp{world}", "loss": round(final_loss, 4)},
+                           "per_gpu_batch": args.batch, "parallelism": f"dp{world}", "loss": round(final_loss, 4),
+                           "rccl_ranks": rccl_ranks},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line))
     if dist is not None:

@@ -33,8 +33,9 @@ class BucketReducer:
         self.handles = []
         self.launched = []
 
-    def _reduce(self, lo, hi):
-        view = self.flat[lo:hi]
+    def reduce_tensor(self, view, lo=0, hi=0):
+        """asynchronous mean all-reduce of `view` in place (RCCL: AVG on the communication stream, ordered after everything
+        the compute stream has enqueued so far; gloo/CPU: SUM now, the division in finish())"""
         op = dist.ReduceOp.AVG if (self.average and self.cuda) else dist.ReduceOp.SUM
         if self.cuda:
             ev = torch.cuda.Event()
@@ -44,7 +45,10 @@ class BucketReducer:
                 h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         else:
             h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
-        self.handles.append((h, lo, hi))
+        self.handles.append((h, view if (lo == 0 and hi == 0) else None, lo, hi))
+
+    def _reduce(self, lo, hi):
+        self.reduce_tensor(self.flat[lo:hi], lo, hi)
         self.launched.append((lo, hi))
 
     def ready(self, off):
@@ -60,14 +64,14 @@ class BucketReducer:
         """Make the compute stream wait for all outstanding reductions."""
         if self.hi > 0:
             self.ready(0)
-        for h, lo, hi in self.handles:
+        for h, t, lo, hi in self.handles:
             if self.cuda:
                 with torch.cuda.stream(self.comm_stream):
                     h.wait()
             else:
                 h.wait()
                 if self.average:
-                    self.flat[lo:hi].div_(dist.get_world_size(self.group))
+                    (t if t is not None else self.flat[lo:hi]).div_(dist.get_world_size(self.group))
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.reset()
@@ -111,13 +115,7 @@ class FlatDDP:
                                "would not be all-reduced — rebuild FlatDDP (Trainer._setup does)")
 
     def _reduce_param(self, p):
-        r = self.reducer
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        r.comm_stream.wait_event(ev)
-        with torch.cuda.stream(r.comm_stream):
-            h = dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        r.handles.append((h, 0, 0))
+        self.reducer.reduce_tensor(p.grad)
         self._extra_done.add(id(p))
 
     def reduce_extra(self):

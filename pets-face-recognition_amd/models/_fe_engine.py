@@ -32,6 +32,30 @@ def default_compute_dtype():
     return torch.float32 if v in ("f32", "fp32", "float32") else torch.bfloat16
 
 
+def flat_layout(model):
+    """name -> offset (in elements) of every parameter inside the flat master / gradient buffers, and their length: forward
+    (registration) order, each parameter padded to a multiple of _ALIGN elements"""
+    offs, total = {}, 0
+    for name, p in model.named_parameters():
+        offs[name] = total
+        total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    return offs, total
+
+
+def grad_ready_marks(model):
+    """The offsets `off` at which the backward pass reports "flat gradient [off, end) is final" (FEEngine._mark), in the order
+    it reports them: after fc, after every residual block (last block first; a block's first parameter is conv1.weight),
+    and 0 at the end.  Pure host logic — what engine/ddp.py's bucket reducer is driven by."""
+    offs, _ = flat_layout(model)
+    marks = [offs["fc.weight"]]
+    for lname in ("layer4", "layer3", "layer2", "layer1"):
+        layer = getattr(model, lname)
+        for bi in reversed(range(len(layer))):
+            marks.append(offs[f"{lname}.{bi}.conv1.weight"])
+    marks.append(0)
+    return marks
+
+
 class _Conv:
     pass
 
@@ -109,10 +133,7 @@ class FEEngine:
     def _adopt(self, model):
         dev = self.device
         named = list(model.named_parameters())
-        offs, total = {}, 0
-        for name, p in named:
-            offs[name] = total
-            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        offs, total = flat_layout(model)
         self.n_flat = total
         self.master = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)

@@ -160,3 +160,90 @@ def test_gallery_sharded_match_gloo_world2(tmp_path):
                         "127.0.0.1", "--master-port", "29633", str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count("ok") == 2
+
+
+_HOOK_SCRIPT = textwrap.dedent("""
+    import sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import pets_face_recognition_amd.models as M
+    from pets_face_recognition_amd.models._fe_engine import flat_layout, grad_ready_marks
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    from pets_face_recognition_amd.engine.ddp import FlatDDP
+
+    torch.manual_seed(50 + rank)
+    m = M.resnet50(); m.fc = torch.nn.Linear(2048, 512)
+    ml = SoftmaxBasedMetricLearning(m, 300, 512, is_focal=True, arc_margin=True)
+    offs, total = flat_layout(m)
+    marks = grad_ready_marks(m)
+    assert marks[0] == offs['fc.weight'] and marks[-1] == 0 and all(a > b for a, b in zip(marks, marks[1:])), marks
+    assert len(marks) == 1 + 16 + 1
+
+    class FakeEngine:                       # what FlatDDP touches of an FEEngine: flat buffers + the grad-ready hook
+        def __init__(self):
+            self.master = torch.full((total,), float(rank + 1))
+            self.grad = torch.zeros(total)
+            self.stats = torch.full((64,), float(rank))
+            self.nbt = torch.zeros(1, dtype=torch.int64)
+            self.grad_ready_hook = None
+    eng = FakeEngine()
+    m.hip_engine = lambda device=None: eng
+    ddp = FlatDDP(ml, bucket_mb=25)
+    assert torch.all(eng.master == 1.0) and torch.all(eng.stats == 0.0)           # rank 0's replica everywhere
+    w_all = [torch.zeros_like(ml.add_margin.weight) for _ in range(world)]
+    dist.all_gather(w_all, ml.add_margin.weight.data)
+    assert torch.equal(w_all[0], w_all[1])
+    # event log: every collective with the gradient-final mark that was current when it was launched
+    log, cur = [], [total]
+    r = ddp.reducer
+    orig = r.reduce_tensor
+    def spy(view, lo=0, hi=0):
+        log.append(('head',) if (lo == 0 and hi == 0) else ('bucket', lo, hi, cur[0]))
+        return orig(view, lo, hi)
+    r.reduce_tensor = spy
+    for step in range(2):
+        log.clear(); cur[0] = total
+        eng.grad.zero_()
+        ml.add_margin.weight.grad = None
+        # head first (its gradient is complete before the backbone's backward starts) ...
+        (ml.add_margin.weight * float(rank + 1)).sum().backward()
+        # ... then the backbone: the engine finishes the flat buffer back to front and reports each mark
+        hi = total
+        for off in marks:
+            eng.grad[off:hi] = torch.arange(off, hi, dtype=torch.float32) * (rank + 1)
+            cur[0] = off
+            eng.grad_ready_hook(off)
+            hi = off
+        ddp.finish_backward()
+        assert log[0] == ('head',), log[:2]
+        buckets = [e for e in log if e[0] == 'bucket']
+        # only final data is sent; ranges tile [0, total) exactly once, back to front
+        assert all(lo >= mark for _, lo, _, mark in buckets), buckets
+        assert buckets[0][2] == total and buckets[-1][1] == 0
+        assert all(a[1] == b[2] for a, b in zip(buckets, buckets[1:])), buckets
+        assert 4 <= len(buckets) <= 6, len(buckets)             # ~25 MB buckets of a 98 MB buffer
+        mean = sum(range(1, world + 1)) / world
+        assert torch.allclose(eng.grad, torch.arange(total, dtype=torch.float32) * mean)
+        assert torch.allclose(ml.add_margin.weight.grad, torch.full_like(ml.add_margin.weight, mean))
+    # a model that got a new engine must be detected, not silently skipped
+    eng2 = FakeEngine(); m.hip_engine = lambda device=None: eng2
+    try:
+        ddp.finish_backward(); raise SystemExit('stale engine not detected')
+    except RuntimeError:
+        pass
+    dist.destroy_process_group()
+    print('rank', rank, 'ok')
+""")
+
+
+def test_flat_ddp_hook_ordering_gloo_world2(tmp_path):
+    """FlatDDP (the class that runs on the MI355X node) driven on CPU/gloo with world size 2 by a fake engine that reports the
+    REAL ResNet-50 grad-ready marks: head all-reduce first, buckets cover every element exactly once with final data only,
+    result = mean over ranks, stale-engine detection.  Reference: /root/reference/utils/__init__.py:114-119."""
+    script = tmp_path / "hook_check.py"
+    script.write_text(_HOOK_SCRIPT.format(root=ROOT))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29637", str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("ok") == 2
