@@ -37,6 +37,11 @@ typedef void* pfr_stream_t; /* hipStream_t */
 const char* pfr_last_error(void);
 int pfr_version(void);
 int pfr_device_arch(char* buf, int buflen);
+/* Run-time tuning knobs (the values the PFR_* environment variables set at start-up), for A/B sweeps inside one process and
+ * for pinning a kernel choice: "igemm_p" 0 = one tile per workgroup only, 1 = heuristic (default), 2 = persistent kernel
+ * whenever the geometry is eligible; "igemm_ptile" -1 heuristic / 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64 (rows x couts).
+ * Results do not depend on the knobs (same accumulation order); statistics-partial granularity follows pfr_conv2d_mtile. */
+int pfr_set_tuning(const char* key, int value);
 
 /* ---- convolution / linear (implicit GEMM on MFMA) -------------------------------------------------------
  * pfr_conv2d_fwd replaces nn.Conv2d.forward / nn.Linear.forward / F.linear of the backbone and head
@@ -48,8 +53,9 @@ int pfr_device_arch(char* buf, int buflen);
  *   accumulate: y += result; out_relu: y = max(y,0)
  *   pro_scale/pro_shift [C] fp32 or NULL: operand is relu?(scale[c]*x + shift[c]) (fused BN-apply of the producer)
  *   stats_part or NULL: fp32 [ceil(M/mtile)][2][Cout] per-channel (mean, M2 = Σ(y-mean)²) of each m-tile of the stored y,
- *   mtile = pfr_conv2d_mtile(M, Cout, R*S*C, dtype, out_dtype)  (input of pfr_bn_finalize; deterministic, no atomics). */
-int pfr_conv2d_mtile(int M, int Cout, int K, int dtype, int out_dtype); /* K = R*S*C */
+ *   mtile = pfr_conv2d_mtile(M, Cout, R*S*C, C, dtype, out_dtype, pro_scale != 0)  (input of pfr_bn_finalize; deterministic, no atomics):
+ *   the m-tile height of the kernel that takes this geometry, or half of it for the persistent kernel (one partial per wave row). */
+int pfr_conv2d_mtile(int M, int Cout, int K, int C, int dtype, int out_dtype, int fused_prologue); /* K = R*S*C */
 int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W, int C,
                    int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int ldy,
                    const float* bias, const void* residual, int accumulate, int out_relu, const float* pro_scale,

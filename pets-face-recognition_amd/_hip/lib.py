@@ -13,7 +13,7 @@ PFR_F32, PFR_BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "csrc", "libpfr_hip.so")
+LIB_PATH = os.environ.get("PFR_LIB_PATH") or os.path.join(_PKG, "csrc", "libpfr_hip.so")   # (override: profiling builds)
 HEADER_PATH = os.path.join(_ROOT, "include", "pfr_hip.h")
 
 

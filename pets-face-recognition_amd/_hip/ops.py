@@ -49,7 +49,7 @@ def conv2d_fwd(x, w, stride=1, pad=0, idil_log2=0, out_hw=None, out=None, out_dt
     M = N * OH * OW
     part = None
     if stats:
-        mt = lib.pfr_conv2d_mtile(M, Cout, R * S * C, dtype_id(x.dtype), dtype_id(out.dtype))
+        mt = lib.pfr_conv2d_mtile(M, Cout, R * S * C, C, dtype_id(x.dtype), dtype_id(out.dtype), int(pro is not None))
         nt = (M + mt - 1) // mt
         part = stats_buf if stats_buf is not None else torch.empty((nt, 2, Cout), dtype=torch.float32, device=x.device)
         assert part.numel() >= nt * 2 * Cout

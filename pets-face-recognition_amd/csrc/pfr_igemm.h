@@ -1,0 +1,44 @@
+// pfr_igemm.h — parameter block shared by the implicit-GEMM kernels (pfr_igemm.hip: one tile per workgroup;
+// pfr_igemm_p.hip: persistent workgroups with a DMA ring that streams across tile boundaries).
+#pragma once
+#include "pfr_mma.h"
+
+struct IgemmParams {
+  const void* x;
+  const void* w;
+  void* y;
+  int N, H, W, C;
+  int R, S, OH, OW, ostride, pad, idil_log2;
+  int Cout, ldy;
+  int M, K;
+  float* stats_part;  // [tilesM][2][Cout] (tile mean, tile M2) or nullptr
+  const float* bias;  // [Cout] or nullptr
+  const void* residual;  // [M][ldy] of TO or nullptr: y = result (+bias) + residual   (transformer residual streams)
+  int accumulate;
+  const float* pro_scale;  // [C] or nullptr
+  const float* pro_shift;
+  int pro_relu;
+  int out_relu;
+  int act;     // 0 none; 2: y2 = z (pre-activation), y = gelu(z); 3: y = z ∘ gelu'(y2)   (y2: [M][ldy] of TO; needs 16-B rows)
+               // 4: top-K filter (gallery match): nothing is stored; scores above the row's threshold key are appended
+               //    to the row's candidate list  (y = cand u64 [M][cap], y2 = thrk u32 [M])
+  void* y2;
+  int* ccnt;   // act 4: candidate counters [M]
+  const unsigned char* res_mask;   // optional bit mask of `residual` ([M][ldy / KPACK] bytes, pfr_bn_act_mask): masked-out elements add 0
+  int cap, col0, self_excl;   // act 4: list capacity, gallery index of column 0, skip column == row (all-vs-all evaluation)
+  FastDiv div_ohow, div_ow;
+  int tilesM, tilesN;
+  // parity-class mode (data gradient of a stride-2 conv, FAST path): output rows are processed per (oh%2, ow%2) class so
+  // that only the taps that exist for that class are visited (a 3x3/s2 dgrad does 9/4 instead of 9 taps per output).
+  int pclass, mclass, tpc;
+  FastDiv div_chw, div_cw;
+#ifdef PFR_IGEMM_TRACE
+  long long* trace;   // [grid][8] wall-clock stamps of workgroup phases (profiling builds only)
+  int dbg;            // 1: gather every tile from rows 0.. (L2-hot operands)   2: skip the output stores
+#endif
+};
+
+// persistent kernel (pfr_igemm_p.hip): returns PFR_OK when it took the launch, 1 when the geometry is not eligible
+int igemm_p_launch(IgemmParams& p, int dtype, int out_dtype, int bq, int bp, hipStream_t st);
+int igemm_p_enabled();
+int igemm_p_forced_tile();

@@ -16,43 +16,9 @@
 // transposed through LDS in the epilogue so that HBM stores are whole 16-byte row segments, per-channel
 // sum / sum-of-squares partials for the FOLLOWING train-mode BatchNorm produced from the same LDS tile
 // (deterministic: one partial row per m-tile, no atomics), XCD-aware tile order (n-tiles of one m-tile adjacent).
-#include "pfr_mma.h"
+#include "pfr_igemm.h"
 #include <stdlib.h>
 
-struct IgemmParams {
-  const void* x;
-  const void* w;
-  void* y;
-  int N, H, W, C;
-  int R, S, OH, OW, ostride, pad, idil_log2;
-  int Cout, ldy;
-  int M, K;
-  float* stats_part;  // [tilesM][2][Cout] (tile mean, tile M2) or nullptr
-  const float* bias;  // [Cout] or nullptr
-  const void* residual;  // [M][ldy] of TO or nullptr: y = result (+bias) + residual   (transformer residual streams)
-  int accumulate;
-  const float* pro_scale;  // [C] or nullptr
-  const float* pro_shift;
-  int pro_relu;
-  int out_relu;
-  int act;     // 0 none; 2: y2 = z (pre-activation), y = gelu(z); 3: y = z ∘ gelu'(y2)   (y2: [M][ldy] of TO; needs 16-B rows)
-               // 4: top-K filter (gallery match): nothing is stored; scores above the row's threshold key are appended
-               //    to the row's candidate list  (y = cand u64 [M][cap], y2 = thrk u32 [M])
-  void* y2;
-  int* ccnt;   // act 4: candidate counters [M]
-  const unsigned char* res_mask;   // optional bit mask of `residual` ([M][ldy / KPACK] bytes, pfr_bn_act_mask): masked-out elements add 0
-  int cap, col0, self_excl;   // act 4: list capacity, gallery index of column 0, skip column == row (all-vs-all evaluation)
-  FastDiv div_ohow, div_ow;
-  int tilesM, tilesN;
-  // parity-class mode (data gradient of a stride-2 conv, FAST path): output rows are processed per (oh%2, ow%2) class so
-  // that only the taps that exist for that class are visited (a 3x3/s2 dgrad does 9/4 instead of 9 taps per output).
-  int pclass, mclass, tpc;
-  FastDiv div_chw, div_cw;
-#ifdef PFR_IGEMM_TRACE
-  long long* trace;   // [grid][8] wall-clock stamps of workgroup phases (profiling builds only)
-  int dbg;            // 1: gather every tile from rows 0.. (L2-hot operands)   2: skip the output stores
-#endif
-};
 #ifdef PFR_IGEMM_TRACE
 static long long* g_igemm_trace = nullptr;
 static int g_igemm_dbg = 0;
@@ -624,9 +590,34 @@ static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) 
   return b == 128 ? TILE_128x64 : TILE_64x64;
 }
 
+// Persistent kernel (pfr_igemm_p.hip) or one tile per workgroup?  PFR_IGEMM_P: 0 never, 1 heuristic (default), 2 whenever
+// eligible.  Returns 1 and the persistent tile in (*bq, *bp) when the persistent kernel takes the launch.
+static int pick_persistent(int M, int Cout, int K, int C, int dtype, int out_dtype, int has_pro, int act, int pclass, int* bq, int* bp) {
+  const int mode = igemm_p_enabled();
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  if (mode == 0 || C % (4 * kp) != 0 || has_pro || act == 4) return 0;
+  const int forced = igemm_p_forced_tile();   // 0:128x128 1:64x128 2:128x64 3:64x64 (PFR_IGEMM_PTILE / pfr_set_tuning)
+  int q, pcols = Cout > 64 ? 128 : 64;
+  const long tiles128 = (long)((M + 127) / 128) * ((Cout + pcols - 1) / pcols);
+  q = tiles128 >= 1024 ? 128 : 64;   // at least ~2 tiles per persistent workgroup, else halve the tile height
+  if (forced >= 0) { q = (forced == 0 || forced == 2) ? 128 : 64; pcols = (forced == 0 || forced == 1) ? 128 : 64; }
+  *bq = q; *bp = pcols;
+  if (mode >= 2) return 1;
+  // Heuristic from the per-layer A/B (tools/gemm_ab.py, profiles/r02_gemm_ab.json).  Both kernels are bound by the same
+  // resource — the vector-memory path into LDS (~24 B/clk/CU of LDS-DMA + stores) — and tie within +-5 % on
+  // most ResNet-50 geometries; the persistent kernel wins clearly (1.3-1.5x) on the parity-class data gradients of the
+  // stride-2 3x3 convs, whose four classes have different reduction lengths (one tile per workgroup leaves the short ones idle).
+  return pclass ? 1 : 0;
+}
+
 template <typename T, typename TO>
 static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
-  int bq;
+  int bq, bp;
+  const int pcl = (p.idil_log2 == 1 && p.ostride == 1 && p.R > 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part) ? 1 : 0;
+  if (pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp)) {
+    const int rc = igemm_p_launch(p, dtype, out_dtype, bq, bp, st);
+    if (rc != 1) return rc;
+  }
   const int v = pick_tile(p.M, p.Cout, p.K, dtype, out_dtype, &bq);
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
     if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 8, 8, 2>(p, st);
@@ -640,8 +631,13 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
   }
 }
 
-extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int dtype, int out_dtype) {
-  int bq;
+// rows per BatchNorm-statistics partial of a convolution launch with this geometry (the caller sizes stats_part with it):
+// the m-tile height, or half of it when the persistent kernel (one partial per wave row) takes the launch
+extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int C, int dtype, int out_dtype, int fused_prologue) {
+  int bq, bp;
+  // (statistics and the parity-class mode exclude each other, so the heuristic never picks the persistent kernel for a
+  //  launch that publishes statistics; PFR_IGEMM_P=2 does)
+  if (pick_persistent(M, Cout, K, C, dtype, out_dtype, fused_prologue, 0, 0, &bq, &bp)) return bq / 2;
   pick_tile(M, Cout, K, dtype, out_dtype, &bq);
   return bq;
 }

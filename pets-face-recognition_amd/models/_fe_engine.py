@@ -453,8 +453,8 @@ class FEEngine:
                                          0 if bias is None else bias.data_ptr(), 0, accumulate, 0, ps, psh, prelu,
                                          0 if part is None else part.data_ptr())))
 
-    def _stats_buf(self, plan, M, Cout, K):
-        mt = lib.pfr_conv2d_mtile(M, Cout, K, self.did, self.did)
+    def _stats_buf(self, plan, M, Cout, K, C, pro=False):
+        mt = lib.pfr_conv2d_mtile(M, Cout, K, C, self.did, self.did, int(pro))
         nt = (M + mt - 1) // mt
         return self._A(plan, (nt, 2, Cout), torch.float32), nt, mt
 
@@ -478,7 +478,7 @@ class FEEngine:
         y = self._A(plan, (N, OH, OW, c.Cout))
         part, nt, mt = (None, 0, 0)
         if train:
-            part, nt, mt = self._stats_buf(plan, N * OH * OW, c.Cout, c.R * c.S * C)
+            part, nt, mt = self._stats_buf(plan, N * OH * OW, c.Cout, c.R * c.S * C, C, pro is not None)
         self._conv_fwd(ops, x, xshape, w if w is not None else c.w, y, c, c.stride, c.pad, OH, OW, pro=pro, part=part)
         self._bn_fwd(ops, bn, part, nt, N * OH * OW, train, mt)
         return y, (N, OH, OW, c.Cout)

@@ -74,7 +74,7 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     # fused per-channel statistics (per-m-tile mean / M2, merged by pfr_bn_finalize) of the stored output
     from pets_face_recognition_amd._hip import lib
     M = yd.numel() // Cout
-    coef = o.bn_finalize(part, lib.pfr_conv2d_mtile(M, Cout, R * R * C, 0 if dtype == torch.float32 else 1, 0 if dtype == torch.float32 else 1), M, None, None, 1e-5, 0.1, None, None)
+    coef = o.bn_finalize(part, lib.pfr_conv2d_mtile(M, Cout, R * R * C, C, 0 if dtype == torch.float32 else 1, 0 if dtype == torch.float32 else 1, 0), M, None, None, 1e-5, 0.1, None, None)
     torch.cuda.synchronize()
     ydf = yd.double().cpu().reshape(-1, Cout)
     assert torch.allclose(coef[0].cpu().double(), ydf.mean(0), rtol=1e-4, atol=1e-5)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Profiling build of the kernel library (-DPFR_IGEMM_TRACE: workgroup phase stamps in the GEMM kernels) next to the product
+# one: pets-face-recognition_amd/csrc/libpfr_hip_trace.so; use with PFR_LIB_PATH=<that file> python tools/p_trace.py
+set -e
+cd "$(dirname "$0")/../pets-face-recognition_amd/csrc"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast -DPFR_IGEMM_TRACE"
+mkdir -p build_trace
+pids=()
+for f in pfr_api pfr_igemm pfr_igemm_p pfr_wgrad pfr_elementwise pfr_head pfr_match pfr_swin; do
+  if [ ! -f build_trace/$f.o ] || [ $f.hip -nt build_trace/$f.o ] || [ pfr_igemm.h -nt build_trace/$f.o ] || [ pfr_mma.h -nt build_trace/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o build_trace/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC build_trace/*.o -o libpfr_hip_trace.so
+echo "built $(pwd)/libpfr_hip_trace.so"
