@@ -42,3 +42,7 @@ struct IgemmParams {
 int igemm_p_launch(IgemmParams& p, int dtype, int out_dtype, int bq, int bp, hipStream_t st);
 int igemm_p_enabled();
 int igemm_p_forced_tile();
+// parity-class mode of the persistent kernel: data gradient of a stride-2 conv (input dilation 1 << 1) over even output sizes
+static inline bool igemm_pclass_ok(const IgemmParams& p) {
+  return p.idil_log2 == 1 && p.ostride == 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part;
+}

@@ -613,7 +613,7 @@ static int pick_persistent(int M, int Cout, int K, int C, int dtype, int out_dty
 template <typename T, typename TO>
 static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   int bq, bp;
-  const int pcl = (p.idil_log2 == 1 && p.ostride == 1 && p.R > 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part) ? 1 : 0;
+  const int pcl = igemm_pclass_ok(p) ? 1 : 0;
   if (pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp)) {
     const int rc = igemm_p_launch(p, dtype, out_dtype, bq, bp, st);
     if (rc != 1) return rc;

@@ -182,6 +182,17 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
     tapbyte = (u_tr * p.S + u_ts) * p.C * (int)sizeof(T);
     newtap();
   };
+  // moves the loader to its next tile that has k-steps (parity classes of a 1x1 / stride-2 data gradient other than (0,0) have
+  // none: their outputs are zeros) or marks it done
+  auto l_next = [&]() {
+    for (;;) {
+      ++lr;
+      const int t = tile_of(lr);
+      if (t < 0) { ldone = true; return; }
+      l_begin(t);
+      if (l_nk > 0) return;
+    }
+  };
   // issues the LDS-DMA of the loader's next k-step into ring slot `buf`, then advances (possibly into the next tile)
   auto gload = [&](int buf) {
     char* base = smem + buf * STAGE;
@@ -199,9 +210,7 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
                                                16, (int)(qbase[j] + (uint32_t)cbyte), 0, 0, 0);
     }
     if (--l_nk == 0) {
-      ++lr;
-      const int t = tile_of(lr);
-      if (t >= 0) l_begin(t); else ldone = true;
+      l_next();
       return;
     }
     cbyte += BK * (int)sizeof(T);
@@ -218,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
     const int t0 = tile_of(0);
     if (t0 < 0) return;
     l_begin(t0);
+    if (l_nk == 0) l_next();
   }
   int inflight = 0, slot_l = 0, slot_c = 0;
 #ifdef PFR_IGEMM_TRACE
@@ -605,12 +615,15 @@ extern "C" int pfr_set_tuning(const char* key, int value) {
 
 template <typename T, typename TO, int BQ, int BP>
 static int launch_p(IgemmParams& p, hipStream_t st) {
-  p.pclass = (p.idil_log2 == 1 && p.ostride == 1 && p.R > 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part) ? 1 : 0;
+  p.pclass = igemm_pclass_ok(p) ? 1 : 0;
   p.mclass = p.N * (p.OH / 2) * (p.OW / 2);
   p.tpc = (p.mclass + BQ - 1) / BQ;
   p.div_chw = make_fastdiv((uint32_t)((p.OH / 2) * (p.OW / 2) > 0 ? (p.OH / 2) * (p.OW / 2) : 1));
   p.div_cw = make_fastdiv((uint32_t)(p.OW / 2 > 0 ? p.OW / 2 : 1));
-  p.tilesM = p.pclass ? 4 * p.tpc : (p.M + BQ - 1) / BQ;
+  // a 1x1 / stride-2 data gradient only has taps for class (0,0): when it ACCUMULATES into dx the other three classes
+  // (which would add zeros) are not visited at all; otherwise they just store zeros (no k-steps)
+  const int ncls = (p.pclass && p.R == 1 && p.S == 1 && p.accumulate && !p.bias && !p.residual && !p.out_relu && !p.act) ? 1 : 4;
+  p.tilesM = p.pclass ? ncls * p.tpc : (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
   const int total = p.tilesM * p.tilesN;
   const int grid = total < 2 * num_cus() ? total : 2 * num_cus();

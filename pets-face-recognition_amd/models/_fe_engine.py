@@ -682,9 +682,11 @@ class FEEngine:
                 bn_bwd(dcur, rmask, cd, oshape, dbn, 3, dgd, None, acc)      # projection-shortcut BN: g = dcur ∘ mask
                 release(dcur)
                 wgrad(xin, xshape, dgd, oshape, dc)
-                dgrad(dgd, oshape, dc, dxin, xshape)
+                # main branch first (writes all of dxin), then the projection shortcut ACCUMULATES: for its 1x1 / stride-2
+                # conv only the (even, even) positions of dxin receive anything, and only those rows are touched
+                dgrad(dy, dyshape, c0, dxin, xshape)
+                dgrad(dgd, oshape, dc, dxin, xshape, accumulate=1)
                 release(dgd)
-                dgrad(dy, dyshape, c0, dxin, xshape, accumulate=1)
             else:
                 # identity shortcut: dxin = dgrad(conv1) + dcur ∘ mask in the data-gradient epilogue
                 log2 = {1: 0, 2: 1}[c0.stride]

@@ -368,3 +368,30 @@ def test_stem_space_to_depth_exact(dtype):
     assert rel_err(yh.cpu().double().permute(0, 3, 1, 2), y.detach()) < t
     assert rel_err(dw.cpu().double(), wr.grad.permute(0, 2, 3, 1)) < t
     assert torch.allclose(dw2, 2 * dw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,H,C,Cout", [(1, 16, 64, 128), (1, 12, 96, 64), (3, 16, 64, 64), (3, 10, 32, 96)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_strided_dgrad_parity_classes(dtype, R, H, C, Cout, accumulate):
+    """Data gradient of stride-2 convs (3x3/pad 1 and the 1x1 projection shortcut, torchvision resnet downsample) through the
+    parity-class path of the persistent kernel: per (oh%2, ow%2) class only the taps that exist; for a 1x1 kernel only class
+    (0,0) has any — with accumulate the other classes are not visited, without they store zeros.  Also odd tile counts."""
+    o = ops()
+    g = torch.Generator().manual_seed(R * 100 + H)
+    N, pad = 3, (R - 1) // 2
+    x = torch.randn(N, C, H, H, generator=g, requires_grad=True)
+    w = torch.randn(Cout, C, R, R, generator=g) / (C * R * R) ** 0.5
+    dx0 = torch.randn(N, C, H, H, generator=g)
+    OH = (H + 2 * pad - R) // 2 + 1
+    dy = torch.randn(N, Cout, OH, OH, generator=g)
+    if dtype == torch.bfloat16:
+        w, dy, dx0 = w.bfloat16().float(), dy.bfloat16().float(), dx0.bfloat16().float()
+    F.conv2d(x, w, stride=2, padding=pad).backward(dy)
+    ref = x.grad + (dx0 if accumulate else 0)
+    wt = o.weight_dgrad_layout(w.permute(0, 2, 3, 1).contiguous().to(DEV, dtype))
+    out = nhwc(dx0).to(DEV, dtype) if accumulate else torch.full((N, H, H, C), float("nan"), device=DEV, dtype=dtype)
+    o.conv2d_dgrad(nhwc(dy).to(DEV, dtype), wt, (H, H), 2, pad, R, R, out=out, accumulate=accumulate)
+    torch.cuda.synchronize()
+    e = rel_err(out.cpu(), nhwc(ref))
+    assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), e
