@@ -69,6 +69,21 @@ int pfr_conv2d_dgrad_join(const void* dy, const void* wt, void* dx, int dtype, i
                           int S, int pad, int idil_log2, int OH, int OW, const void* res, const unsigned char* res_mask,
                           pfr_stream_t stream);
 
+/* Data gradient that ALSO produces the BatchNorm-backward partial sums of the BN layer(s) whose OUTPUT gradient dx is (replaces
+ * pfr_bn_bwd_reduce's pass over the gradient and the BN input; reference: autograd of nn.BatchNorm2d + ReLU after the conv,
+ * torchvision resnet Bottleneck.forward).  part[t][0][c] = sum g*mask, part[t][1][c] = sum g*mask*xhat over the rows of m-tile t,
+ * g = the value stored to dx, xhat = (x - mean)*invstd; mask = bn_mask bits ([M][Cout/KPACK] bytes of pfr_bn_act_mask) when given,
+ * else scale*x + shift > 0.  bn_coef = [4][Cout] (mean, invstd, scale, shift rows, as pfr_bn_finalize writes them); bn2_* = an
+ * optional second BN consuming the same gradient through the same bit mask (projection shortcut).  res/res_mask = the residual
+ * join of pfr_conv2d_dgrad_join (both or neither), accumulate adds into dx.  pfr_conv2d_dgrad_bn_parts -> number of partial
+ * rows per BN for the geometry (feed pfr_bn_bwd_finalize with it), or 0 when the fused form does not apply (run
+ * pfr_bn_bwd_reduce instead). */
+int pfr_conv2d_dgrad_bn_parts(int dtype, int N, int H, int W, int C, int Cout, int R, int S, int idil_log2, int OH, int OW);
+int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int R, int S,
+                        int pad, int idil_log2, int OH, int OW, const void* res, const unsigned char* res_mask, int accumulate,
+                        const void* bn_x, const float* bn_coef, const unsigned char* bn_mask, float* bn_part, const void* bn2_x,
+                        const float* bn2_coef, float* bn2_part, pfr_stream_t stream);
+
 /* pfr_conv2d_wgrad replaces the autograd weight gradient of nn.Conv2d / nn.Linear / F.linear:
  *   dw[co][r][s][c] (fp32) = scale * sum_m dy[m][co] * act(x)[...]  (+ dw if accumulate)
  * workspace: fp32 [pfr_conv2d_wgrad_splits(M,Cout,R*S*C)][Cout][R*S*C] (may be NULL when splits == 1). */

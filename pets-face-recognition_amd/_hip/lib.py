@@ -103,6 +103,7 @@ class _Lib:
                 if rc != 0:
                     raise PfrError(f"{_name} failed (rc={rc}): {self._dll.pfr_last_error().decode()}")
                 return rc
+            checked.__name__ = name
             setattr(self, name, checked)
             return checked
         setattr(self, name, fn)
@@ -114,7 +115,7 @@ class _Lib:
 
 
 # queries that return a value rather than an error code
-_NO_CHECK = {"pfr_version", "pfr_bn_stats_rows_per_part", "pfr_bn_finalize_ws_floats", "pfr_topk_state_bytes", "pfr_layernorm_bwd_blocks", "pfr_window_bias_table_floats", "pfr_colsum_ws_floats", "pfr_conv2d_mtile", "pfr_conv2d_wgrad_splits", "pfr_colreduce_blocks", "pfr_match_ws_bytes"}
+_NO_CHECK = {"pfr_version", "pfr_bn_stats_rows_per_part", "pfr_bn_finalize_ws_floats", "pfr_topk_state_bytes", "pfr_layernorm_bwd_blocks", "pfr_window_bias_table_floats", "pfr_colsum_ws_floats", "pfr_conv2d_mtile", "pfr_conv2d_dgrad_bn_parts", "pfr_conv2d_wgrad_splits", "pfr_colreduce_blocks", "pfr_match_ws_bytes"}
 
 lib = _Lib()
 

@@ -32,6 +32,15 @@ struct IgemmParams {
   // that only the taps that exist for that class are visited (a 3x3/s2 dgrad does 9/4 instead of 9 taps per output).
   int pclass, mclass, tpc;
   FastDiv div_chw, div_cw;
+  // BatchNorm-backward partial sums fused into the epilogue of the launch that PRODUCES the gradient g of a BN output
+  // (replaces pfr_bn_bwd_reduce's pass over g and x): for up to two BN layers that consume g (a block's last BN and the BN
+  // of its projection shortcut), x = that BN's input [M][ldy] of TO, coef = its [4][Cout] (mean, invstd, scale, shift),
+  // part = [tilesM][2][Cout]: Σ g·mask and Σ g·mask·x̂ over the tile's rows.  mask: bit mask bnb_mask ([M][ldy / KPACK]) when
+  // given, else scale·x + shift > 0 of set 0.
+  const void* bnb_x[2];
+  const float* bnb_coef[2];
+  float* bnb_part[2];
+  const unsigned char* bnb_mask;
 #ifdef PFR_IGEMM_TRACE
   long long* trace;   // [grid][8] wall-clock stamps of workgroup phases (profiling builds only)
   int dbg;            // 1: gather every tile from rows 0.. (L2-hot operands)   2: skip the output stores

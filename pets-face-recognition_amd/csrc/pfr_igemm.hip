@@ -40,8 +40,8 @@ extern "C" void pfr_debug_igemm_flags(int f) { g_igemm_dbg = f; }
 #define PFR_IGEMM_NST 2
 #endif
 
-template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_, bool FILT = false>
-__global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && sizeof(T) == 2) ? PFR_IGEMM_OCC4 : 1) void igemm_kernel(IgemmParams p) {
+template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_, bool FILT = false, bool BNB = false>
+__global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && sizeof(T) == 2) ? (BNB ? 2 : PFR_IGEMM_OCC4) : 1) void igemm_kernel(IgemmParams p) {
   constexpr int KP = DT<T>::KPACK;
   constexpr int KCH = KCH_;                    // 16-byte chunks per LDS row per k-step (4: 64-B rows, 8: 128-B rows)
   constexpr int ROWB = KCH * 16;
@@ -400,6 +400,27 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   }
   const bool vec_ok = (co + KPO <= p.Cout) && ((p.ldy * (int)sizeof(TO)) % 16 == 0);
   char* yb = reinterpret_cast<char*>(p.y);
+  // BN-backward partial sums (BNB): x̂ = x·ca + cb with ca = invstd, cb = −mean·invstd
+  float bs1[2][KPO], bs2[2][KPO], bca[2][KPO], bcb[2][KPO], bsc[KPO], bsh[KPO];
+  if constexpr (BNB) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < KPO; ++e) {
+        bs1[q][e] = 0.f; bs2[q][e] = 0.f; bca[q][e] = 0.f; bcb[q][e] = 0.f;
+        if (p.bnb_part[q] && co + e < p.Cout) {
+          const float mu = p.bnb_coef[q][co + e], is = p.bnb_coef[q][p.Cout + co + e];
+          bca[q][e] = is;
+          bcb[q][e] = -mu * is;
+        }
+      }
+#pragma unroll
+    for (int e = 0; e < KPO; ++e) {
+      const bool need = !p.bnb_mask && co + e < p.Cout;
+      bsc[e] = need ? p.bnb_coef[0][2 * p.Cout + co + e] : 0.f;
+      bsh[e] = need ? p.bnb_coef[0][3 * p.Cout + co + e] : 0.f;
+    }
+  }
 #pragma unroll 4
   for (int rr = rl; rr < BQ; rr += RPP) {
     int m = m0 + rr;
@@ -475,6 +496,23 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
         s2[e] = fmaf(d, d, s2[e]);
       }
     }
+    if constexpr (BNB) {
+      const size_t eo = ((size_t)m * p.ldy + co) * sizeof(TO);
+      const unsigned bits = p.bnb_mask ? p.bnb_mask[(size_t)m * (p.ldy / KPO) + co / KPO] : 0u;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (!p.bnb_part[q]) continue;
+        float xv[KPO];
+        Chunk<TO>::unpack(ld16(reinterpret_cast<const char*>(p.bnb_x[q]) + eo), xv);
+#pragma unroll
+        for (int e = 0; e < KPO; ++e) {
+          const bool keep = p.bnb_mask ? ((bits >> e) & 1u) : (fmaf(xv[e], bsc[e], bsh[e]) > 0.f);
+          const float gg = keep ? f[e] : 0.f;
+          bs1[q][e] += gg;
+          bs2[q][e] = fmaf(gg, fmaf(xv[e], bca[q][e], bcb[q][e]), bs2[q][e]);
+        }
+      }
+    }
 #ifdef PFR_IGEMM_TRACE
     if (p.dbg & 2) continue;
 #endif
@@ -520,6 +558,41 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       p.stats_part[((size_t)tm * 2 + 1) * p.Cout + n0 + ch] = b - a * a / nt;      // tile M2 = Σ (x − mean_t)²
     }
   }
+  if constexpr (BNB) {
+    float* red = reinterpret_cast<float*>(smem + EPI);  // [NW waves][2][BP]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!p.bnb_part[q]) continue;   // (uniform)
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < KPO; ++e) {
+          bs1[q][e] += __shfl_xor(bs1[q][e], o, 64);
+          bs2[q][e] += __shfl_xor(bs2[q][e], o, 64);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // the previous set's readers are done with `red`
+      if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < KPO; ++e) {
+          red[(wave * 2 + 0) * BP + oc * KPO + e] = bs1[q][e];
+          red[(wave * 2 + 1) * BP + oc * KPO + e] = bs2[q][e];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid < BP && n0 + tid < p.Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          a += red[(w * 2 + 0) * BP + tid];
+          b += red[(w * 2 + 1) * BP + tid];
+        }
+        p.bnb_part[q][((size_t)tm * 2 + 0) * p.Cout + n0 + tid] = a;
+        p.bnb_part[q][((size_t)tm * 2 + 1) * p.Cout + n0 + tid] = b;
+      }
+    }
+  }
   TSTAMP(6);
 }
 
@@ -527,7 +600,8 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
 template <typename T, typename TO, int BQ, int BP, int KCH, int NW, int WP, int NST = 2>
 static int launch_tile_k(IgemmParams& p, hipStream_t st) {
   const bool fast = (p.C % (KCH * DT<T>::KPACK)) == 0;
-  p.pclass = (fast && p.idil_log2 == 1 && p.ostride == 1 && p.R > 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part) ? 1 : 0;
+  p.pclass = (fast && p.idil_log2 == 1 && p.ostride == 1 && p.R > 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part &&
+              !p.bnb_part[0]) ? 1 : 0;
   p.mclass = p.N * (p.OH / 2) * (p.OW / 2);
   p.tpc = (p.mclass + BQ - 1) / BQ;
   p.div_chw = make_fastdiv((uint32_t)((p.OH / 2) * (p.OW / 2) > 0 ? (p.OH / 2) * (p.OW / 2) : 1));
@@ -539,6 +613,14 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
     if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, true, KCH, NW, WP, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, false, KCH, NW, WP, 2>), grid, block, 0, st, p);
   } else {
+    if constexpr (sizeof(T) == sizeof(TO)) {
+      if (p.bnb_part[0]) {
+        if (!fast || p.pclass) { pfr_set_error("conv2d: BN-backward sums need the k-step-uniform, non-parity-class path"); return PFR_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true, KCH, NW, WP, NST, false, true>), grid, block, 0, st, p);
+        PFR_CHECK_LAUNCH();
+        return PFR_OK;
+      }
+    }
     if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true, KCH, NW, WP, NST>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, false, KCH, NW, WP, NST>), grid, block, 0, st, p);
   }
@@ -614,7 +696,7 @@ template <typename T, typename TO>
 static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   int bq, bp;
   const int pcl = igemm_pclass_ok(p) ? 1 : 0;
-  if (pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp)) {
+  if (!p.bnb_part[0] && pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp)) {
     const int rc = igemm_p_launch(p, dtype, out_dtype, bq, bp, st);
     if (rc != 1) return rc;
   }
@@ -642,11 +724,17 @@ extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int C, int dtype, int ou
   return bq;
 }
 
+struct BnbArgs {
+  const void* x[2];
+  const float* coef[2];
+  float* part[2];
+  const unsigned char* mask;
+};
 static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
                            int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
                            int ldy, const float* bias, const void* residual, int accumulate, int out_relu,
                            const float* pro_scale, const float* pro_shift, int pro_relu, float* stats_part,
-                           const unsigned char* res_mask, hipStream_t stream);
+                           const unsigned char* res_mask, hipStream_t stream, const BnbArgs* bnb = nullptr);
 extern "C" int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
                               int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
                               int ldy, const float* bias, const void* residual, int accumulate, int out_relu,
@@ -665,11 +753,51 @@ extern "C" int pfr_conv2d_dgrad_join(const void* dy, const void* wt, void* dx, i
   return conv2d_fwd_impl(dy, wt, dx, dtype, dtype, N, H, W, C, Cout, R, S, 1, pad, idil_log2, OH, OW, Cout, nullptr, res, 0, 0,
                          nullptr, nullptr, 0, nullptr, res_mask, stream);
 }
+// Number of [2][Cin] partial rows pfr_conv2d_dgrad_bn writes per BN layer for this geometry (= m-tiles of the launch), or 0
+// when the fused form is not available for it (the parity-class data gradients of stride-2 convs on even extents, channel
+// counts that are not k-step multiples): the caller then runs pfr_bn_bwd_reduce on the finished gradient instead.
+extern "C" int pfr_conv2d_dgrad_bn_parts(int dtype, int N, int H, int W, int C, int Cout, int R, int S, int idil_log2, int OH,
+                                         int OW) {
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  if (C % (4 * kp) != 0 || Cout % kp != 0) return 0;
+  if (idil_log2 == 1 && (OH % 2) == 0 && (OW % 2) == 0) return 0;
+  int bq;
+  const int M = N * OH * OW;
+  const int v = pick_tile(M, Cout, R * S * C, dtype, dtype, &bq);
+  if ((v == TILE_256x256 || v == TILE_256x128) && C % 64 != 0) return 0;
+  (void)H; (void)W;
+  return (M + bq - 1) / bq;
+}
+
+// Data gradient (as pfr_conv2d_fwd over dy with tap-flipped weights; optional residual join `res` through `res_mask`, optional
+// accumulation into dx) that ALSO produces the BatchNorm-backward partial sums of the BN layer(s) whose output gradient dx is:
+//   part[t][0][c] = Σ_rows-of-tile-t g·mask,  part[t][1][c] = Σ g·mask·x̂,   g = the value stored to dx, x̂ = (x − mean)·invstd,
+// mask = bit mask `bn_mask` ([M][Cout/KPACK] bytes, pfr_bn_act_mask) when given, else scale·x + shift > 0 (coef rows 2, 3).
+// bn_x / bn_coef ([4][Cout]: mean, invstd, scale, shift) / bn_part describe the first BN, bn2_* an optional second one that
+// consumes the same gradient through the same mask (projection shortcut).  Replaces pfr_bn_bwd_reduce's pass over (g, x).
+extern "C" int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout,
+                                   int R, int S, int pad, int idil_log2, int OH, int OW, const void* res,
+                                   const unsigned char* res_mask, int accumulate, const void* bn_x, const float* bn_coef,
+                                   const unsigned char* bn_mask, float* bn_part, const void* bn2_x, const float* bn2_coef,
+                                   float* bn2_part, hipStream_t stream) {
+  PFR_CHECK_ARG(bn_x && bn_coef && bn_part, "pfr_conv2d_dgrad_bn: null pointer");
+  PFR_CHECK_ARG(!bn2_part || (bn2_x && bn2_coef && bn_mask), "pfr_conv2d_dgrad_bn: the second BN needs x, coef and the shared bit mask");
+  PFR_CHECK_ARG((res == nullptr) == (res_mask == nullptr), "pfr_conv2d_dgrad_bn: res and res_mask go together");
+  PFR_CHECK_ARG(pfr_conv2d_dgrad_bn_parts(dtype, N, H, W, C, Cout, R, S, idil_log2, OH, OW) > 0,
+                "pfr_conv2d_dgrad_bn: geometry not supported by the fused form (see pfr_conv2d_dgrad_bn_parts)");
+  BnbArgs b;
+  b.x[0] = bn_x; b.coef[0] = bn_coef; b.part[0] = bn_part;
+  b.x[1] = bn2_x; b.coef[1] = bn2_coef; b.part[1] = bn2_part;
+  b.mask = bn_mask;
+  return conv2d_fwd_impl(dy, wt, dx, dtype, dtype, N, H, W, C, Cout, R, S, 1, pad, idil_log2, OH, OW, Cout, nullptr, res, accumulate,
+                         0, nullptr, nullptr, 0, nullptr, res_mask, stream, &b);
+}
+
 static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
                            int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
                            int ldy, const float* bias, const void* residual, int accumulate, int out_relu,
                            const float* pro_scale, const float* pro_shift, int pro_relu, float* stats_part,
-                           const unsigned char* res_mask, hipStream_t stream) {
+                           const unsigned char* res_mask, hipStream_t stream, const BnbArgs* bnb) {
   PFR_CHECK_ARG(x && w && y, "pfr_conv2d_fwd: null pointer");
   PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_conv2d_fwd: bad dtype %d", dtype);
   PFR_CHECK_ARG(out_dtype == dtype || out_dtype == PFR_F32, "pfr_conv2d_fwd: out_dtype must be dtype or f32");
@@ -687,6 +815,9 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int
   p.M = N * OH * OW; p.K = R * S * C;
   p.stats_part = stats_part; p.bias = bias; p.residual = residual; p.accumulate = accumulate; p.out_relu = out_relu;
   p.act = 0; p.y2 = nullptr; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = res_mask;
+  p.bnb_mask = nullptr;
+  for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
+  if (bnb) { p.bnb_mask = bnb->mask; for (int q = 0; q < 2; ++q) { p.bnb_x[q] = bnb->x[q]; p.bnb_coef[q] = bnb->coef[q]; p.bnb_part[q] = bnb->part[q]; } }
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
@@ -721,6 +852,8 @@ extern "C" int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, lo
   p.stats_part = nullptr; p.bias = bias; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
   p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
   p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = nullptr;
+  p.bnb_mask = nullptr;
+  for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
   p.div_ohow = make_fastdiv(1u);
   p.div_ow = make_fastdiv(1u);
 #ifdef PFR_IGEMM_TRACE
@@ -762,6 +895,8 @@ extern "C" int pfr_match_scores_filter(const void* q, const void* g, int dtype, 
   p.stats_part = nullptr; p.bias = nullptr; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
   p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
   p.act = 4; p.y2 = t.thrk; p.ccnt = t.ccnt; p.cap = cap; p.col0 = col0; p.self_excl = exclude_self; p.res_mask = nullptr;
+  p.bnb_mask = nullptr;
+  for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
   p.div_ohow = make_fastdiv(1u);
   p.div_ow = make_fastdiv(1u);
 #ifdef PFR_IGEMM_TRACE

@@ -125,6 +125,12 @@ class FEEngine:
         # conv): measured on MI355X it costs ~2x the kernel time, far more than the single elementwise pass it saves.
         # Default: materialise z = relu(BN(c)) once (pfr_bn_act); PFR_FUSE_PROLOGUE=1 re-enables the fused form.
         self.fuse_prologue = os.environ.get("PFR_FUSE_PROLOGUE", "0") == "1"
+        # Opt-in (PFR_FUSE_BNB=1): BatchNorm-backward sums (Σ g·mask, Σ g·mask·x̂) out of the epilogue of the data-gradient launch
+        # that produces g (pfr_conv2d_dgrad_bn) instead of a separate pass over g and x (pfr_bn_bwd_reduce).  It removes one
+        # read of g per BN layer (-5.7 GB/step) and 45 launches, but MEASURED SLOWER (25.2 vs 23.2 ms/step): the data-gradient
+        # kernels are bound by their vector-memory path into LDS, not by HBM, so the extra x reads and the registers of the sums
+        # lengthen them (3.5 -> 7.4 ms) by more than the HBM-speed reduce kernels (2.1 ms at 4.5 TB/s) cost.  DESIGN.md §6.
+        self.fuse_bnb = os.environ.get("PFR_FUSE_BNB", "0") == "1"
         self.grad_ready_hook = None     # callable(lo, hi): flat-grad range [lo, hi) is final (DDP bucket hook)
         self.bucket_elems = 6 * 1024 * 1024
         self._adopt(model)
@@ -620,15 +626,18 @@ class FEEngine:
             self._conv_fwd(ops, dy, dyshape, c.wt, dx, c, 1, c.R - 1 - c.pad, dxshape[1], dxshape[2], idil=log2,
                            accumulate=accumulate, Cout=c.Cin)
 
-        def bn_bwd(dout, out_act, x, xshape, bn, mask_mode, dx, gres, acc):
+        def bn_bwd(dout, out_act, x, xshape, bn, mask_mode, dx, gres, acc, pre=None):
             rows = xshape[0] * xshape[1] * xshape[2]
             C = xshape[3]
-            nb = lib.pfr_colreduce_blocks(C, self.did, rows)
-            part = G((nb, 2, C), torch.float32)
             oa = 0 if out_act is None else out_act.data_ptr()
-            ops.append((lib.pfr_bn_bwd_reduce, (dout.data_ptr(), oa, x.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
-                                                bn.coef[2].data_ptr(), bn.coef[3].data_ptr(), mask_mode, self.did, rows, C,
-                                                part.data_ptr())))
+            if pre is not None:
+                part, nb = pre          # the launch that produced `dout` already left the partial sums (pfr_conv2d_dgrad_bn)
+            else:
+                nb = lib.pfr_colreduce_blocks(C, self.did, rows)
+                part = G((nb, 2, C), torch.float32)
+                ops.append((lib.pfr_bn_bwd_reduce, (dout.data_ptr(), oa, x.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
+                                                    bn.coef[2].data_ptr(), bn.coef[3].data_ptr(), mask_mode, self.did, rows, C,
+                                                    part.data_ptr())))
             ops.append((lib.pfr_bn_bwd_finalize, (part.data_ptr(), nb, C, float(rows), bn.gamma.data_ptr(), bn.coef[0].data_ptr(),
                                                   bn.coef[1].data_ptr(), bn.dgamma.data_ptr(), bn.dbeta.data_ptr(),
                                                   bn.bcoef.data_ptr(), acc)))
@@ -636,6 +645,24 @@ class FEEngine:
                                                bn.coef[3].data_ptr(), mask_mode, dx.data_ptr(),
                                                0 if gres is None else gres.data_ptr(), self.did, rows, C)))
             release(part)
+
+        def dgrad_parts(dyshape, c, dxshape):
+            if not self.fuse_bnb:
+                return 0
+            return lib.pfr_conv2d_dgrad_bn_parts(self.did, dyshape[0], dyshape[1], dyshape[2], dyshape[3], c.Cin, c.R, c.S,
+                                                 {1: 0, 2: 1}[c.stride], dxshape[1], dxshape[2])
+
+        def dgrad_bn(dy, dyshape, c, dx, dxshape, bn1, bn2=None, res=None, res_mask=None, accumulate=0):
+            """data gradient + BN-backward partial sums; bn1 = (x, bn record, bit mask or None, part), bn2 = (x, bn record, part)"""
+            x1, b1, mk, p1 = bn1
+            x2p = c2p = p2p = 0
+            if bn2 is not None:
+                x2p, c2p, p2p = bn2[0].data_ptr(), bn2[1].coef.data_ptr(), bn2[2].data_ptr()
+            ops.append((lib.pfr_conv2d_dgrad_bn, (dy.data_ptr(), c.wt.data_ptr(), dx.data_ptr(), self.did, dyshape[0], dyshape[1],
+                                                  dyshape[2], dyshape[3], c.Cin, c.R, c.S, c.R - 1 - c.pad, {1: 0, 2: 1}[c.stride],
+                                                  dxshape[1], dxshape[2], 0 if res is None else res.data_ptr(),
+                                                  0 if res_mask is None else res_mask.data_ptr(), accumulate, x1.data_ptr(),
+                                                  b1.coef.data_ptr(), 0 if mk is None else mk.data_ptr(), p1.data_ptr(), x2p, c2p, p2p)))
 
         acc = 0  # placeholder: _finalize_plan emits an overwrite (0) and an accumulate (1) variant of every grad write
         # fc
@@ -651,13 +678,18 @@ class FEEngine:
         ops.append((lib.pfr_avgpool_bwd, (dgap.data_ptr(), dcur.data_ptr(), self.did, N, Hh * Ww, Cf)))
         release(dgap)
         # blocks in reverse
-        for (convs, down), (xin, xshape, raws, cd, out, oshape, acts) in zip(reversed(self.blocks), reversed(bsaved)):
+        nblk = len(self.blocks)
+        pre3 = {}     # block index -> partial sums of its last BN / projection BN left by the producer of its output gradient
+        for k in range(nblk - 1, -1, -1):
+            convs, down = self.blocks[k]
+            xin, xshape, raws, cd, out, oshape, acts = bsaved[k]
             lastc, lastbn = convs[-1]
             ylast, _ = raws[-1]
             # BN(last) + residual + ReLU backward.  `out` is the block's ReLU bit mask; dcur (the gradient that arrived at
             # the block output) is KEPT: the residual branch consumes it through the same mask (no masked copy is written)
             dz3 = G(oshape)
-            bn_bwd(dcur, out, ylast, oshape, lastbn, 3, dz3, None, acc)
+            p3 = pre3.get(k)
+            bn_bwd(dcur, out, ylast, oshape, lastbn, 3, dz3, None, acc, pre=None if p3 is None else p3[0])
             rmask = out
             dy, dyshape = dz3, oshape
             for i in range(len(convs) - 1, 0, -1):
@@ -669,30 +701,61 @@ class FEEngine:
                 else:
                     wgrad(xraw, xrs, dy, dyshape, c, pro=(pbn.coef[2], pbn.coef[3]))
                 dz = G(xrs)
-                dgrad(dy, dyshape, c, dz, xrs)
-                release(dy)
-                bn_bwd(dz, None, xraw, xrs, pbn, 2, dz, None, acc)
+                npart = dgrad_parts(dyshape, c, xrs)
+                if npart > 0:
+                    part = G((npart, 2, xrs[3]), torch.float32)
+                    dgrad_bn(dy, dyshape, c, dz, xrs, (xraw, pbn, None, part))
+                    release(dy)
+                    bn_bwd(dz, None, xraw, xrs, pbn, 2, dz, None, acc, pre=(part, npart))
+                else:
+                    dgrad(dy, dyshape, c, dz, xrs)
+                    release(dy)
+                    bn_bwd(dz, None, xraw, xrs, pbn, 2, dz, None, acc)
                 dy, dyshape = dz, xrs
             c0, bn0 = convs[0]
             wgrad(xin, xshape, dy, dyshape, c0)
             dxin = G(xshape)
+            # the launch that finishes dxin also leaves the BN-backward sums of the PREVIOUS block's output BN(s), whose
+            # output gradient dxin is (through that block's ReLU bit mask)
+            nxt = None
+            if k > 0:
+                pconvs, pdown = self.blocks[k - 1]
+                _, _, praws, pcd, pmask, poshape, _ = bsaved[k - 1]
+                nxt = (praws[-1][0], pconvs[-1][1], pmask, pcd, None if pdown is None else pdown[1])
             if down is not None:
                 dc, dbn = down
                 dgd = G(oshape)
-                bn_bwd(dcur, rmask, cd, oshape, dbn, 3, dgd, None, acc)      # projection-shortcut BN: g = dcur ∘ mask
+                bn_bwd(dcur, rmask, cd, oshape, dbn, 3, dgd, None, acc,
+                       pre=None if (p3 is None or p3[1] is None) else p3[1])      # projection-shortcut BN: g = dcur ∘ mask
                 release(dcur)
                 wgrad(xin, xshape, dgd, oshape, dc)
                 # main branch first (writes all of dxin), then the projection shortcut ACCUMULATES: for its 1x1 / stride-2
                 # conv only the (even, even) positions of dxin receive anything, and only those rows are touched
                 dgrad(dy, dyshape, c0, dxin, xshape)
-                dgrad(dgd, oshape, dc, dxin, xshape, accumulate=1)
+                npart = dgrad_parts(oshape, dc, xshape) if nxt is not None else 0
+                if npart > 0:
+                    part = G((npart, 2, xshape[3]), torch.float32)
+                    part2 = G((npart, 2, xshape[3]), torch.float32) if nxt[3] is not None else None
+                    dgrad_bn(dgd, oshape, dc, dxin, xshape, (nxt[0], nxt[1], nxt[2], part),
+                             None if part2 is None else (nxt[3], nxt[4], part2), accumulate=1)
+                    pre3[k - 1] = ((part, npart), None if part2 is None else (part2, npart))
+                else:
+                    dgrad(dgd, oshape, dc, dxin, xshape, accumulate=1)
                 release(dgd)
             else:
                 # identity shortcut: dxin = dgrad(conv1) + dcur ∘ mask in the data-gradient epilogue
                 log2 = {1: 0, 2: 1}[c0.stride]
-                ops.append((lib.pfr_conv2d_dgrad_join, (dy.data_ptr(), c0.wt.data_ptr(), dxin.data_ptr(), self.did, dyshape[0],
-                                                        dyshape[1], dyshape[2], dyshape[3], c0.Cin, c0.R, c0.S, c0.R - 1 - c0.pad,
-                                                        log2, xshape[1], xshape[2], dcur.data_ptr(), rmask.data_ptr())))
+                npart = dgrad_parts(dyshape, c0, xshape) if nxt is not None else 0
+                if npart > 0:
+                    part = G((npart, 2, xshape[3]), torch.float32)
+                    part2 = G((npart, 2, xshape[3]), torch.float32) if nxt[3] is not None else None
+                    dgrad_bn(dy, dyshape, c0, dxin, xshape, (nxt[0], nxt[1], nxt[2], part),
+                             None if part2 is None else (nxt[3], nxt[4], part2), res=dcur, res_mask=rmask)
+                    pre3[k - 1] = ((part, npart), None if part2 is None else (part2, npart))
+                else:
+                    ops.append((lib.pfr_conv2d_dgrad_join, (dy.data_ptr(), c0.wt.data_ptr(), dxin.data_ptr(), self.did, dyshape[0],
+                                                            dyshape[1], dyshape[2], dyshape[3], c0.Cin, c0.R, c0.S, c0.R - 1 - c0.pad,
+                                                            log2, xshape[1], xshape[2], dcur.data_ptr(), rmask.data_ptr())))
                 release(dcur)
             self._mark(ops, c0.off)  # conv1.weight is the block's first parameter: flat grads [c0.off, end) are final
             release(dy)

@@ -354,3 +354,26 @@ def test_fused_head_baseline_size_vs_oracle(dtype, tol_logit, tol_grad):
     assert abs(r["loss"].item() - loss_o.item()) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(loss_o.item())
     assert rel(xh.grad, xo.grad) < tol_grad
     assert rel(hip.add_margin.weight.grad, wo.grad) < tol_grad
+
+
+def test_fused_bn_backward_sums_equal_separate_reduce(monkeypatch):
+    """PFR_FUSE_BNB=1 (pfr_conv2d_dgrad_bn: BN-backward partial sums out of the data-gradient epilogue, incl. the two-BN form for
+    blocks with a projection shortcut) must give the gradients of the default path (separate pfr_bn_bwd_reduce) — fp32, R50."""
+    from oracle import resnet_ref
+    sd = resnet_ref.init_state_dict("resnet50", 512, seed=8)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(6, 3, 96, 96, generator=g).to(DEV)
+    demb = (torch.randn(6, 512, generator=g) * 0.05).to(DEV)
+    grads = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PFR_FUSE_BNB", flag)
+        m = build("resnet50", torch.float32, sd).train()
+        assert m.hip_engine().fuse_bnb == (flag == "1")
+        m(x).backward(demb)
+        torch.cuda.synchronize()
+        grads.append(torch.cat([p.grad.flatten() for p in m.parameters()]).double().cpu())
+        if flag == "1":
+            names = [f.__name__ for f, _ in m.hip_engine()._last_plan.meta["bwd0"] if hasattr(f, "__name__")]
+            assert names.count("pfr_conv2d_dgrad_bn") >= 40 and names.count("pfr_bn_bwd_reduce") <= 10, names.count("pfr_conv2d_dgrad_bn")
+    e = ((grads[0] - grads[1]).norm() / grads[0].norm()).item()
+    assert e < 1e-5, e
