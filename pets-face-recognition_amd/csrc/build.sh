@@ -6,7 +6,7 @@ ARCH=gfx950
 FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast"
 mkdir -p build
 pids=()
-for f in pfr_api pfr_igemm pfr_igemm_p pfr_wgrad pfr_elementwise pfr_head pfr_match pfr_swin; do
+for f in pfr_api pfr_igemm pfr_igemm_p pfr_igemm_ws pfr_wgrad pfr_elementwise pfr_head pfr_match pfr_swin; do
   [ -f $f.hip ] || continue
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ pfr_common.h -nt build/$f.o ] || [ pfr_mma.h -nt build/$f.o ] || [ pfr_igemm.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &

@@ -51,6 +51,11 @@ struct IgemmParams {
 int igemm_p_launch(IgemmParams& p, int dtype, int out_dtype, int bq, int bp, hipStream_t st);
 int igemm_p_enabled();
 int igemm_p_forced_tile();
+// wave-specialised kernel (pfr_igemm_ws.hip): PFR_IGEMM_WS / pfr_set_tuning("igemm_ws"): 0 off, 1 heuristic, 2 whenever eligible
+int igemm_ws_mode();
+void igemm_ws_set_mode(int v);
+bool igemm_ws_eligible(const IgemmParams& p, int dtype, int out_dtype);
+int igemm_ws_launch(IgemmParams& p, hipStream_t st);
 // parity-class mode of the persistent kernel: data gradient of a stride-2 conv (input dilation 1 << 1) over even output sizes
 static inline bool igemm_pclass_ok(const IgemmParams& p) {
   return p.idil_log2 == 1 && p.ostride == 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part;

@@ -692,9 +692,20 @@ static int pick_persistent(int M, int Cout, int K, int C, int dtype, int out_dty
   return pclass ? 1 : 0;
 }
 
+// wave-specialised kernel: geometry-only part of the decision (what pfr_conv2d_mtile can see too)
+static int pick_ws(int M, int Cout, int K, int C, int dtype, int out_dtype, int has_pro) {
+  const int mode = igemm_ws_mode();
+  if (mode == 0 || dtype != PFR_BF16 || out_dtype != PFR_BF16 || has_pro) return 0;
+  if (C % 32 != 0 || M % 256 != 0 || Cout % 64 != 0 || K < 64 || (size_t)M * Cout * 2 >= ((size_t)1 << 31)) return 0;
+  return 1;
+}
+
 template <typename T, typename TO>
 static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   int bq, bp;
+  if (igemm_ws_mode() && igemm_ws_eligible(p, dtype, out_dtype) &&
+      (igemm_pclass_ok(p) || pick_ws(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr)))
+    return igemm_ws_launch(p, st);
   const int pcl = igemm_pclass_ok(p) ? 1 : 0;
   if (!p.bnb_part[0] && pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp)) {
     const int rc = igemm_p_launch(p, dtype, out_dtype, bq, bp, st);
@@ -717,6 +728,7 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
 // the m-tile height, or half of it when the persistent kernel (one partial per wave row) takes the launch
 extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int C, int dtype, int out_dtype, int fused_prologue) {
   int bq, bp;
+  if (pick_ws(M, Cout, K, C, dtype, out_dtype, fused_prologue)) return 64;   // one partial per memory wave (64 rows)
   // (statistics and the parity-class mode exclude each other, so the heuristic never picks the persistent kernel for a
   //  launch that publishes statistics; PFR_IGEMM_P=2 does)
   if (pick_persistent(M, Cout, K, C, dtype, out_dtype, fused_prologue, 0, 0, &bq, &bp)) return bq / 2;

@@ -57,8 +57,17 @@ __device__ __forceinline__ void halving_sum(float* v, int lane) { Halving<NV, 5,
 
 // LEAN: epilogue specialised for whole tiles of bf16 output without post-ops (the train-step forward convs with their
 // BatchNorm statistics, and the plain data gradients): no bounds checks, buffer stores whose row offset is a scalar.
-template <typename T, typename TO, int BQ, int BP, int KCH_, int NST_, bool LEAN>
-__global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int total_tiles) {
+// PF: operand fragments of the NEXT k-group are read from LDS while the MFMAs of the current one run — also across k-steps and
+// tile boundaries (the barrier that publishes a stage is taken one stage early, so the first fragments of stage s+1 are
+// already readable during stage s): the ~300-cycle ds_read latency at the head of every k-step disappears from the chain.
+// WS (wave specialisation): a FIFTH wave per workgroup does nothing but the operand DMA (address arithmetic, tile decode,
+// issue, counted waits) while the four MFMA waves only {barrier, ds_read, MFMA, epilogue}.  Why: an LDS-DMA instruction costs
+// its issuing wave ~125 cycles of in-order issue time whenever the CU's texture-address path is busy (it sustains 1 KiB per
+// ~16-23 clocks), and the MFMA pipe of that wave's SIMD starves meanwhile — with the issue on its own wave the two
+// resources (TA ~ 44-65 B/clk/CU, MFMA) run concurrently instead of back to back (tools/p_trace.py: a k-step of a 4-wave
+// workgroup takes 1150 cycles with the DMA issue inline, 660 without, for 256 cycles of MFMA work).
+template <typename T, typename TO, int BQ, int BP, int KCH_, int NST_, bool LEAN, bool PF = false, bool WS = false>
+__global__ __launch_bounds__(WS ? 320 : 256, WS ? 3 : (((BP + BQ) * KCH_ * 16 * NST_ + 4 * 4096 <= 80 * 1024) ? 2 : 1)) void igemm_p_kernel(IgemmParams p, int total_tiles) {
   constexpr int KP = DT<T>::KPACK;
   constexpr int KCH = KCH_;
   constexpr int ROWB = KCH * 16;
@@ -66,7 +75,8 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
   constexpr int RPI = 64 / KCH;
   constexpr int NW = 4, WP = 2, WQ = 2;
   constexpr int TP = BP / (WP * 32), TQ = BQ / (WQ * 32);
-  constexpr int QCH = BQ / (NW * RPI), PCH = BP / (NW * RPI);
+  constexpr int LW = WS ? 1 : NW;                             // waves that issue the operand DMA
+  constexpr int QCH = BQ / (LW * RPI), PCH = BP / (LW * RPI);
   static_assert(TP >= 1 && TQ >= 1 && QCH >= 1 && PCH >= 1, "tile too small");
   constexpr int NLD = QCH + PCH;
   constexpr int NST = NST_;
@@ -80,7 +90,10 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
   constexpr int EWAVE = 32 * ERB;                             // staging window of one wave
   constexpr int RPS = 64 / NCH;                               // rows covered by one wave-wide 16-byte access
   constexpr int SMEM = NST * STAGE + NW * EWAVE;
-  static_assert(SMEM <= 80 * 1024, "two workgroups must fit the 160 KiB LDS of a CU");
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  static_assert(!PF || NST == 4, "the early-barrier schedule needs a 4-slot ring");
+  static_assert(!(WS && PF), "WS uses the plain schedule");
+  static_assert(!WS || NLD * (NST - 1) <= 63, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -89,12 +102,12 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
   const int b = blockIdx.x, G = gridDim.x;
 
   // round r of this workgroup -> logical tile (consecutive logical tiles of a round sit on one XCD: they share A rows / L2)
-  auto tile_of = [&](int r) -> int {
+  auto tile_of = [&](int r) __attribute__((always_inline)) -> int {
     const int base = r * G;
     const int nr = min(G, total_tiles - base);
     return (b < nr) ? base + (int)xcd_remap((uint32_t)b, (uint32_t)nr) : -1;
   };
-  auto decode = [&](int m, int mlim, int ph, int pw, uint32_t& n_img, uint32_t& oh, uint32_t& ow) -> bool {
+  auto decode = [&](int m, int mlim, int ph, int pw, uint32_t& n_img, uint32_t& oh, uint32_t& ow) __attribute__((always_inline)) -> bool {
     if (m >= mlim) return false;
     if (p.pclass) {
       n_img = fdiv((uint32_t)m, p.div_chw);
@@ -114,7 +127,10 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
 
   // ------------------------------------------------------------------------------------------ loader (runs ahead)
   const int rsub = lane / KCH;
-  const int lc = (lane % KCH) ^ row_swizzle<KCH>(wave * RPI + rsub);
+  const int lw = WS ? 0 : wave;                      // index of this wave among the DMA-issuing waves
+  const bool is_loader = WS && wave == NW;
+  // logical 16-byte chunk this lane fetches for pass j (swizzle on the SOURCE side; for LW = 4 it does not depend on j)
+  auto lcj = [&](int j) __attribute__((always_inline)) -> int { return (lane % KCH) ^ row_swizzle<KCH>((j * LW + lw) * RPI + rsub); };
   const int dmask = (1 << p.idil_log2) - 1;
   const uint32_t OOBB = 0xF0000000u;   // beyond num_records: the LDS-DMA writes zeros
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
   int lr = 0;          // round of the loader's current tile
   bool ldone = false;
 
-  auto newtap = [&]() {
+  auto newtap = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < QCH; ++j) {
       int ih = ihb[j] + u_tr, iw = iwb[j] + u_ts;
@@ -139,11 +155,11 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
       ih >>= p.idil_log2;
       iw >>= p.idil_log2;
       ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W) && (u_tr < p.R);
-      const uint32_t off = (uint32_t)(((pixb[j] + ih * p.W + iw) * p.C + lc * KP) * (int)sizeof(T));
+      const uint32_t off = (uint32_t)(((pixb[j] + ih * p.W + iw) * p.C + lcj(j) * KP) * (int)sizeof(T));
       qbase[j] = ok ? off : OOBB;
     }
   };
-  auto l_begin = [&](int t) {
+  auto l_begin = [&](int t) __attribute__((always_inline)) {
     const int tn = t % p.tilesN, tm = t / p.tilesN;
     const int n0 = tn * BP;
     const int cls = p.pclass ? tm / p.tpc : 0;
@@ -151,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
     const int m0 = (p.pclass ? tm - cls * p.tpc : tm) * BQ;
 #pragma unroll
     for (int j = 0; j < QCH; ++j) {
-      const int m = m0 + (j * NW + wave) * RPI + rsub;
+      const int m = m0 + (j * LW + lw) * RPI + rsub;
       uint32_t n_img, oh, ow;
       if (decode(m, mlim, ph, pw, n_img, oh, ow)) {
         ihb[j] = (int)oh * p.ostride - p.pad;
@@ -165,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
     }
 #pragma unroll
     for (int j = 0; j < PCH; ++j) {
-      const int row = n0 + (j * NW + wave) * RPI + rsub;
-      wbase[j] = row < p.Cout ? (uint32_t)(((size_t)row * p.K + lc * KP) * sizeof(T)) : OOBB;
+      const int row = n0 + (j * LW + lw) * RPI + rsub;
+      wbase[j] = row < p.Cout ? (uint32_t)(((size_t)row * p.K + lcj(j) * KP) * sizeof(T)) : OOBB;
     }
     l_tr0 = p.pclass ? ((p.pad + ph) & 1) : 0;
     l_ts0 = p.pclass ? ((p.pad + pw) & 1) : 0;
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
   };
   // moves the loader to its next tile that has k-steps (parity classes of a 1x1 / stride-2 data gradient other than (0,0) have
   // none: their outputs are zeros) or marks it done
-  auto l_next = [&]() {
+  auto l_next = [&]() __attribute__((always_inline)) {
     for (;;) {
       ++lr;
       const int t = tile_of(lr);
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
     }
   };
   // issues the LDS-DMA of the loader's next k-step into ring slot `buf`, then advances (possibly into the next tile)
-  auto gload = [&](int buf) {
+  auto gload = [&](int buf) __attribute__((always_inline)) {
     char* base = smem + buf * STAGE;
 #ifdef PFR_IGEMM_TRACE
     if (!(p.dbg & 16))   // experiment: no operand DMA at all
@@ -202,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
     {
 #pragma unroll
     for (int j = 0; j < PCH; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * NW + wave) * RPI * ROWB),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * LW + lw) * RPI * ROWB),
                                                16, (int)(wbase[j] + (uint32_t)(tapbyte + cbyte)), 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < QCH; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * NW + wave) * RPI) * ROWB),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * LW + lw) * RPI) * ROWB),
                                                16, (int)(qbase[j] + (uint32_t)cbyte), 0, 0, 0);
     }
     if (--l_nk == 0) {
@@ -223,11 +239,37 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
     }
   };
 
-  {
+  if constexpr (WS) {
+    if (is_loader) {
+      // ---- the loader wave: fill all ring slots, then per stage {wait until it has landed, barrier (= publish it and learn
+      //      that the stage before it has been consumed), refill the slot that stage left}
+      const int t0 = tile_of(0);
+      if (t0 < 0) return;
+      l_begin(t0);
+      if (l_nk == 0) l_next();
+      int issued = 0, slot = 0;
+#pragma unroll 1
+      for (; issued < NST && !ldone; ++issued) { gload(slot); slot = (slot + 1 == NST) ? 0 : slot + 1; }
+#pragma unroll 1
+      for (int s = 0; s < issued; ++s) {
+        const int younger = issued - (s + 1);
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST >= 4 ? 3 * NLD : 0) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST >= 3 ? 2 * NLD : 0) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s >= 1 && !ldone) { gload(slot); slot = (slot + 1 == NST) ? 0 : slot + 1; ++issued; }
+      }
+      return;
+    }
+  }
+  if constexpr (!WS) {
     const int t0 = tile_of(0);
     if (t0 < 0) return;
     l_begin(t0);
     if (l_nk == 0) l_next();
+  } else {
+    if (tile_of(0) < 0) return;
   }
   int inflight = 0, slot_l = 0, slot_c = 0;
 #ifdef PFR_IGEMM_TRACE
@@ -242,13 +284,36 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
 #define PSTAMP(acc) do {} while (0)
 #define PSTART() do {} while (0)
 #endif
-  auto issue = [&]() {
+  auto issue = [&]() __attribute__((always_inline)) {
     gload(slot_l);
     slot_l = (slot_l + 1 == NST) ? 0 : slot_l + 1;
     ++inflight;
   };
+  if constexpr (!WS) {
 #pragma unroll 1
-  for (int s = 0; s < NST - 1 && !ldone; ++s) issue();
+    for (int s = 0; s < NST - 1 && !ldone; ++s) issue();
+  }
+  // PF: fragment registers, double-buffered by k-group parity, live across k-steps and tiles
+  constexpr int NKG = KCH / 2;
+  u32x4 fp[2][TP], fq[2][TQ];
+  const int frow = lane & 31, fhalf = lane >> 5, fsw = row_swizzle<KCH>(frow);
+  auto rdfrag = [&](int slot, int kg, int bsel) __attribute__((always_inline)) {
+    const char* sb = smem + slot * STAGE;
+    const char* ldsP = sb + (wp * (BP / WP)) * ROWB;
+    const char* ldsQ = sb + (BP + wq * (BQ / WQ)) * ROWB;
+    const int off = (((kg * 2 + fhalf) ^ fsw) << 4);
+#pragma unroll
+    for (int i = 0; i < TP; ++i) fp[bsel][i] = *reinterpret_cast<const u32x4*>(ldsP + (i * 32 + frow) * ROWB + off);
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) fq[bsel][j] = *reinterpret_cast<const u32x4*>(ldsQ + (j * 32 + frow) * ROWB + off);
+  };
+  if constexpr (PF) {
+    // stages 0 and 1 must have landed (stage 2 may stay in flight), then the first fragments of stage 0
+    if (inflight >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rdfrag(0, 0, 0);
+  }
 
   char* ewin = smem + NST * STAGE + wave * EWAVE;   // this wave's epilogue staging window
   const uint32_t ewin_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ewin;   // its LDS byte address
@@ -280,6 +345,65 @@ __global__ __launch_bounds__(256, 2) void igemm_p_kernel(IgemmParams p, int tota
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    if constexpr (WS) {
+#pragma unroll 1
+      for (int kt = 0; kt < nk; ++kt) {
+        PSTART();
+        __builtin_amdgcn_s_barrier();          // the loader wave arrives here once this stage has landed
+        PSTAMP(c_wait);
+        const char* base = smem + slot_c * STAGE;
+        mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc);
+        slot_c = (slot_c + 1 == NST) ? 0 : slot_c + 1;
+#ifdef PFR_IGEMM_TRACE
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+        PSTAMP(c_mma);
+        ++n_ks;
+#endif
+      }
+    } else if constexpr (PF) {
+#pragma unroll 1
+      for (int kt = 0; kt < nk; ++kt) {
+        PSTART();
+        if (!ldone) issue();                 // stage s+3 into the slot stage s-1 left (everyone passed the last barrier)
+        const int nslot = (slot_c + 1 == NST) ? 0 : slot_c + 1;
+        const bool has_next = inflight >= 2;
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg) {
+          const int bsel = kg & 1;
+          if (kg + 1 < NKG) rdfrag(slot_c, kg + 1, bsel ^ 1);
+          else if (has_next) rdfrag(nslot, 0, bsel ^ 1);   // first fragments of the next stage (next tile's, at a tile end)
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+              for (int j = 0; j < TQ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fp[bsel][i]),
+                                                                     __builtin_bit_cast(bf16x8, fq[bsel][j]), acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fp[bsel][i][e]), __uint_as_float(fq[bsel][j][e]),
+                                                                    acc[i][j], 0, 0, 0);
+          }
+        }
+        --inflight;
+        slot_c = nslot;
+#ifdef PFR_IGEMM_TRACE
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+        PSTAMP(c_mma);
+        ++n_ks;
+#endif
+        // publish stage s+2 for the next iteration: only stage s+3 may stay in flight
+        if (inflight >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PSTAMP(c_wait);
+      }
+    } else
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
       // the oldest stage in flight is the one to consume: wait until only the (inflight - 1) younger ones are outstanding
@@ -593,7 +717,7 @@ static int num_cus() {
   return n;
 }
 
-static int g_p_mode = -1, g_p_tile = -2, g_p_kch = -1;
+static int g_p_mode = -1, g_p_tile = -2, g_p_kch = -1, g_p_pf = -1;
 int igemm_p_enabled() {
   if (g_p_mode < 0) g_p_mode = getenv("PFR_IGEMM_P") ? atoi(getenv("PFR_IGEMM_P")) : 1;
   return g_p_mode;
@@ -609,6 +733,8 @@ extern "C" int pfr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "igemm_p")) { g_p_mode = value; return PFR_OK; }
   if (!strcmp(key, "igemm_ptile")) { g_p_tile = value; return PFR_OK; }
   if (!strcmp(key, "igemm_pkch")) { g_p_kch = value; return PFR_OK; }
+  if (!strcmp(key, "igemm_ppf")) { g_p_pf = value; return PFR_OK; }
+  if (!strcmp(key, "igemm_ws")) { igemm_ws_set_mode(value); return PFR_OK; }
   pfr_set_error("pfr_set_tuning: unknown key %s", key);
   return PFR_ERR_ARG;
 }
@@ -637,7 +763,15 @@ static int launch_p(IgemmParams& p, hipStream_t st) {
     const bool lean = !post && mrows % BQ == 0 && p.Cout % BP == 0 && (p.ldy * (int)sizeof(TO)) % 16 == 0 &&
                       (size_t)p.M * p.ldy * sizeof(TO) < ((size_t)1 << 31) && !getenv("PFR_IGEMM_P_NOLEAN");
     if (lean) {
-      if (k8) hipLaunchKernelGGL((igemm_p_kernel<T, TO, BQ, BP, 8, 2, true>), g, blk, 0, st, p, total);
+      if (g_p_pf < 0) g_p_pf = getenv("PFR_IGEMM_PPF") ? atoi(getenv("PFR_IGEMM_PPF")) : 0;
+      if (g_p_pf == 3) {
+        hipLaunchKernelGGL((igemm_p_kernel<T, TO, BQ, BP, 4, 4, true, false, true>), g, dim3(320), 0, st, p, total);
+      } else if (g_p_pf == 2 && p.C % (8 * DT<T>::KPACK) == 0) {
+        // 128-byte k-steps, 4-slot ring of 32 KiB stages: one workgroup per CU
+        const int grid1 = total < num_cus() ? total : num_cus();
+        hipLaunchKernelGGL((igemm_p_kernel<T, TO, BQ, BP, 8, 4, true, true>), dim3((unsigned)grid1), blk, 0, st, p, total);
+      } else if (g_p_pf >= 1) hipLaunchKernelGGL((igemm_p_kernel<T, TO, BQ, BP, 4, 4, true, true>), g, blk, 0, st, p, total);
+      else if (k8) hipLaunchKernelGGL((igemm_p_kernel<T, TO, BQ, BP, 8, 2, true>), g, blk, 0, st, p, total);
       else hipLaunchKernelGGL((igemm_p_kernel<T, TO, BQ, BP, 4, 4, true>), g, blk, 0, st, p, total);
       PFR_CHECK_LAUNCH();
       return PFR_OK;

@@ -395,3 +395,45 @@ def test_strided_dgrad_parity_classes(dtype, R, H, C, Cout, accumulate):
     torch.cuda.synchronize()
     e = rel_err(out.cpu(), nhwc(ref))
     assert e < (1e-2 if dtype == torch.bfloat16 else 1e-5), e
+
+
+@pytest.mark.parametrize("case", [
+    # kind, N, H, C, Cout, R, stride / dilation-log2
+    ("fwd", 8, 32, 64, 128, 1, 1), ("fwd", 8, 32, 64, 64, 3, 1), ("fwd", 8, 16, 256, 256, 3, 1), ("fwd", 8, 32, 128, 128, 3, 2),
+    ("dgrad", 8, 16, 128, 128, 3, 1), ("dgrad", 8, 32, 256, 64, 1, 0), ("fwd", 20, 16, 96, 192, 1, 1)])
+def test_alternative_gemm_kernels_bit_identical(case):
+    """The persistent (pfr_igemm_p.hip) and wave-specialised (pfr_igemm_ws.hip) kernels must reproduce the one-tile-per-
+    workgroup kernel BIT FOR BIT (same MFMA accumulation order) and publish BatchNorm statistics that finalise to the same
+    mean / invstd, whatever partial granularity pfr_conv2d_mtile reports for them.  pfr_set_tuning selects the kernel."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    kind, N, H, C, Co, R, sd = case
+    pad = (R - 1) // 2
+    g = torch.Generator().manual_seed(H * C + R)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(Co, R, R, C, generator=g) / (C * R * R) ** 0.5).to(DEV).bfloat16()
+    if kind == "fwd":
+        kw = dict(stride=sd, pad=pad, stats=True)
+    else:
+        kw = dict(stride=1, pad=R - 1 - pad, idil_log2=sd, out_hw=(H << sd, H << sd), stats=False)
+    outs = []
+    try:
+        for knobs in ({"igemm_p": 0, "igemm_ws": 0}, {"igemm_p": 2, "igemm_ws": 0, "igemm_ppf": 0}, {"igemm_p": 2, "igemm_ws": 0, "igemm_ppf": 1},
+                      {"igemm_p": 2, "igemm_ws": 0, "igemm_ppf": 3}, {"igemm_p": 0, "igemm_ws": 2}):
+            for k, v in knobs.items():
+                lib.pfr_set_tuning(k.encode(), v)
+            y, part = o.conv2d_fwd(x, w, **kw)
+            st = None
+            if part is not None:
+                M = y.numel() // Co
+                mt = lib.pfr_conv2d_mtile(M, Co, R * R * C, C, 1, 1, 0)
+                st = o.bn_finalize(part, mt, M, None, None, 1e-5, 0.1, None, None)[:2].clone()
+            torch.cuda.synchronize()
+            outs.append((y.clone(), st))
+    finally:
+        for k, v in (("igemm_p", 1), ("igemm_ws", 0), ("igemm_ppf", 0)):
+            lib.pfr_set_tuning(k.encode(), v)
+    for y, st in outs[1:]:
+        assert torch.equal(y, outs[0][0])
+        if st is not None:
+            assert torch.allclose(st, outs[0][1], rtol=2e-4, atol=1e-5)

@@ -41,14 +41,15 @@ for kind, H, C, Co, R, s, dil, n in cases:
     by = (x.numel() + B * OH * OH * Co + w.numel()) * 2
     res = {}
     ref = None
-    variants = [("old", 0, -1, 4), ("p128x128", 2, 0, 4), ("p128x64", 2, 2, 4), ("p128x128k8", 2, 0, 8), ("p64x128k8", 2, 1, 8),
-                ("p128x64k8", 2, 2, 8), ("p64x64k8", 2, 3, 8)]
-    for name, mode, tile, kch in variants:
-        if kch == 8 and C % 64:
+    variants = [("old", 0, -1, 4, 0), ("p128x128", 2, 0, 8, 0), ("ws2", 0, -1, 4, 0)]
+    for name, mode, tile, kch, pf in variants:
+        if pf == 2 and C % 64:
             continue
+        lib.pfr_set_tuning(b"igemm_ws", 2 if name == "ws2" else 0)
         lib.pfr_set_tuning(b"igemm_p", mode)
         lib.pfr_set_tuning(b"igemm_ptile", tile)
         lib.pfr_set_tuning(b"igemm_pkch", kch)
+        lib.pfr_set_tuning(b"igemm_ppf", pf)
         y, part = ops.conv2d_fwd(x, w, **kw)
         torch.cuda.synchronize()
         if ref is None:

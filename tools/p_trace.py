@@ -17,6 +17,8 @@ CASES = {
 dll.pfr_debug_igemm_flags(int(os.environ.get("DBG", "0")))
 lib.pfr_set_tuning(b"igemm_p", 2)
 lib.pfr_set_tuning(b"igemm_ptile", int(os.environ.get("PTILE", "0")))
+lib.pfr_set_tuning(b"igemm_ppf", int(os.environ.get("PPF", "0")))
+lib.pfr_set_tuning(b"igemm_pkch", int(os.environ.get("PKCH", "4")))
 big = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device='cuda')
 for stats in (True, False):
     for name, (N, H, W, C, Co, R, s, p) in CASES.items():
