@@ -179,6 +179,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.item())
+    # host time to enqueue ONE step into an EMPTY queue (no back-pressure from the GPU): what the host side really costs
+    host_free = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        host_free.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    host_free_ms = min(host_free)
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
 
@@ -243,6 +252,7 @@ def main():
     if rank == 0:
         line = {"metric": f"FE train images/sec @224^2 bs={args.batch}/GPU", "value": round(value, 1), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_ms, 3),
+                "host_enqueue_ms_empty_queue": round(host_free_ms, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"{args.arch} FE + ArcFace(s=64,m=0.5) + CE, {args.classes} ids, 224x224x3, "
                                        f"fwd+bwd+SGD(momentum 0.9, param groups of the reference recipe)",

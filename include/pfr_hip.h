@@ -43,6 +43,20 @@ int pfr_device_arch(char* buf, int buflen);
  * Results do not depend on the knobs (same accumulation order); statistics-partial granularity follows pfr_conv2d_mtile. */
 int pfr_set_tuning(const char* key, int value);
 
+/* C-side executor of a pre-built launch plan (csrc/pfr_plan.hip): the host keeps a step's fixed list of C-ABI calls (fixed device
+ * pointers) in a plan and replays it with ONE call instead of one interpreter round trip per launch.  An entry is appended with
+ * the index of the entry point's thunk (pfr_plan_thunk_index("pfr_conv2d_fwd"), -1: not plannable) and its arguments as flat
+ * 64-bit slots in declaration order WITHOUT the trailing stream (pointers / integers as such, floats as IEEE-754 bits).
+ * kind: 0 launch on main | 1 launch on side | 2 fork (record event ev on main, side waits) | 3 record ev on side | 4 main waits
+ * for ev | 5 as 4 but only when hook_stops | 6 hook stop (ev = user tag).  pfr_plan_run(begin, end <0 = all) returns -1 at the
+ * end, the index of a kind-6 entry when hook_stops and it reached one (resume at index + 1), <= -2 on error. */
+int pfr_plan_thunk_index(const char* name);
+void* pfr_plan_create(int n_events);
+int pfr_plan_destroy(void* plan);
+int pfr_plan_append(void* plan, int kind, int thunk, int ev, const unsigned long long* args, int nargs);
+int pfr_plan_size(void* plan);
+int pfr_plan_run(void* plan, int begin, int end, pfr_stream_t main_stream, pfr_stream_t side_stream, int hook_stops);
+
 /* ---- convolution / linear (implicit GEMM on MFMA) -------------------------------------------------------
  * pfr_conv2d_fwd replaces nn.Conv2d.forward / nn.Linear.forward / F.linear of the backbone and head
  * (torchvision resnet50 built at configs/dog_fe/fe_dogs_config.py:102-103; F.linear at

@@ -46,9 +46,9 @@ def parse_header(path=HEADER_PATH):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int|long)\s+(pfr_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const\s+char\s*\*|void\s*\*|int|long)\s+(pfr_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if "char" in ret else (ctypes.c_long if ret == "long" else ctypes.c_int)
+        restype = ctypes.c_char_p if "char" in ret else (ctypes.c_void_p if "void" in ret else (ctypes.c_long if ret == "long" else ctypes.c_int))
         argtypes, argnames = [], []
         if args and args != "void":
             for a in args.split(","):
@@ -115,7 +115,7 @@ class _Lib:
 
 
 # queries that return a value rather than an error code
-_NO_CHECK = {"pfr_version", "pfr_bn_stats_rows_per_part", "pfr_bn_finalize_ws_floats", "pfr_topk_state_bytes", "pfr_layernorm_bwd_blocks", "pfr_window_bias_table_floats", "pfr_colsum_ws_floats", "pfr_conv2d_mtile", "pfr_conv2d_dgrad_bn_parts", "pfr_conv2d_wgrad_splits", "pfr_colreduce_blocks", "pfr_match_ws_bytes"}
+_NO_CHECK = {"pfr_version", "pfr_bn_stats_rows_per_part", "pfr_bn_finalize_ws_floats", "pfr_topk_state_bytes", "pfr_layernorm_bwd_blocks", "pfr_window_bias_table_floats", "pfr_colsum_ws_floats", "pfr_conv2d_mtile", "pfr_conv2d_dgrad_bn_parts", "pfr_plan_thunk_index", "pfr_plan_size", "pfr_plan_run", "pfr_conv2d_wgrad_splits", "pfr_colreduce_blocks", "pfr_match_ws_bytes"}
 
 lib = _Lib()
 

@@ -23,6 +23,7 @@ import torch.nn as nn
 from .._hip import lib, dtype_id, PfrError
 from .._hip.lib import _TRACER
 from .._hip.ops import conv_out_hw
+from .._hip.cplan import CPlan
 
 _ALIGN = 64  # elements; keeps every parameter 16-byte aligned in both fp32 and bf16 shadows
 
@@ -125,6 +126,9 @@ class FEEngine:
         # conv): measured on MI355X it costs ~2x the kernel time, far more than the single elementwise pass it saves.
         # Default: materialise z = relu(BN(c)) once (pfr_bn_act); PFR_FUSE_PROLOGUE=1 re-enables the fused form.
         self.fuse_prologue = os.environ.get("PFR_FUSE_PROLOGUE", "0") == "1"
+        # replay the step's launch lists from C (csrc/pfr_plan.hip) instead of a Python loop: ~16 ms -> ~2 ms of host time per
+        # ResNet-50 step (PFR_C_PLAN=0 keeps the interpreter loop; a launch tracer always uses it)
+        self.c_plan = os.environ.get("PFR_C_PLAN", "1") != "0"
         # Opt-in (PFR_FUSE_BNB=1): BatchNorm-backward sums (Σ g·mask, Σ g·mask·x̂) out of the epilogue of the data-gradient launch
         # that produces g (pfr_conv2d_dgrad_bn) instead of a separate pass over g and x (pfr_bn_bwd_reduce).  It removes one
         # read of g per BN layer (-5.7 GB/step) and 45 launches, but MEASURED SLOWER (25.2 vs 23.2 ms/step): the data-gradient
@@ -335,9 +339,18 @@ class FEEngine:
                 self.wt_fork.record(torch.cuda.current_stream())
                 self.side.wait_event(self.wt_fork)
                 sptr = self.side.cuda_stream
-            for c in self.all_convs:
-                if c.need_wt:
-                    lib.pfr_weight_dgrad_layout(c.w.data_ptr(), c.wt.data_ptr(), self.did, c.Cout, c.R, c.S, c.Cin, sptr)
+            wt_ops = [(lib.pfr_weight_dgrad_layout, (c.w.data_ptr(), c.wt.data_ptr(), self.did, c.Cout, c.R, c.S, c.Cin))
+                      for c in self.all_convs if c.need_wt]
+            cp = None
+            if self.c_plan and _TRACER[0] is None:
+                cp = getattr(self, "_wt_cplan", None)
+                if cp is None:
+                    cp = self._wt_cplan = CPlan.compile(wt_ops)
+            if cp is not None:
+                cp.run(sptr)
+            else:
+                for fn, args in wt_ops:
+                    fn(*args, sptr)
             self.wt_pending = use_side
             if use_side:
                 self.wt_ready.record(self.side)
@@ -862,6 +875,7 @@ class FEEngine:
                 else:
                     res.append((fn, args))
             plan.meta["bwd%d" % acc] = res
+            plan.meta.pop("c_bwd%d" % acc, None)
         plan.meta["ws_ptr"] = self.ws.data_ptr() if self.ws is not None else 0
 
     def forward(self, x, train, with_backward, ticket=None):
@@ -881,12 +895,25 @@ class FEEngine:
         if plan.meta.get("folded"):
             lib.pfr_fold_bn(self.fold_desc.data_ptr(), self.fold_n, self.did, stream)
         self._input_layout(plan, x, stream)
-        for fn, args in plan.meta["fwd"]:
-            fn(*args, stream)
+        if not self._run_list(plan, "fwd", stream):
+            for fn, args in plan.meta["fwd"]:
+                fn(*args, stream)
         if train:
             self.nbt.add_(1)
         self._last_plan = plan
         return plan.meta["emb"]
+
+    def _run_list(self, plan, key, stream, side=0, hook=None, n_events=0):
+        """replays plan.meta[key] (a launch list) — through the C executor when possible"""
+        if self.c_plan and _TRACER[0] is None:
+            ck = "c_" + key
+            cp = plan.meta.get(ck, False)
+            if cp is False:
+                cp = plan.meta[ck] = CPlan.compile(plan.meta[key], n_events)
+            if cp is not None:
+                cp.run(stream, side, hook)
+                return True
+        return False
 
     def _eval_launches(self, plan, xin):
         """weight refresh + BN fold + input layout + every launch of the inference plan, on the current stream"""
@@ -895,8 +922,9 @@ class FEEngine:
         self.refresh_weights(stream, for_backward=False)
         lib.pfr_fold_bn(self.fold_desc.data_ptr(), self.fold_n, self.did, stream)
         self._input_layout(plan, xin, stream)
-        for fn, args in plan.meta["fwd"]:
-            fn(*args, stream)
+        if not self._run_list(plan, "fwd", stream):
+            for fn, args in plan.meta["fwd"]:
+                fn(*args, stream)
 
     def _forward_graphed(self, plan, x):
         """Opt-in (PFR_GRAPH_EVAL=1): the inference plan replayed as ONE hipGraph, captured on the second call (the first
@@ -929,9 +957,12 @@ class FEEngine:
         main = torch.cuda.current_stream()
         stream = main.cuda_stream
         use_side = self._side_ok()
+        if use_side and self.side is None:
+            self.side = torch.cuda.Stream(device=self.device)
+        if self._run_list(plan, "bwd%d" % acc, stream, self.side.cuda_stream if use_side else 0,
+                          (lambda off: hook(off)) if hook is not None else None, 2 * plan.meta.get("n_side", 0)):
+            return
         if use_side:
-            if self.side is None:
-                self.side = torch.cuda.Stream(device=self.device)
             side, sptr = self.side, self.side.cuda_stream
             ev = self.side_events
             while len(ev) < 2 * plan.meta.get("n_side", 0):
