@@ -108,6 +108,159 @@ def cpu_baseline(args):
                       f"restatement (torchvision absent), {torch.get_num_threads()} threads"}
 
 
+def cpu_thread_sweep(args):
+    """BASELINE.md §3 protocol for the CPU leg: thread sweep at bs = cpu_batch (one warm-up + one timed step per thread count,
+    then two more timed steps at the best), reported with the thread count that won."""
+    from oracle import resnet_ref, arcface_ref
+    if args.arch not in resnet_ref.ARCH:
+        return None
+    B = args.cpu_batch
+    sd = resnet_ref.init_state_dict(args.arch, 512, seed=0)
+    names = resnet_ref.param_names(sd)
+    ps = {k: (v.requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(123)
+    w = (torch.randn(args.classes, 512, generator=g) * 0.02).requires_grad_(True)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, args.classes, (B,), generator=g)
+    opt = torch.optim.SGD([ps[k] for k in names] + [w], 0.01, momentum=0.9)
+
+    def step():
+        opt.zero_grad()
+        emb = resnet_ref.forward(ps, x, args.arch, train=True)
+        arcface_ref.focal_loss(arcface_ref.arc_margin_logits(emb, w, y, 64.0, 0.5), y).backward()
+        opt.step()
+
+    ncpu = os.cpu_count() or 1
+    sweep = {}
+    for nt in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(nt)
+        step()
+        t0 = time.perf_counter()
+        step()
+        sweep[nt] = B / (time.perf_counter() - t0)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2:
+        step()
+        n += 1
+    v = B * n / (time.perf_counter() - t0)
+    return {"value": round(max(v, sweep[best]), 2), "unit": "images/sec", "cores": best, "kind": "port",
+            "thread_sweep_img_s": {str(k): round(val, 2) for k, val in sweep.items()},
+            "sample": f"{args.arch}+ArcFace(C={args.classes}) train steps at bs={B}, PyTorch-CPU fp32 oracle restatement (torchvision "
+                      f"absent): 1 warm-up + 1 timed step per thread count, 2 more timed steps at the best ({best} threads of {ncpu})"}
+
+
+def extras(args, device):
+    """The other BASELINE configs in the driver-run record: Swin-T bs 128 (config 4), the 10k x 1M match
+    (config 5) with its CPU baselines, the eval-mode embedder, and the fp32 (reference arithmetic) train step."""
+    import types
+    from pets_face_recognition_amd.match import cosine_topk
+    out = {}
+
+    def train_rate(arch, batch, dtype, steps, warm):
+        a = types.SimpleNamespace(arch=arch, dtype=dtype, classes=args.classes, batch=batch)
+        ml, opt = build(a, device)
+        g = torch.Generator(device="cpu").manual_seed(7)
+        x = torch.rand(batch, 3, 224, 224, generator=g).to(device)
+        y = torch.randint(0, args.classes, (batch,), generator=g).to(device)
+
+        def st():
+            opt.zero_grad()
+            o = ml(x, y)
+            o["loss"].backward()
+            opt.step()
+            return o["loss"]
+        for _ in range(warm):
+            st()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            l = st()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        fl = conv_flops_per_img(arch) * batch
+        res = {"value": round(batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "dtype": dtype,
+               "loss_finite": bool(torch.isfinite(l).item()),
+               "roofline": {"bound": "mfma", "achieved": round(fl / dt / 1e12, 1), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                            "frac": round(fl / dt / 1e12 / PEAK_TFLOPS[dtype], 4), "note": "whole step (all kernels), conv/linear FLOPs only"}}
+        del ml, opt
+        torch.cuda.empty_cache()
+        return res
+
+    out["swin_t_bs128"] = train_rate("swin_t", 128, "bf16", 10, 3)
+    out["f32_resnet50_bs256"] = train_rate("resnet50", 256, "f32", 4, 2)
+    # eval-mode embedder (Controller.validation_step path)
+    a = types.SimpleNamespace(arch="resnet50", dtype="bf16", classes=args.classes, batch=256)
+    ml, _ = build(a, device)
+    ml.eval()
+    x = torch.rand(256, 3, 224, 224).to(device)
+    with torch.no_grad():
+        for _ in range(3):
+            ml(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            e = ml(x)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    out["eval_r50_bs256"] = {"value": round(256 / dt, 1), "unit": "images/sec", "ms_per_batch": round(dt * 1e3, 3),
+                             "roofline": {"bound": "mfma", "achieved": round(2 * CONV_GMAC["resnet50"] * 1e9 * 256 / dt / 1e12, 1),
+                                          "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                          "frac": round(2 * CONV_GMAC["resnet50"] * 1e9 * 256 / dt / 1e12 / PEAK_TFLOPS["bf16"], 4)}}
+    del ml
+    torch.cuda.empty_cache()
+    # config 5: 10 000 x 1 000 000 x 512 cosine match, top-100, candR@10/100 (synthetic per SURVEY 8d)
+    Q, G, D, K = 10000, 1000000, 512, 100
+    g = torch.Generator(device=device).manual_seed(123)
+    ncls = G // 10
+    centers = torch.randn(ncls, D, device=device, generator=g)
+    gcls = torch.arange(ncls, device=device).repeat_interleave(10)[torch.randperm(G, device=device, generator=g)]
+    gal = centers[gcls] + 3.2 * torch.randn(G, D, device=device, generator=g)
+    qcls = torch.randint(0, ncls, (Q,), device=device, generator=g)
+    qry = centers[qcls] + 3.2 * torch.randn(Q, D, device=device, generator=g)
+    cosine_topk(qry, gal, K)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sc, idx = cosine_topk(qry, gal, K)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hit = gcls[idx.long().clamp_min(0)] == qcls[:, None]
+    m = {"seconds": round(dt, 4), "tflops": round(2.0 * Q * G * D / dt / 1e12, 1), "dtype": "bf16 candidates + fp32 re-score",
+         "candR10": round(hit[:, :10].any(1).float().mean().item(), 4), "candR100": round(hit.any(1).float().mean().item(), 4),
+         "roofline": {"bound": "mfma", "achieved": round(2.0 * Q * G * D / dt / 1e12, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                      "frac": round(2.0 * Q * G * D / dt / 1e12 / PEAK_TFLOPS["bf16"], 4)}}
+    # CPU baselines: (i) the reference's per-query python loop (cost-faithful restatement) at N = 2000, 250 of the queries;
+    # (ii) vectorised mm + topk at the full size, queries in blocks of 500
+    from oracle import match_ref
+    ncpu = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(ncpu)
+    ecpu = qry[:2000].float().cpu()
+    ccpu = qcls[:2000].cpu()
+    t0 = time.perf_counter()
+    match_ref.recall_loop_reference_cost(ecpu, ccpu, range(0, 2000, 8))
+    t_loop = time.perf_counter() - t0
+    us_pair = t_loop / (250 * 1999) * 1e6
+    galc = gal.float().cpu()
+    galc = galc / galc.norm(dim=1, keepdim=True)
+    qc = qry.float().cpu()
+    qc = qc / qc.norm(dim=1, keepdim=True)
+    t0 = time.perf_counter()
+    cidx = []
+    for i in range(0, Q, 500):
+        cidx.append(torch.topk(qc[i:i + 500] @ galc.t(), K, dim=1).indices)
+    t_mm = time.perf_counter() - t0
+    cidx = torch.cat(cidx)
+    agree = float((cidx[:, 0] == idx[:, 0].long().cpu()).float().mean())
+    m["cpu_baseline"] = {"loop_N2000_us_per_pair": round(us_pair, 2), "loop_extrapolated_hours_10kx1M": round(us_pair * Q * G / 3.6e9, 1),
+                         "mm_topk_seconds": round(t_mm, 2), "cores": ncpu, "kind": "port", "top1_agreement_with_gpu": round(agree, 5),
+                         "sample": "reference per-query python loop restated (controller.py:77-90) on 250 of 2000 queries x 1999 others; "
+                                   "torch.mm + topk fp32 at 10k x 1M in query blocks of 500"}
+    out["match_10kx1M"] = m
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +273,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the Swin-T / match / eval / fp32 measurements after the headline")
     ap.add_argument("--detail", default=None, help="write per-launch timings grouped by geometry to this JSON file")
     args = ap.parse_args()
 
@@ -246,8 +400,13 @@ def main():
         dist.barrier()
 
     cpu = None
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extras and args.arch == "resnet50" and args.dtype == "bf16":
+        del ml, opt
+        torch.cuda.empty_cache()
+        extra = extras(args, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
+        cpu = cpu_thread_sweep(args)
 
     if rank == 0:
         line = {"metric": f"FE train images/sec @224^2 bs={args.batch}/GPU", "value": round(value, 1), "unit": "images/sec",
@@ -259,7 +418,7 @@ def main():
                            "global_batch": args.batch * world,
                            "per_gpu_batch": args.batch, "parallelism": f"dp{world}", "loss": round(final_loss, 4),
                            "rccl_ranks": rccl_ranks},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -60,3 +60,29 @@ def cand_recall_query_gallery(idx, q_cls, g_cls, ks=(10, 100)):
     hit = g_cls[idx] == q_cls[:, None]
     present = (q_cls[:, None] == torch.unique(g_cls)[None, :]).any(dim=1)
     return {k: [int((hit[:, :k].any(dim=1) & present).sum().item()), int(present.sum().item())] for k in ks}
+
+
+def recall_loop_reference_cost(emb, classes, queries, ks=(10, 100)):
+    """COST-faithful restatement of the per-query body of /root/reference/engine/controller.py:77-90 + similarity_f
+    (configs/dog_fe/fe_dogs_config.py:89-93) for the queries in `queries` only: tuple index list, a python list of per-row
+    tensors, `torch.cat` of unsqueezed rows, cosine similarity, (unstable) argsort — the operations whose interpreter overhead
+    makes the reference's evaluation O(N²) at ~8 µs per scored pair.  Used as the timed CPU baseline of the match (bench.py)."""
+    import torch.nn.functional as F
+
+    def sim(pairs):
+        t1 = torch.cat([p[0].unsqueeze(0) for p in pairs], dim=0)
+        t2 = torch.cat([p[1].unsqueeze(0) for p in pairs], dim=0)
+        return (F.cosine_similarity(t1, t2) + 1) / 2
+
+    n = classes.shape[0]
+    out = {k: [0, 0] for k in ks}
+    for j in queries:
+        cur, cls = emb[j], classes[j]
+        other = emb[tuple(jj for jj in range(n) if jj != j), :]
+        sc = sim(list(zip([cur] * (n - 1), [other[jj] for jj in range(len(other))])))
+        oc = classes[torch.as_tensor(tuple(jj for jj in range(n) if jj != j))]
+        oc = oc[torch.argsort(sc, descending=True)]
+        for k in ks:
+            out[k][0] += int((cls == oc[:k]).sum().item() != 0)
+            out[k][1] += int((cls == oc).sum().item() != 0)
+    return out

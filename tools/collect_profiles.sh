@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 # bench.py takes its per-launch HIP-event timings (a tracer forces serial execution), so the per-kernel averages of the
 # two agree; with the side stream on, concurrently running kernels stretch each other's durations.
 export PFR_SIDE_STREAM=0
-CMD="python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline"
+CMD="python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-extras"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o stats -- $CMD > $OUT/${TAG}_prof_run.log 2>&1 )
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" $OUT/${TAG}_kernel_stats_bench_resnet50_bs256_bf16.csv
