@@ -254,6 +254,15 @@ int pfr_pair_similarity(const float* emb, int D, const long* idx_a, const long* 
 int pfr_card_centroids(const float* emb, const long* seg, int ncards, int D, float eps, float* cent32, void* cent,
                        int cent_dtype, pfr_stream_t stream);
 
+/* head/body fusion of the inference ranking (generate_tsv.py:91-110), in place over `head_scores`.  head_scores,
+ * body_scores: fp32 [rows][ld] centroid dot products of a query-card block against gallery cards col0..col0+n.
+ * q_flags [rows], g_flags [all gallery cards] (indexed col0 + j): bit 0 = card has head vectors, bit 1 = has body
+ * vectors, bits 2..7 = species `type` (1-based).  thresholds: HOST array of n_types floats (generate_tsv.py:107:
+ * [0.9069641, 0.985643]).  Pairs the reference skips (type mismatch, both scores 0) become -inf. */
+int pfr_card_fuse_scores(float* head_scores, const float* body_scores, int rows, int ld, int n, int col0,
+                         const unsigned char* q_flags, const unsigned char* g_flags, const float* thresholds, int n_types,
+                         pfr_stream_t stream);
+
 /* Linear layer with a fused activation epilogue — the Swin MLP `FeedForward` (reference models/swin.py:40-52: Linear →
  * GELU → Linear) and its autograd.  x [M][K], w [N][K] (nn.Linear layout), y / y2 [M][N], all of `dtype`.
  *   act 2: y2 = x·wT + bias (pre-activation, kept for backward), y = gelu(y2)            (forward of the first Linear)

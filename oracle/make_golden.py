@@ -223,6 +223,46 @@ def gen_pairs():
     np.savez_compressed(os.path.join(OUT, "pairs.npz"), **out)
 
 
+def ref_calc_scores():
+    """generate_tsv.py's `similarity_f`, `mean_strategy_cal_scores`, `calc_scores` (:63-125), extracted by name — the
+    module itself imports the whole inference stack (mmdet pipelines, pandas CLI) at import time."""
+    import typing
+    from pathlib import Path
+    src = open(os.path.join(REF, "generate_tsv.py")).read()
+    tree = ast.parse(src)
+    want = ("similarity_f", "mean_strategy_cal_scores", "calc_scores")
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert len(fns) == len(want)
+    ns = {"torch": torch, "F": torch.nn.functional, "np": np, "Path": Path, "List": typing.List, "Dict": typing.Dict,
+          "Any": typing.Any, "tqdm": lambda it, **kw: it}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "generate_tsv.calc_scores", "exec"), ns)
+    return ns["calc_scores"]
+
+
+def gen_calc_scores():
+    from pathlib import Path
+    from oracle.match_ref import calc_scores_case
+    calc = ref_calc_scores()
+    (qh, qhs, qb, qbs, qt), (gh, ghs, gb, gbs, gt) = calc_scores_case()
+
+    def db(prefix, h, hs, b, bs, t):
+        return {Path(f"/cards/{prefix}{c:04d}"): {"head_vectors": [torch.from_numpy(v) for v in h[hs[c]:hs[c + 1]]],
+                                                  "body_vectors": [torch.from_numpy(v) for v in b[bs[c]:bs[c + 1]]],
+                                                  "type": int(t[c])} for c in range(len(t))}
+    rows = calc(db("q", qh, qhs, qb, qbs, qt), db("g", gh, ghs, gb, gbs, gt))
+    qrow = np.array([int(r[0][1:]) for r in rows])
+    ans = np.full((len(rows), 100), -1, np.int64)
+    for i, r in enumerate(rows):
+        a = [int(n[1:]) for n in r[4].split(",")]
+        ans[i, :len(a)] = a
+    np.savez_compressed(os.path.join(OUT, "calc_scores.npz"), q_head=qh, q_head_seg=qhs, q_body=qb, q_body_seg=qbs, q_type=qt,
+                        g_head=gh, g_head_seg=ghs, g_body=gb, g_body_seg=gbs, g_type=gt, rows_query=qrow,
+                        top1=np.array([r[1] for r in rows]), mean3=np.array([r[2] for r in rows]),
+                        mean10=np.array([r[3] for r in rows]), answer=ans)
+    print("calc_scores.npz:", len(rows), "rows of", len(qt), "queries; answers/row",
+          sorted(set((ans >= 0).sum(1).tolist()))[:4], "...")
+
+
 def gen_swin():
     ref = load_ref_module("ref_swin", "models/swin.py")
     torch.manual_seed(1234)
@@ -362,6 +402,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pairs":
         gen_pairs()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "calc_scores":
+        gen_calc_scores()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "arcface":
         gen_arcface(ref_losses())
         sys.exit(0)
@@ -369,6 +412,7 @@ if __name__ == "__main__":
     gen_arcface(L)
     gen_recall(ref_controller(), ref_similarity_f())
     gen_pairs()
+    gen_calc_scores()
     gen_swin()
     gen_train_trace(L)
     gen_resnet_hf()

@@ -86,3 +86,63 @@ def recall_loop_reference_cost(emb, classes, queries, ks=(10, 100)):
             out[k][0] += int((cls == oc[:k]).sum().item() != 0)
             out[k][1] += int((cls == oc).sum().item() != 0)
     return out
+
+
+def calc_scores_reference(q, g, k=100, thresholds=(0.9069641, 0.985643)):
+    """Restatement of /root/reference/generate_tsv.py:63-125 (`similarity_f`, `mean_strategy_cal_scores`, `calc_scores`)
+    on ragged arrays.  q, g: tuples (head [P,D], head_seg [n+1], body [P,D], body_seg [n+1], type [n]) of float32 /
+    int arrays.  → list of (query card index, top1, mean3, mean10, [gallery card indices, best first]); a query whose
+    candidate list is empty yields no row (:114).  Pinned by tests/golden/calc_scores.npz (written by running the
+    reference's own functions, oracle/make_golden.py:gen_calc_scores)."""
+    qh, qhs, qb, qbs, qt = q
+    gh, ghs, gb, gbs, gt = g
+
+    def mean_strategy(v1, v2):                      # :71-78 — every photo pair, (cos+1)/2, mean, clamp(min=0)
+        a = torch.from_numpy(np.repeat(v1, len(v2), axis=0))
+        b = torch.from_numpy(np.tile(v2, (len(v1), 1)))
+        return torch.mean(similarity_f(a, b)).clamp(min=0.0).item()
+
+    rows = []
+    for i in range(len(qt)):
+        v1, v1_body, type_ = qh[qhs[i]:qhs[i + 1]], qb[qbs[i]:qbs[i + 1]], int(qt[i])
+        cand = []
+        for j in range(len(gt)):
+            if int(gt[j]) != type_:                 # :100-101
+                continue
+            v2, v2_body = gh[ghs[j]:ghs[j + 1]], gb[gbs[j]:gbs[j + 1]]
+            s0 = mean_strategy(v1, v2) if len(v1) and len(v2) else 0
+            s1 = mean_strategy(v1_body, v2_body) if len(v1_body) and len(v2_body) else 0
+            if s0 + s1 == 0:                        # :107-108
+                continue
+            cand.append((j, s1 if len(v1) == 0 or (s0 == 0 and s1 > thresholds[type_ - 1]) else s0))   # :109
+        cand.sort(key=lambda x: x[1], reverse=True)  # stable: ties keep gallery order
+        if cand:
+            sc = [c[1] for c in cand]
+            rows.append((i, sc[0], float(np.mean(sc[:3])), float(np.mean(sc[:10])), [c[0] for c in cand[:k]]))
+    return rows
+
+
+def calc_scores_case(seed=11, Q=24, G=260, D=32, n_id=40):
+    """ragged synthetic cards: identities shared between query and gallery cards so that some body scores clear the
+    fusion thresholds; cards without head vectors, without body vectors, and without either"""
+    rs = np.random.RandomState(seed)
+    ident_h = rs.randn(n_id, D).astype(np.float32)
+    ident_b = rs.randn(n_id, D).astype(np.float32)
+
+    def cards(n, first_ids):
+        head, body, hs, bs, types = [], [], [0], [0], []
+        for c in range(n):
+            i = first_ids[c] if c < len(first_ids) else rs.randint(n_id)
+            types.append(1 + i % 2)
+            u = rs.rand()
+            nh = 0 if u < 0.25 else rs.randint(1, 5)
+            nb = 0 if 0.2 < u < 0.4 or u > 0.93 else rs.randint(1, 4)     # u in (0.2, 0.25): neither modality
+            noise = [0.05, 0.15, 0.6][rs.randint(3)]
+            head.extend(ident_h[i] + noise * rs.randn(D).astype(np.float32) for _ in range(nh))
+            body.extend(ident_b[i] + noise * rs.randn(D).astype(np.float32) for _ in range(nb))
+            hs.append(len(head))
+            bs.append(len(body))
+        return (np.stack(head).astype(np.float32), np.array(hs), np.stack(body).astype(np.float32), np.array(bs),
+                np.array(types))
+
+    return cards(Q, list(range(Q))), cards(G, list(range(n_id)) * 2)

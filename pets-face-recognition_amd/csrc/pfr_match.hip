@@ -395,3 +395,45 @@ extern "C" int pfr_card_centroids(const float* emb, const long* seg, int ncards,
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
+
+// Head/body score fusion of the inference ranking (generate_tsv.py:91-110).  In: the two centroid dot-product chunks
+// (head, body) of a query block against a gallery chunk.  Out (over `head`): the fused card score, −inf where the
+// reference `continue`s (different species `type`, or both modality scores 0).
+//   s0 = both cards have head vectors ? max((dot_head + 1)/2, 0) : 0        (mean_strategy_cal_scores, :71-78)
+//   s1 = both cards have body vectors ? max((dot_body + 1)/2, 0) : 0
+//   score = (query has no head vectors || (s0 == 0 && s1 > thr[type-1])) ? s1 : s0          (:107)
+// flags byte per card: bit 0 = has head vectors, bit 1 = has body vectors, bits 2..7 = type.
+struct FuseThr { float v[8]; };
+__global__ __launch_bounds__(256) void card_fuse_kernel(float* __restrict__ head, const float* __restrict__ body, int ld, int n,
+                                                        int col0, const unsigned char* __restrict__ qf,
+                                                        const unsigned char* __restrict__ gf, FuseThr thr) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int r = blockIdx.y;
+  const unsigned q = qf[r], g = gf[col0 + j];
+  const size_t o = (size_t)r * ld + j;
+  float out = -INFINITY;
+  if ((q >> 2) == (g >> 2)) {
+    const float s0 = (q & g & 1u) ? fmaxf((head[o] + 1.f) * 0.5f, 0.f) : 0.f;
+    const float s1 = (q & g & 2u) ? fmaxf((body[o] + 1.f) * 0.5f, 0.f) : 0.f;
+    if (s0 + s1 != 0.f) {
+      const unsigned t = (q >> 2) - 1u;
+      const float th = thr.v[t < 8u ? t : 7u];
+      out = (!(q & 1u) || (s0 == 0.f && s1 > th)) ? s1 : s0;
+    }
+  }
+  head[o] = out;
+}
+
+extern "C" int pfr_card_fuse_scores(float* head_scores, const float* body_scores, int rows, int ld, int n, int col0,
+                                    const unsigned char* q_flags, const unsigned char* g_flags, const float* thresholds,
+                                    int n_types, hipStream_t st) {
+  PFR_CHECK_ARG(head_scores && body_scores && q_flags && g_flags && thresholds, "pfr_card_fuse_scores: null pointer");
+  PFR_CHECK_ARG(rows > 0 && n > 0 && ld >= n && n_types >= 1 && n_types <= 8 && rows <= 65535, "pfr_card_fuse_scores: bad sizes");
+  FuseThr t;
+  for (int i = 0; i < 8; ++i) t.v[i] = thresholds[i < n_types ? i : n_types - 1];
+  hipLaunchKernelGGL(card_fuse_kernel, dim3((n + 255) / 256, rows), dim3(256), 0, st, head_scores, body_scores, ld, n, col0,
+                     q_flags, g_flags, t);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}

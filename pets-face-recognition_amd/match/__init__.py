@@ -172,6 +172,125 @@ def card_match(q_emb, q_seg, g_emb, g_seg, k=100, compute_dtype=torch.bfloat16):
     return ((dots + 1) / 2).clamp_min(0), idx
 
 
+FUSION_THRESHOLDS = (0.9069641, 0.985643)   # generate_tsv.py:107, indexed by species `type` - 1
+
+
+def _card_flags(head_seg, body_seg, types, device):
+    """flags byte per card: bit 0 = has head vectors, bit 1 = has body vectors, bits 2..7 = species type"""
+    hs = torch.as_tensor(head_seg, dtype=torch.int64)
+    bs = torch.as_tensor(body_seg, dtype=torch.int64)
+    t = torch.as_tensor(types, dtype=torch.int64)
+    if not (hs.numel() == bs.numel() == t.numel() + 1):
+        raise PfrError("calc_scores: head_seg / body_seg need ncards+1 offsets, types ncards entries")
+    if int(t.min()) < 1 or int(t.max()) > 63:
+        raise PfrError("calc_scores: species type must be in 1..63")
+    f = (hs[1:] > hs[:-1]).long() | ((bs[1:] > bs[:-1]).long() << 1) | (t << 2)
+    return f.to(torch.uint8).to(device).contiguous()
+
+
+def calc_scores(q_head, q_head_seg, q_body, q_body_seg, q_type, g_head, g_head_seg, g_body, g_body_seg, g_type, k=100,
+                thresholds=FUSION_THRESHOLDS, chunk=32768):
+    """Card-vs-card ranking of the reference's inference pipeline WITH its head/body fusion rule
+    (generate_tsv.py:91-125 `calc_scores`), on the device.
+
+    Query cards (the reference's `init_db`) and gallery cards (`extra_db`) are given per modality as ragged photo-embedding
+    matrices: `*_head [P, D]` + `*_head_seg [ncards+1]` row offsets (an empty range = the card has no head vectors),
+    likewise `*_body`; `*_type [ncards]` is the species id (1 or 2).  Per (query card, gallery card) pair:
+        skip when types differ                                                               (:100-101)
+        s0 = mean-strategy head score if both have head vectors else 0                        (:103-104, :71-78)
+        s1 = mean-strategy body score if both have body vectors else 0                        (:105-106)
+        skip when s0 + s1 == 0                                                                (:107-108)
+        score = s1 if (query has no head vectors or (s0 == 0 and s1 > thresholds[type-1])) else s0   (:109)
+    then descending sort, best `k` (=100) gallery cards, and the (top-1, mean of best 3, mean of best 10) columns (:112-123).
+
+    The mean over the photo cross product of (cos+1)/2 is (⟨centroid_q, centroid_g⟩ + 1)/2, so each modality is one fp32
+    GEMM of card centroids per gallery chunk; `pfr_card_fuse_scores` applies the rule in place and the running top-k
+    kernel keeps the best k.  Ties → lower gallery index (Python's stable `sorted(reverse=True)` keeps dict order).
+    → dict(scores [Q,k] fp32, idx [Q,k] int32 (−1 past the end of a short list), count [Q], top1, mean3, mean10 [Q] fp64).
+    A query with count 0 gets no row in the reference; with fewer than 3 / 10 entries the reference raises IndexError,
+    here the available ones are averaged."""
+    dev = q_head.device if q_head.numel() else q_body.device
+    if dev.type != "cuda":
+        raise PfrError("calc_scores runs on the gfx950 device only (tests use oracle/match_ref.py as the CPU checker)")
+    if k > 512:
+        raise PfrError(f"calc_scores: k={k} exceeds the 512-entry running list of the gfx950 top-K kernels")
+    qf = _card_flags(q_head_seg, q_body_seg, q_type, dev)
+    gf = _card_flags(g_head_seg, g_body_seg, g_type, dev)
+    Q, G = qf.numel(), gf.numel()
+    if Q > 65535:
+        raise PfrError("calc_scores: split the query cards into blocks of <= 65535")
+
+    def cents(emb, seg, n):
+        if emb.numel() == 0:
+            return None
+        return card_centroids(emb.to(dev), seg)
+
+    qc = (cents(q_head, q_head_seg, Q), cents(q_body, q_body_seg, Q))
+    gc = (cents(g_head, g_head_seg, G), cents(g_body, g_body_seg, G))
+    chunk = min(chunk, G)
+    ld = (chunk + 3) // 4 * 4
+    sb = [torch.zeros((Q, 1, 1, ld), dtype=torch.float32, device=dev) for _ in range(2)]
+    state = torch.empty(lib.pfr_topk_state_bytes(Q, k), dtype=torch.uint8, device=dev)
+    lib.pfr_topk_reset(state.data_ptr(), Q, k, _stream())
+    thr = (ctypes.c_float * len(thresholds))(*thresholds)
+    for c0 in range(0, G, chunk):
+        n = min(chunk, G - c0)
+        for m in range(2):
+            if qc[m] is not None and gc[m] is not None:   # a modality nobody has stays 0 and is masked by the flags
+                D = qc[m].shape[1]
+                ops.conv2d_fwd(qc[m].view(Q, 1, 1, D), gc[m][c0:c0 + n].view(n, 1, 1, D), out=sb[m])
+        lib.pfr_card_fuse_scores(sb[0].data_ptr(), sb[1].data_ptr(), Q, ld, n, c0, qf.data_ptr(), gf.data_ptr(),
+                                 ctypes.addressof(thr), len(thresholds), _stream())
+        lib.pfr_topk_update(sb[0].data_ptr(), Q, ld, n, c0, k, state.data_ptr(), 0, _stream())
+    sc = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((Q, k), dtype=torch.int32, device=dev)
+    lib.pfr_topk_finish(state.data_ptr(), Q, k, sc.data_ptr(), idx.data_ptr(), _stream())
+    skipped = torch.isinf(sc) & (sc < 0)          # pairs the reference `continue`s sort last; drop them
+    idx = torch.where(skipped, torch.full_like(idx, -1), idx)
+    count = (~skipped).sum(1)
+    s64 = torch.where(skipped, torch.zeros_like(sc), sc).double()
+    cs = s64.cumsum(1)
+
+    def mean_first(m):
+        m_eff = count.clamp(min=1, max=min(m, k))
+        return cs.gather(1, (m_eff - 1)[:, None])[:, 0] / m_eff
+    return {"scores": sc, "idx": idx, "count": count, "top1": s64[:, 0], "mean3": mean_first(3), "mean10": mean_first(10)}
+
+
+def calc_scores_db(init_db, extra_db, device="cuda", k=100, thresholds=FUSION_THRESHOLDS):
+    """`calc_scores(init_db, extra_db)` with the reference's own argument and return types (generate_tsv.py:91-125):
+    both dbs map a card path to {'head_vectors': [tensor], 'body_vectors': [tensor], 'type': int}; → list of
+    (query name, top-1 score, mean of best 3, mean of best 10, ','-joined names of the best `k` gallery cards)."""
+    from pathlib import Path
+
+    def pack(db):
+        names, types, head, body, hs, bs = [], [], [], [], [0], [0]
+        for f, card in db.items():
+            names.append(Path(f).name)
+            types.append(int(card['type']))
+            head.extend(card['head_vectors'])
+            body.extend(card['body_vectors'])
+            hs.append(len(head))
+            bs.append(len(body))
+        cat = lambda v: torch.stack([t.reshape(-1).float() for t in v]).to(device) if v else torch.empty((0, 0), device=device)
+        return names, cat(head), hs, cat(body), bs, types
+
+    qn, qh, qhs, qb, qbs, qt = pack(init_db)
+    gn, gh, ghs, gb, gbs, gt = pack(extra_db)
+    if not qn or not gn:
+        return []
+    r = calc_scores(qh, qhs, qb, qbs, qt, gh, ghs, gb, gbs, gt, k=k, thresholds=thresholds)
+    idx, cnt = r["idx"].cpu(), r["count"].cpu()
+    top1, m3, m10 = r["top1"].cpu(), r["mean3"].cpu(), r["mean10"].cpu()
+    rows = []
+    for i, name in enumerate(qn):
+        if int(cnt[i]) == 0:
+            continue
+        rows.append((str(name), float(top1[i]), float(m3[i]), float(m10[i]),
+                     ','.join(gn[j] for j in idx[i, :int(cnt[i])].tolist())))
+    return rows
+
+
 def cosine_topk_sharded(q, g_local, k, g_offset, group=None, **kw):
     """Gallery sharded by rows across the ranks of `group` (each rank holds rows [g_offset, g_offset + len(g_local))),
     queries replicated: local GEMM + top-k per rank, ONE all-gather of the (score, index) lists (k·8 bytes per query

@@ -195,3 +195,68 @@ def test_controller_eval_on_gpu_equals_reference_metrics(name):
     from pets_face_recognition_amd.engine import metrics as M
     ref_scores = custom_sim([(emb[a], emb[b]) for a, b in pairs])
     assert abs(m2["ROC AUC"] - M.auroc(ref_scores, torch.tensor(plabels))) < 1e-6
+
+
+def _calc_scores_golden():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "calc_scores.npz"))
+    q = [z[k] for k in ("q_head", "q_head_seg", "q_body", "q_body_seg", "q_type")]
+    g = [z[k] for k in ("g_head", "g_head_seg", "g_body", "g_body_seg", "g_type")]
+    return z, q, g
+
+
+def _check_calc_scores(res_idx, res_sc, cnt, top1, m3, m10, rows):
+    """rows: reference-order (query, top1, mean3, mean10, answer list).  Order must agree except between entries whose
+    reference scores are closer than fp32 accumulation noise."""
+    have = {r[0]: r for r in rows}
+    for qi in range(res_idx.shape[0]):
+        if qi not in have:
+            assert cnt[qi] == 0 and (res_idx[qi] == -1).all()
+            continue
+        _, t1, rm3, rm10, ans = have[qi]
+        n = len(ans)
+        assert cnt[qi] == n and (res_idx[qi, n:] == -1).all()
+        assert abs(top1[qi] - t1) < 2e-6 and abs(m3[qi] - rm3) < 2e-6 and abs(m10[qi] - rm10) < 2e-6
+        got = res_idx[qi, :n].tolist()
+        assert sorted(got) == sorted(ans) or n == 100          # same candidate set when nothing is cut off
+        sc = res_sc[qi, :n]
+        for p, (a, b) in enumerate(zip(got, ans)):
+            if a != b:                                          # a swap is only admissible inside a near-tie
+                assert b in got and abs(sc[p] - sc[got.index(b)]) < 2e-6, (qi, p, a, b)
+
+
+@pytest.mark.gpu
+def test_calc_scores_fusion_rule_equals_reference_rows():
+    """generate_tsv.py:91-125 on the device (centroid GEMMs + pfr_card_fuse_scores + running top-100) vs the rows the
+    reference's own calc_scores wrote into tests/golden/calc_scores.npz, and vs the oracle at a larger ragged case"""
+    from pets_face_recognition_amd.match import calc_scores, calc_scores_db
+    from oracle.match_ref import calc_scores_reference
+    z, q, g = _calc_scores_golden()
+    dev = lambda t: [torch.from_numpy(t[0]).to(DEV), t[1], torch.from_numpy(t[2]).to(DEV), t[3], t[4]]
+    for chunk in (32768, 64):                                   # one chunk / several gallery chunks
+        r = calc_scores(*dev(q), *dev(g), k=100, chunk=chunk)
+        rows = [(int(qi), t1, a, b, ans[ans >= 0].tolist())
+                for qi, t1, a, b, ans in zip(z["rows_query"], z["top1"], z["mean3"], z["mean10"], z["answer"])]
+        _check_calc_scores(r["idx"].cpu().numpy(), r["scores"].cpu().numpy(), r["count"].cpu().numpy(), r["top1"].cpu().numpy(),
+                           r["mean3"].cpu().numpy(), r["mean10"].cpu().numpy(), rows)
+
+    # the reference's own argument / return types
+    from pathlib import Path
+    def db(prefix, t):
+        h, hs, b, bs, ty = t
+        return {Path(f"/cards/{prefix}{c:04d}"): {"head_vectors": [torch.from_numpy(v) for v in h[hs[c]:hs[c + 1]]],
+                                                  "body_vectors": [torch.from_numpy(v) for v in b[bs[c]:bs[c + 1]]],
+                                                  "type": int(ty[c])} for c in range(len(ty))}
+    out = calc_scores_db(db("q", q), db("g", g), device=DEV)
+    assert [o[0] for o in out] == [f"q{int(i):04d}" for i in z["rows_query"]]
+    for o, t1, ans in zip(out, z["top1"], z["answer"]):
+        assert abs(o[1] - t1) < 2e-6
+        names = o[4].split(",")
+        assert len(names) == int((ans >= 0).sum()) and names[0] == f"g{int(ans[0]):04d}"
+
+    # a second ragged case (other seed, D=64) against the oracle restatement
+    from oracle.match_ref import calc_scores_case
+    qq, gg = calc_scores_case(seed=5, Q=16, G=700, D=64, n_id=90)
+    rows = calc_scores_reference(qq, gg)
+    r = calc_scores(*dev(list(qq)), *dev(list(gg)), k=100, chunk=256)
+    _check_calc_scores(r["idx"].cpu().numpy(), r["scores"].cpu().numpy(), r["count"].cpu().numpy(), r["top1"].cpu().numpy(),
+                       r["mean3"].cpu().numpy(), r["mean10"].cpu().numpy(), rows)

@@ -256,3 +256,25 @@ def test_pair_generator_seeded_equivalent_to_reference(name):
     assert [pg.correction[k] for k in sorted(pg.correction)] == G[f"{name}_corr_vals"].tolist()
     assert np.array_equal(np.array(pg.corrected_indices), G[f"{name}_corrected"])
     assert pg.indices == [tuple(r[:2]) for r in G[f"{name}_pairs"].tolist()]
+
+
+def _calc_scores_fixture():
+    z = np.load(os.path.join(GOLD, "calc_scores.npz"))
+    q = tuple(z[k] for k in ("q_head", "q_head_seg", "q_body", "q_body_seg", "q_type"))
+    g = tuple(z[k] for k in ("g_head", "g_head_seg", "g_body", "g_body_seg", "g_type"))
+    return z, q, g
+
+
+def test_calc_scores_restatement_equals_reference_rows():
+    """oracle/match_ref.calc_scores_reference vs the rows generate_tsv.py's own calc_scores produced (fusion rule, type
+    filter, skipped pairs, stable descending order, top-100 answers, top-1 / mean-3 / mean-10 columns)"""
+    from oracle.match_ref import calc_scores_reference
+    z, q, g = _calc_scores_fixture()
+    rows = calc_scores_reference(q, g)
+    assert [r[0] for r in rows] == z["rows_query"].tolist()
+    assert len(rows) < len(q[4])                     # the fixture holds query cards without any usable modality
+    for r, t1, m3, m10, ans in zip(rows, z["top1"], z["mean3"], z["mean10"], z["answer"]):
+        assert abs(r[1] - t1) < 1e-6 and abs(r[2] - m3) < 1e-6 and abs(r[3] - m10) < 1e-6
+        assert r[4] == ans[ans >= 0].tolist()
+    # the fixture exercises every branch of the rule
+    assert any((a >= 0).sum() < 100 for a in z["answer"]) and any((a >= 0).sum() == 100 for a in z["answer"])
