@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # main + side + comm + RCCL streams must not share hardware queues (see package __init__)
 
 import torch
@@ -258,7 +260,65 @@ def extras(args, device):
                          "sample": "reference per-query python loop restated (controller.py:77-90) on 250 of 2000 queries x 1999 others; "
                                    "torch.mm + topk fp32 at 10k x 1M in query blocks of 500"}
     out["match_10kx1M"] = m
+    out["augment_bs256"] = augment_extra(device)
     return out
+
+
+def augment_extra(device):
+    """the train Compose pipeline of fe_dogs_config.py:17-26 on a 256 x 224 x 224 x 3 uint8 batch: device rate,
+    HBM roofline on the algorithmic bytes (uint8 frame in, float32 NCHW out), and the PIL pipeline on one host core"""
+    from pets_face_recognition_amd.data_loading import train_augmentation
+    N = 256
+    x = torch.randint(0, 256, (N, 224, 224, 3), dtype=torch.uint8, device=device)
+    aug = train_augmentation(torch.Generator().manual_seed(3))
+    flags, angles = aug.draw(N, 224, 224)
+    for _ in range(3):
+        aug.apply(x, flags, angles)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        y = aug.apply(x, flags, angles)
+    torch.cuda.synchronize()
+    dt_e2e = (time.perf_counter() - t0) / 20
+    # device-only time of the two kernels: records resident, HIP events on the launch stream
+    from pets_face_recognition_amd._hip import lib
+    rec = torch.zeros((N, 12), dtype=torch.int32)
+    lib.pfr_augment_params(flags.numpy().ctypes.data, angles.numpy().ctypes.data, N, 224, 224, rec.data_ptr())
+    rec = rec.to(device)
+    ws = torch.empty(lib.pfr_augment_ws_bytes(N, 224, 224), dtype=torch.uint8, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    e0.record()
+    for _ in range(20):
+        lib.pfr_augment_train(x.data_ptr(), N, 224, 224, 220, 220, 224, 224, rec.data_ptr(), y.data_ptr(), ws.data_ptr(), st)
+    e1.record()
+    torch.cuda.synchronize()
+    dt_k = e0.elapsed_time(e1) / 20 / 1e3
+    nbytes = N * 224 * 224 * 3 * (1 + 4)
+    res = {"value": round(N / dt_e2e, 1), "unit": "images/sec", "ms_per_batch": round(dt_e2e * 1e3, 3), "dtype": "u8",
+           "kernels_ms_per_batch": round(dt_k * 1e3, 4),
+           "roofline": {"bound": "hbm", "achieved": round(nbytes / dt_k / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(nbytes / dt_k / 8e12, 4), "note": "uint8 frame read + float32 NCHW written, per batch"}}
+    try:
+        from PIL import Image, ImageEnhance, ImageOps
+        xs = x[:64].cpu().numpy()
+        fl, an = flags.numpy(), angles.numpy()
+        t0 = time.perf_counter()
+        for i in range(64):
+            im = Image.fromarray(xs[i])
+            if fl[i, 0]:
+                im = ImageEnhance.Sharpness(im).enhance(0)
+            if fl[i, 1]:
+                im = ImageOps.autocontrast(im)
+            im = im.crop((int(fl[i, 3]), int(fl[i, 2]), int(fl[i, 3]) + 220, int(fl[i, 2]) + 220)).resize((224, 224), Image.BILINEAR)
+            im = im.rotate(float(an[i]), Image.NEAREST, fillcolor=(0, 0, 0))
+            t = torch.from_numpy(np.asarray(im)).permute(2, 0, 1).float().div(255)
+        dt_c = (time.perf_counter() - t0) / 64
+        res["cpu_baseline"] = {"value": round(1 / dt_c, 1), "unit": "images/sec", "cores": 1, "kind": "reference",
+                               "sample": "the same Pillow calls torchvision's PIL transforms make, 64 images, one dataloader worker"}
+    except ImportError:
+        res["cpu_baseline"] = None
+    return res
 
 
 def main():

@@ -263,6 +263,18 @@ int pfr_card_fuse_scores(float* head_scores, const float* body_scores, int rows,
                          const unsigned char* q_flags, const unsigned char* g_flags, const float* thresholds, int n_types,
                          pfr_stream_t stream);
 
+/* ---- train-time augmentation on the device (configs/dog_fe/fe_dogs_config.py:17-26: RandomAdjustSharpness(0, 0.1),
+ * RandomAutocontrast(0.3), RandomCrop((220, 220)), Resize((224, 224)), RandomRotation(5), ToTensor), bit-exact with the
+ * Pillow arithmetic torchvision's PIL-image transforms run (oracle/augment_ref.py).
+ * pfr_augment_params (HOST arrays in, HOST array out; no device work): flags int32 [N][4] = (apply sharpness, apply
+ * autocontrast, crop top, crop left), angles float32 [N] degrees → records int32 [N][12] (the flags + Pillow's 16.16
+ * fixed-point inverse rotation about the centre of the out_w x out_h image).  Upload `records` and pass it below.
+ * pfr_augment_train: x uint8 [N][H][W][3] → y float32 [N][3][out_h][out_w] in [0, 1]; ws: pfr_augment_ws_bytes. */
+int pfr_augment_params(const int* flags, const float* angles, int N, int out_w, int out_h, int* records);
+long pfr_augment_ws_bytes(int N, int H, int W);
+int pfr_augment_train(const unsigned char* x, int N, int H, int W, int crop_h, int crop_w, int out_h, int out_w,
+                      const int* records, float* y, void* ws, pfr_stream_t stream);
+
 /* Linear layer with a fused activation epilogue — the Swin MLP `FeedForward` (reference models/swin.py:40-52: Linear →
  * GELU → Linear) and its autograd.  x [M][K], w [N][K] (nn.Linear layout), y / y2 [M][N], all of `dtype`.
  *   act 2: y2 = x·wT + bias (pre-activation, kept for backward), y = gelu(y2)            (forward of the first Linear)

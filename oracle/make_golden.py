@@ -263,6 +263,42 @@ def gen_calc_scores():
           sorted(set((ans >= 0).sum(1).tolist()))[:4], "...")
 
 
+def gen_augment():
+    """tests/golden/augment.npz: the train augmentation of fe_dogs_config.py:17-26 executed with PILLOW's own functions
+    (the calls torchvision's PIL backend makes; torchvision itself is not installed here) for fixed random decisions."""
+    from PIL import Image, ImageEnhance, ImageOps
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_augment_oracle import _images
+    out = {}
+    for tag, n, H, W, crop, size in (("full", 4, 224, 224, 220, 224), ("small", 10, 48, 52, 44, 48)):
+        x = np.stack(_images(17, n, H, W))
+        g = torch.Generator().manual_seed(100 + n)
+        flags = np.stack([(torch.rand(n, generator=g) < 0.5).int().numpy(), (torch.rand(n, generator=g) < 0.5).int().numpy(),
+                          torch.randint(0, H - crop + 1, (n,), generator=g).int().numpy(),
+                          torch.randint(0, W - crop + 1, (n,), generator=g).int().numpy()], 1).astype(np.int32)
+        flags[0, :2] = (1, 1)
+        flags[1, :2] = (0, 0)
+        flags[2, :2] = (1, 0)
+        flags[3, :2] = (0, 1)
+        angles = torch.empty(n).uniform_(-5, 5, generator=g).numpy()
+        res = []
+        for i in range(n):
+            im = Image.fromarray(x[i])
+            if flags[i, 0]:
+                im = ImageEnhance.Sharpness(im).enhance(0)
+            if flags[i, 1]:
+                im = ImageOps.autocontrast(im)
+            t, l = int(flags[i, 2]), int(flags[i, 3])
+            im = im.crop((l, t, l + crop, t + crop))
+            im = im.resize((size, size), Image.BILINEAR)
+            im = im.rotate(float(angles[i]), Image.NEAREST, expand=False, center=None, fillcolor=(0, 0, 0))
+            res.append(np.asarray(im))
+        out.update({f"{tag}_x": x, f"{tag}_flags": flags, f"{tag}_angles": angles, f"{tag}_out": np.stack(res),
+                    f"{tag}_crop": crop, f"{tag}_size": size})
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
+    print("augment.npz:", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def gen_swin():
     ref = load_ref_module("ref_swin", "models/swin.py")
     torch.manual_seed(1234)
@@ -402,6 +438,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pairs":
         gen_pairs()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":
+        gen_augment()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "calc_scores":
         gen_calc_scores()
         sys.exit(0)
@@ -413,6 +452,7 @@ if __name__ == "__main__":
     gen_recall(ref_controller(), ref_similarity_f())
     gen_pairs()
     gen_calc_scores()
+    gen_augment()
     gen_swin()
     gen_train_trace(L)
     gen_resnet_hf()

@@ -15,9 +15,9 @@ from losses import SoftmaxBasedMetricLearning
 
 
 def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs, device, n_epochs=1, seed=0,
-         fused_optimizer=True, compute_dtype=None, limit_train_batches=None, workers=0, n_pairs=200):
+         fused_optimizer=True, compute_dtype=None, limit_train_batches=None, workers=0, n_pairs=200, device_augment=False):
     torch.manual_seed(seed)
-    dataset = SyntheticRecDataset(n_train_ids + n_val_ids, photos, image_size, seed=seed)
+    dataset = SyntheticRecDataset(n_train_ids + n_val_ids, photos, image_size, seed=seed, raw_uint8=device_augment)
     train_users = list(range(n_train_ids))
     val_users = list(range(n_train_ids, n_train_ids + n_val_ids))
     labels = dataset.get_labels()
@@ -71,6 +71,12 @@ def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs
     def val_dataloader():
         return DataLoader(val, test_bs, num_workers=0)
 
+    if device_augment:
+        # the reference's train/val Compose pipelines (fe_dogs_config.py:17-32) applied on the device to uint8 batches
+        from data_loading import DeviceAugmentation, val_augmentation
+        ns['device_train_augmentation'] = DeviceAugmentation((image_size - 4, image_size - 4), (image_size, image_size), 0.1, 0.3,
+                                                             5.0, torch.Generator().manual_seed(seed))
+        ns['device_val_augmentation'] = val_augmentation()
     output = Path('results')
     output.mkdir(exist_ok=True)
     ns.update(dict(

@@ -8,8 +8,11 @@ from torch.utils.data import Dataset
 
 
 class SyntheticRecDataset(Dataset):
-    def __init__(self, n_identities, photos_per_identity, image_size=224, seed=0, noise=0.15):
+    def __init__(self, n_identities, photos_per_identity, image_size=224, seed=0, noise=0.15, raw_uint8=False):
         self.n_id, self.ppi, self.size, self.seed, self.noise = n_identities, photos_per_identity, image_size, seed, noise
+        # raw_uint8: hand out the HWC uint8 frame the reference's dataset holds BEFORE its transform (dataset.py:100-121);
+        # the augmentation then runs on the device for the whole batch (data_loading/augment.py)
+        self.raw_uint8 = raw_uint8
         self.labels = torch.arange(n_identities).repeat_interleave(photos_per_identity)
         self.label_map = {u: u for u in range(n_identities)}
         # identity -> dataset indices, the attribute the reference's PairGenerator samples from (dataset.py:93-96)
@@ -33,6 +36,8 @@ class SyntheticRecDataset(Dataset):
         ident = int(self.labels[i])
         g = torch.Generator().manual_seed(self.seed * 7919 + i)
         x = (self._pattern(ident) + self.noise * torch.randn(3, self.size, self.size, generator=g)).clamp_(0, 1)
+        if self.raw_uint8:
+            x = (x * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous()
         return {'x': x, 'label': torch.tensor(self.label_map[ident], dtype=torch.int64), 'index': torch.tensor(i, dtype=torch.int64)}
 
 

@@ -36,11 +36,21 @@ class Controller(nn.Module):
         return self.model_loss(*args, **kwargs)
 
     # ------------------------------------------------------------------ steps
+    def _images(self, x, train):
+        """uint8 [N, H, W, 3] batches are raw frames: the config's device-side Compose pipeline (the reference's
+        train_augmentation / val_augmentation, fe_dogs_config.py:17-32) turns them into the float NCHW batch"""
+        if x.dtype != torch.uint8:
+            return x
+        aug = self.config.get('device_train_augmentation' if train else 'device_val_augmentation')
+        if aug is None:
+            raise ValueError("uint8 image batch but the config defines no device_train_augmentation / device_val_augmentation")
+        return aug(x)
+
     def training_step(self, batch, batch_idx=0):
-        return self.model_loss(batch['x'], batch['label'])['loss']
+        return self.model_loss(self._images(batch['x'], True), batch['label'])['loss']
 
     def validation_step(self, batch, batch_idx=0, dataset_idx=0):
-        return {'emb': self.model_loss(batch['x']), 'label': batch['label'], 'index': batch['index']}
+        return {'emb': self.model_loss(self._images(batch['x'], False)), 'label': batch['label'], 'index': batch['index']}
 
     def test_step(self, batch, batch_idx=0, dataset_idx=0):
         return self.validation_step(batch, batch_idx, dataset_idx)

@@ -34,6 +34,25 @@ def test_main_on_hip_device(tmp_path):
     assert int(sd["model_loss.module.bn1.num_batches_tracked"]) == 12   # 2 epochs x 6 train batches
 
 
+def test_main_with_device_augmentation(tmp_path):
+    """uint8 HWC frames from the dataset, the reference's train/val Compose pipelines on the device (pfr_augment.hip)"""
+    cfg = tmp_path / "fe_small_aug.py"
+    common = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic")
+    cfg.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {common!r})
+        from _common import make as _make
+        _make(globals(), arch='resnet18', n_train_ids=24, n_val_ids=10, photos=4, image_size=64, train_bs=16, test_bs=8,
+              device='cuda:0', n_epochs=1, n_pairs=30, device_augment=True)
+    """))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", str(cfg)], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])   # a uint8 batch reaching the model would raise
+    assert "Completed!" in r.stdout and "Val Recall@K=10" in r.stdout
+    losses = [float(l.split("loss")[1]) for l in r.stdout.splitlines() if l.startswith("epoch") and "loss" in l]
+    assert losses and all(l == l for l in losses)
+
+
 _DDP_SCRIPT = r"""
 import os, sys, torch
 sys.path.insert(0, {root!r})
