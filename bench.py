@@ -420,24 +420,48 @@ def main():
         fence()
     if rank == 0 and tr is not None:
         summ = tr.summary()
+        # per launch geometry: FLOPs, algorithmic HBM bytes (input + output activations + weights, each once) and the
+        # bound time max(FLOPs / MFMA peak, bytes / HBM peak) -- most ResNet-50 layers at bs 256 are HBM-bound, so the
+        # whole-family MFMA fraction above cannot approach 1; `layer_bound` is the sum of the per-launch bounds over the
+        # measured time of the same launches
+        esz = 2 if args.dtype == "bf16" else 4
+        det = {}
+        for name, a, e0, e1 in tr.records:
+            if name == "pfr_conv2d_fwd":
+                key = "fwd N%d H%d W%d C%d Co%d R%d s%d dil%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], a[15], 1 if a[22] else 0)
+                fl = 2.0 * a[5] * a[15] * a[16] * a[9] * a[10] * a[11] * a[8] / (4 ** a[14])
+                by = esz * (a[5] * a[6] * a[7] * a[8] + a[5] * a[15] * a[16] * a[9] + a[9] * a[10] * a[11] * a[8])
+            elif name == "pfr_conv2d_wgrad":
+                key = "wgrad N%d H%d W%d C%d Co%d R%d s%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], 1 if a[17] else 0)
+                fl = 2.0 * a[5] * a[14] * a[15] * a[9] * a[10] * a[11] * a[8]
+                by = esz * (a[5] * a[6] * a[7] * a[8] + a[5] * a[14] * a[15] * a[9]) + 4 * a[9] * a[10] * a[11] * a[8]
+            elif name == "pfr_conv2d_dgrad_join":
+                # (dy, wt, dx, dtype, N, H, W, C, Cout, R, S, pad, idil, OH, OW, res, mask): reads dy + res, writes dx
+                key = "dgrad_join N%d H%d W%d C%d Co%d R%d dil%d OH%d" % (a[4], a[5], a[6], a[7], a[8], a[9], a[12], a[13])
+                fl = 2.0 * a[4] * a[13] * a[14] * a[8] * a[9] * a[10] * a[7] / (4 ** a[12])
+                by = esz * (a[4] * a[5] * a[6] * a[7] + 2 * a[4] * a[13] * a[14] * a[8] + a[8] * a[9] * a[10] * a[7])
+            else:
+                key, fl, by = name, 0.0, 0.0
+            d = det.setdefault(key, [0, 0.0, fl, by])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+        peak_f, peak_b = PEAK_TFLOPS[args.dtype] * 1e12, 8.0e12
+        lb_ms = lb_meas = lb_hbm = 0.0
+        for k, v in det.items():
+            if v[2]:
+                n = v[0] / nprof
+                lb_ms += n * max(v[2] / peak_f, v[3] / peak_b) * 1e3
+                lb_hbm += n * (v[3] / peak_b) * 1e3
+                lb_meas += v[1] / nprof
         if args.detail:
-            det = {}
-            for name, a, e0, e1 in tr.records:
-                if name == "pfr_conv2d_fwd":
-                    key = "fwd N%d H%d W%d C%d Co%d R%d s%d dil%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], a[15], 1 if a[22] else 0)
-                    fl = 2.0 * a[5] * a[15] * a[16] * a[9] * a[10] * a[11] * a[8] / (4 ** a[14])
-                elif name == "pfr_conv2d_wgrad":
-                    key = "wgrad N%d H%d W%d C%d Co%d R%d s%d OH%d pro%d" % (a[5], a[6], a[7], a[8], a[9], a[10], a[12], a[14], 1 if a[17] else 0)
-                    fl = 2.0 * a[5] * a[14] * a[15] * a[9] * a[10] * a[11] * a[8]
-                else:
-                    key, fl = name, 0.0
-                d = det.setdefault(key, [0, 0.0, fl])
-                d[0] += 1
-                d[1] += e0.elapsed_time(e1)
-            rows = sorted(((k, v[0] // nprof, v[1] / nprof, v[2]) for k, v in det.items()), key=lambda r: -r[2])
+            rows = sorted(((k, v[0] // nprof, v[1] / nprof, v[2], v[3]) for k, v in det.items()), key=lambda r: -r[2])
             with open(args.detail, "w") as f:
                 json.dump([{"op": k, "launches_per_step": n, "ms_per_step": round(ms_, 4),
-                            "tflops": round(fl * n / (ms_ * 1e-3) / 1e12, 1) if fl else None} for k, n, ms_, fl in rows], f, indent=1)
+                            "tflops": round(fl * n / (ms_ * 1e-3) / 1e12, 1) if fl else None,
+                            "mfma_bound_ms": round(n * fl / peak_f * 1e3, 4) if fl else None,
+                            "hbm_bound_ms": round(n * by / peak_b * 1e3, 4) if fl else None,
+                            "bound_over_measured": round(n * max(fl / peak_f, by / peak_b) * 1e3 / ms_, 3) if fl else None}
+                           for k, n, ms_, fl, by in rows], f, indent=1)
         conv_ms = sum(v[1] for k, v in summ.items() if k in CONV_FAMILY) / nprof
         total_ms = sum(v[1] for v in summ.values()) / nprof
         flops = conv_flops_per_img(args.arch) * args.batch
@@ -455,6 +479,10 @@ def main():
                 "traffic_note": "HBM bytes per step of the same launches (PMC), algorithmic minimum = activations+weights once",
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(total_ms, 3),
                 "whole_step_frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
+                "layer_bound": {"bound_ms": round(lb_ms, 3), "hbm_only_ms": round(lb_hbm, 3), "measured_ms": round(lb_meas, 3),
+                                "frac": round(lb_ms / lb_meas, 4) if lb_meas else None,
+                                "note": "sum over conv launches of max(FLOPs/MFMA peak, (in+out activations+weights)/8 TB/s) "
+                                        "over their measured time; per-geometry rows: --detail / profiles/*layer_roofline*"},
                 "by_entry_point_ms": {k: round(v[1] / nprof, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
     if dist is not None and world > 1:
         dist.barrier()

@@ -1,5 +1,5 @@
 """HBM bytes per train step from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE), per kernel family.
-usage: hbm_traffic.py <fetch_dir> <write_dir> <steps_in_run>
+usage: hbm_traffic.py <fetch_dir> <write_dir> <steps_in_run> [workload label]
 Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: rocprofv3 reports FETCH_SIZE and
 WRITE_SIZE in kilobytes; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so the fetch side is doubled; WRITE_SIZE is
 taken as reported (uncalibrated, see the guide)."""
@@ -20,8 +20,12 @@ def load(d, counter):
 
 
 def family(name):
-    if "igemm_kernel" in name or "wgrad" in name:
+    if "igemm" in name or "wgrad" in name:
         return "conv"
+    if "window_attn" in name:
+        return "attention"
+    if "layernorm" in name:
+        return "layernorm"
     if name.startswith("bn_") or "bn_" in name[:40]:
         return "bn"
     return "other"
@@ -35,7 +39,7 @@ for k in set(fe) | set(wr):
     o[0] += fe.get(k, 0.0) * 1024 * 2      # KB -> B, x2 gfx950 correction
     o[1] += wr.get(k, 0.0) * 1024
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/collect_profiles.sh); FETCH_SIZE x2 (gfx950), KB units",
-       "workload": "resnet50 bs256 bf16 224x224 train step", "steps_in_run": steps}
+       "workload": sys.argv[4] if len(sys.argv) > 4 else "resnet50 bs256 bf16 224x224 train step", "steps_in_run": steps}
 for f, (a, b) in fam.items():
     out[f + "_fetch_bytes_per_step"] = a / steps
     out[f + "_write_bytes_per_step"] = b / steps
