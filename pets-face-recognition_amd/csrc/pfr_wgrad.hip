@@ -31,6 +31,7 @@ struct WgradParams {
   int pro_relu;
   FastDiv div_ohow, div_ow;
   int tilesP, tilesQ;
+  int adv_q1, adv_q2, adv_r2;   // wgrad3: 32 rows = adv_q1 images + adv_q2 output rows + adv_r2 output columns
 };
 
 #ifndef PFR_WGRAD_MUL
@@ -417,6 +418,231 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v3 (bf16, no fused prologue): the v2 data path with the per-stage VECTOR-ALU work removed.  PMC counters of v2 (3x3, 256 ch,
+// 14x14, bs 256): 316 VALU instructions per wave per 64-row stage against 16 MFMAs — address arithmetic of the transpose reads
+// (recomputed per read), register moves assembling the fragments, and a divide-based (n, oh, ow) decode per gathered row; at 4
+// cycles per wave64 VALU instruction that is 2.5x the MFMA time of the stage, so the matrix pipe idles behind the vector ALU.
+//   * transpose reads: one base VGPR per fragment (lane part of the swizzled address, computed once) + the stage / k-group /
+//     half position as the instruction's immediate offset (the stage loop is unrolled over the 4 ring slots);
+//   * dy (and x of 1x1 stride-1 layers): constant per-lane offsets; the stage advances the buffer descriptor's base and shrinks
+//     num_records on the scalar ALU, so row tails are zero-filled by the bounds check with no vector compare;
+//   * gathered x (3x3 / strided): (n, oh, ow) is decoded once and then ADVANCED by 32 rows per stage with carries;
+//   * ring of 4 stages of 32 rows, counted vmcnt; reads are inline asm (a compiler-visible LDS read drains the DMAs in flight).
+__device__ __forceinline__ u32x2 lds_read_tr16(uint32_t addr, int imm) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm) : "memory");
+  return v;
+}
+template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BP, int BQ>
+__global__ __launch_bounds__(256) void wgrad3_kernel(WgradParams p) {
+  using T = bf16_t;
+  constexpr int KP = 8, BMR = 32, NST = 4;
+  constexpr int TP = BP / 64, TQ = BQ / 64;
+  constexpr int RSP = BP * 2, RSQ = BQ * 2;
+  constexpr int GPRP = RSP / 32, GPRQ = RSQ / 32;
+  constexpr int TILEP = BMR * RSP, TILEQ = BMR * RSQ, STAGE = TILEP + TILEQ;
+  constexpr int RPIP = 1024 / RSP, RPIQ = 1024 / RSQ;
+  constexpr int NDP = BMR / (4 * RPIP), NDQ = BMR / (4 * RPIQ);
+  constexpr int IPS = NDP + NDQ, D = NST - 1;
+  static_assert(NDP >= 1 && NDQ >= 1 && NST * STAGE <= 65536, "tile geometry");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave >> 1, wq = wave & 1;
+  const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = p.tilesP * p.tilesQ;
+  const int split = t / ntile, tile = t % ntile;
+  const int tq = tile % p.tilesQ, tpp = tile / p.tilesQ;
+  const int co0 = tpp * BP, kk0 = tq * BQ;
+  const int mbeg = split * p.mchunk;
+  const int mend = min(p.M, mbeg + p.mchunk);
+  const int nrows = mend - mbeg;
+  const int nk = (nrows + BMR - 1) / BMR;
+
+  // ---- DMA lane geometry (as v2): lane l of a wave instruction lands at tile row l / CPR, physical 16-byte chunk l % CPR
+  constexpr int CPRP = RSP / 16, CPRQ = RSQ / 16;
+  const int prsub = lane / CPRP, qrsub = lane / CPRQ;
+  int pchunk = lane % CPRP, qchunk = lane % CPRQ;
+  pchunk = ((((pchunk >> 1) ^ gran_swz<GPRP>(wave * RPIP + prsub)) << 1) | (pchunk & 1));
+  qchunk = ((((qchunk >> 1) ^ gran_swz<GPRQ>(wave * RPIQ + qrsub)) << 1) | (qchunk & 1));
+  const int pco = co0 + pchunk * KP;
+  const int kk = kk0 + qchunk * KP;
+  const bool kkok = kk < p.KK;
+  const int tap = kkok ? kk / p.C : 0;
+  const int ci = kk - tap * p.C;
+  const int tr = tap / p.S, ts = tap - tr * p.S;
+  const uint32_t OOB = 0xFFFFFF00u;
+
+  uint32_t voffP[NDP], voffQ[NDQ];
+#pragma unroll
+  for (int j = 0; j < NDP; ++j)
+    voffP[j] = pco < p.Cout ? (uint32_t)((((j * 4 + wave) * RPIP + prsub) * p.lddy + pco) * 2) : OOB;
+  // gathered-x walker state per DMA pass (general form only)
+  int w_ow[NDQ], w_oh[NDQ], w_rem[NDQ];
+  uint32_t w_nb[NDQ];
+  const uint32_t hwc2 = (uint32_t)p.H * p.W * p.C * 2, wc2 = (uint32_t)p.W * p.C * 2, c2 = (uint32_t)p.C * 2;
+#pragma unroll
+  for (int j = 0; j < NDQ; ++j) {
+    const int rowj = (j * 4 + wave) * RPIQ + qrsub;
+    if (p.simple) {
+      voffQ[j] = kkok ? (uint32_t)((rowj * p.C + ci) * 2) : OOB;
+    } else {
+      const uint32_t m = (uint32_t)(mbeg + rowj);
+      const uint32_t n_img = fdiv(m, p.div_ohow);
+      const uint32_t rem = m - n_img * (uint32_t)(p.OH * p.OW);
+      const uint32_t oh = fdiv(rem, p.div_ow);
+      w_ow[j] = (int)(rem - oh * p.OW);
+      w_oh[j] = (int)oh;
+      w_nb[j] = n_img * hwc2 + (uint32_t)ci * 2;
+      w_rem[j] = kkok ? nrows - rowj : 0;
+    }
+  }
+  const int dih = tr - p.pad, diw = ts - p.pad;
+
+  const char* dyb = reinterpret_cast<const char*>(p.dy);
+  const char* xb = reinterpret_cast<const char*>(p.x);
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.C * sizeof(T)), 0x00020000);
+
+  auto issue = [&](int slot, int s) __attribute__((always_inline)) {
+    char* base = smem + slot * STAGE;
+    const int mb = mbeg + s * BMR;
+    const int left = mend - mb;   // > 0
+    __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dyb + (size_t)mb * p.lddy * 2), 0,
+                                                                  left * p.lddy * 2, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NDP; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (__attribute__((address_space(3))) void*)(base + (j * 4 + wave) * RPIP * RSP), 16,
+                                               (int)voffP[j], 0, 0, 0);
+    if (p.simple) {
+      __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb + (size_t)mb * p.C * 2), 0,
+                                                                    left * p.C * 2, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < NDQ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qr, (__attribute__((address_space(3))) void*)(base + TILEP + (j * 4 + wave) * RPIQ * RSQ),
+                                                 16, (int)voffQ[j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NDQ; ++j) {
+        const int ih = w_oh[j] * p.stride + dih, iw = w_ow[j] * p.stride + diw;
+        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && w_rem[j] > 0;
+        const uint32_t off = ok ? w_nb[j] + (uint32_t)ih * wc2 + (uint32_t)iw * c2 : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + TILEP + (j * 4 + wave) * RPIQ * RSQ),
+                                                 16, (int)off, 0, 0, 0);
+        // advance this lane's row by BMR output pixels: columns, then rows, then images (each wraps at most once)
+        int ow = w_ow[j] + p.adv_r2;
+        const int c1 = ow >= p.OW ? 1 : 0;
+        ow -= c1 ? p.OW : 0;
+        int oh = w_oh[j] + p.adv_q2 + c1;
+        const int cc = oh >= p.OH ? 1 : 0;
+        oh -= cc ? p.OH : 0;
+        w_ow[j] = ow;
+        w_oh[j] = oh;
+        w_nb[j] += (uint32_t)(p.adv_q1 + cc) * hwc2;
+        w_rem[j] -= BMR;
+      }
+    }
+  };
+
+  f32x16 acc[TP][TQ];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- transpose-read lane bases: row (g>>1)*8 + (s4>>2) of a k-group, swizzled 32-byte granule, 8-byte piece s4&3
+  const int g = lane >> 4, s4 = lane & 15;
+  const int r0 = (g >> 1) * 8 + (s4 >> 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t laneP[TP], laneQ[TQ];
+#pragma unroll
+  for (int i = 0; i < TP; ++i) {
+    const int gran = (wp * (BP / 2) + i * 32) / 16 + (g & 1);
+    laneP[i] = lds0 + r0 * RSP + ((gran ^ gran_swz<GPRP>(r0)) << 5) + (s4 & 3) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < TQ; ++j) {
+    const int gran = (wq * (BQ / 2) + j * 32) / 16 + (g & 1);
+    laneQ[j] = lds0 + TILEP + r0 * RSQ + ((gran ^ gran_swz<GPRQ>(r0)) << 5) + (s4 & 3) * 8;
+  }
+
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nk) issue(s, s);
+
+  constexpr int NR = 2 * (TP + TQ);   // transpose reads per k-group
+  auto stage = [&](auto slot_c, int kt) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    const int younger = min(D - 1, nk - 1 - kt);
+    if (younger >= 2) wg_wait_vm<2 * IPS>();
+    else if (younger == 1) wg_wait_vm<IPS>();
+    else wg_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();   // every wave's share of stage kt is in LDS; everyone is done reading slot (SLOT + D) % NST
+    u32x2 hp[2][TP][2], hq[2][TQ][2];
+    auto rd = [&](auto kg_c, int b) __attribute__((always_inline)) {
+      constexpr int KG = decltype(kg_c)::value;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < TP; ++i) hp[b][i][q] = lds_read_tr16(laneP[i], SLOT * STAGE + (KG * 16 + q * 4) * RSP);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) hq[b][j][q] = lds_read_tr16(laneQ[j], SLOT * STAGE + (KG * 16 + q * 4) * RSQ);
+      }
+    };
+    auto mma = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(hp[b][i][q]));
+#pragma unroll
+      for (int j = 0; j < TQ; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(hq[b][j][q]));
+#pragma unroll
+      for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+          const u32x4 ua = {hp[b][i][0][0], hp[b][i][0][1], hp[b][i][1][0], hp[b][i][1][1]};
+          const u32x4 ub = {hq[b][j][0][0], hq[b][j][0][1], hq[b][j][1][0], hq[b][j][1][1]};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), acc[i][j],
+                                                               0, 0, 0);
+        }
+    };
+    rd(std::integral_constant<int, 0>{}, 0);
+    rd(std::integral_constant<int, 1>{}, 1);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+    mma(0);
+    if (kt + D < nk) issue((SLOT + D) % NST, kt + D);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma(1);
+  };
+  for (int kt0 = 0; kt0 < nk; kt0 += NST) {
+    stage(std::integral_constant<int, 0>{}, kt0);
+    if (kt0 + 1 < nk) stage(std::integral_constant<int, 1>{}, kt0 + 1);
+    if (kt0 + 2 < nk) stage(std::integral_constant<int, 2>{}, kt0 + 2);
+    if (kt0 + 3 < nk) stage(std::integral_constant<int, 3>{}, kt0 + 3);
+  }
+
+  float* out = p.dw + (size_t)split * p.Cout * p.KK;
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int col = kk0 + wq * (BQ / 2) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wp * (BP / 2) + i * 32 + acc_row(r, lane);
+        if (co < p.Cout && col < p.KK) out[(size_t)co * p.KK + col] = acc[i][j][r];
+      }
+    }
+}
+
 // sums the split slabs: block = 64 columns (of 4 floats) x 4 split-lanes; every lane keeps 4 independent loads in flight
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4,
                                                            int splits, float scale, int accumulate) {
@@ -446,6 +672,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+static int wgrad_v3() {
+  static const int v = getenv("PFR_WGRAD_V3") ? atoi(getenv("PFR_WGRAD_V3")) : 1;
+  return v;
+}
+
 template <typename T, int BP, int BQ>
 static int launch_wgrad(WgradParams& p, hipStream_t st) {
   p.tilesP = (p.Cout + BP - 1) / BP;
@@ -453,6 +684,8 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
   const dim3 grid((unsigned)(p.tilesP * p.tilesQ * p.splits));
   if (p.pro_scale)
     hipLaunchKernelGGL((wgrad_kernel<T, BP, BQ, true>), grid, dim3(256), 0, st, p);
+  else if (p.v2 && sizeof(T) == 2 && wgrad_v3())
+    hipLaunchKernelGGL((wgrad3_kernel<BP, BQ>), grid, dim3(256), 0, st, p);
   else if (p.v2)
     hipLaunchKernelGGL((wgrad2_kernel<T, BP, BQ>), grid, dim3(256), 0, st, p);
   else
@@ -502,6 +735,7 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
   p.splits = pfr_conv2d_wgrad_splits(p.M, Cout, p.KK);
+  { const int ohow = OH * OW, r1 = 32 % ohow; p.adv_q1 = 32 / ohow; p.adv_q2 = r1 / OW; p.adv_r2 = r1 % OW; }
   { const char* e = getenv("PFR_WGRAD_V2"); p.v2 = (!pro_scale && !(e && e[0] == '0')) ? 1 : 0; }
   const int bmr = p.v2 ? (dtype == PFR_BF16 ? 64 : 32) : PFR_WGRAD_MUL * (dtype == PFR_BF16 ? 32 : 16);
   p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
