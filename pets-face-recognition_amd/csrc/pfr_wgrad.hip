@@ -701,21 +701,34 @@ static void wgrad_tiles(int Cout, int KK, int* bp, int* bq) {
   if (forced >= 0) { *bp = (forced & 1) ? 64 : 128; *bq = (forced & 2) ? 64 : 128; }
 }
 
-// number of m-splits the launcher uses (the caller sizes the workspace as splits*Cout*KK floats)
+// number of m-splits the launcher uses (the caller sizes the workspace as splits*Cout*KK floats).
+// Two workgroups fit a CU (64 KB of LDS each) and a CU runs two about as fast as one (the kernel waits on DMA latency), so a
+// launch of W = tiles*s workgroups takes ceil(W / 512) rounds of M/s rows: s is chosen to minimise
+//     t_pass * (ceil(W/512)*512 / W)  +  s * slab * 2 / 4 TB/s          (fp32 partial slabs written once, read once)
+// with t_pass = the pass at full occupancy (600 TFLOP/s or 4 TB/s of operand bytes, whichever is slower).  Measured on MI355X
+// (tools/scratch/split_sweep.sh): 3x3 256ch 14x14: 10 -> 14 splits = 98 -> 82 us; 3x3 512ch 7x7: 4 -> 3 splits = 115 -> 91 us.
 extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   int bp, bq;
   wgrad_tiles(Cout, KK, &bp, &bq);
   const long tiles = (long)((Cout + bp - 1) / bp) * ((KK + bq - 1) / bq);
-  long want = (512 + tiles - 1) / tiles;   // two workgroups per CU (measured: 512 beats 768 on the Cout = 64 layers, equal elsewhere)
   const long maxs = (M + 255) / 256;       // at least 256 reduction rows per split
-  if (want > maxs) want = maxs;
-  // the fp32 partial slabs are written and re-read once: keep them well below the activation traffic of the layer
   const long slab = (long)Cout * KK * 4;
-  static const long slab_mb = getenv("PFR_WGRAD_SLAB_MB") ? atol(getenv("PFR_WGRAD_SLAB_MB")) : 24;
-  const long cap = (slab_mb << 20) / slab;
-  if (want > cap) want = cap;
-  if (want < 1) want = 1;
-  return (int)want;
+  static const long slab_mb = getenv("PFR_WGRAD_SLAB_MB") ? atol(getenv("PFR_WGRAD_SLAB_MB")) : 48;
+  long cap = (slab_mb << 20) / slab;
+  if (cap > maxs) cap = maxs;
+  if (cap < 1) cap = 1;
+  const double t_flop = 2.0 * M * Cout * KK / 6.0e14, t_byte = 2.0 * M * ((double)Cout + KK) / 4.0e12;
+  const double t_pass = t_flop > t_byte ? t_flop : t_byte;
+  long best = 1;
+  double best_t = 1e30;
+  for (long s = 1; s <= cap && s * tiles <= 4096; ++s) {
+    const long w = tiles * s, rounds = (w + 511) / 512;
+    const double t = t_pass * (double)(rounds * 512) / (double)w + (double)s * slab * 2.0 / 4.0e12;
+    if (t < best_t * 0.999) { best_t = t; best = s; }
+  }
+  static const int forced = getenv("PFR_WGRAD_FORCE_SPLITS") ? atoi(getenv("PFR_WGRAD_FORCE_SPLITS")) : 0;   // tuning sweeps
+  if (forced > 0) best = forced < maxs ? forced : maxs;
+  return (int)best;
 }
 
 extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float* workspace, int dtype, int N, int H,
