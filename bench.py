@@ -468,15 +468,25 @@ def main():
         ach = flops / (conv_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         traffic = None
+        traffic_stale = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.arch == "resnet50" and args.batch == 256 and args.dtype == "bf16":
             # HBM bytes of the conv family per step from rocprofv3 PMC passes of THIS command (FETCH_SIZE x2-corrected
             # + WRITE_SIZE, see profiles/traffic.json); bench.py cannot run the profiler on itself.
             with open(tpath) as f:
-                traffic = json.load(f).get("conv_family_bytes_per_step")
+                tj = json.load(f)
+            traffic = tj.get("conv_family_bytes_per_step")
+            import glob, hashlib
+            h = hashlib.sha256()
+            csrc = os.path.join(ROOT, "pets-face-recognition_amd", "csrc")
+            for fn in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+                with open(fn, "rb") as f:
+                    h.update(f.read())
+            traffic_stale = tj.get("csrc_sha256") != h.hexdigest()   # counters collected with other kernel sources
         roof = {"bound": "mfma", "kernel": "igemm_kernel + wgrad_kernel (all conv/linear launches of a step)",
                 "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes per step of the same launches (PMC), algorithmic minimum = activations+weights once",
+                "traffic_stale": traffic_stale,
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(total_ms, 3),
                 "whole_step_frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
                 "layer_bound": {"bound_ms": round(lb_ms, 3), "hbm_only_ms": round(lb_hbm, 3), "measured_ms": round(lb_meas, 3),

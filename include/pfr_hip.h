@@ -112,6 +112,8 @@ int pfr_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, in
 int pfr_cast(const void* x, int src_dtype, void* y, int dst_dtype, size_t n, pfr_stream_t stream);
 /* w [O][R][S][I] → wt [I][R][S][O], taps flipped: the weights pfr_conv2d_fwd needs to compute the data gradient */
 int pfr_weight_dgrad_layout(const void* w, void* wt, int dtype, int O, int R, int S, int I, pfr_stream_t stream);
+/* the same for n_layers convs in one launch; descs: DEVICE array of {const void* w; void* wt; int O, R, S, I;} (24 bytes each) */
+int pfr_weight_dgrad_layout_batch(const void* descs, int n_layers, int dtype, pfr_stream_t stream);
 int pfr_add(const void* a, const void* b, void* y, int dtype, size_t n, pfr_stream_t stream);
 long pfr_colsum_ws_floats(long rows, int C); /* 0 for small row counts */
 int pfr_colsum(const void* x, int dtype, long rows, int C, float* out, int accumulate, float* workspace, pfr_stream_t stream);

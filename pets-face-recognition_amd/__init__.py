@@ -16,7 +16,15 @@ import os as _os
 # The train step uses up to four HIP streams at once (main, weight-gradient side stream, gradient all-reduce, RCCL's own).
 # HIP multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; ask for 8 so that none of them share a queue.
 # Only effective if set before the HIP runtime creates its queues, hence at package import.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    import sys as _sys
+    _t = _sys.modules.get("torch")
+    if _t is not None and _t.cuda.is_available() and _t.cuda.is_initialized():
+        # torch created the HIP queues before this import: the setting above came too late for this process
+        import warnings as _w
+        _w.warn("pets_face_recognition_amd imported after torch initialised HIP: export GPU_MAX_HW_QUEUES=8 before the first "
+                "CUDA call, otherwise the side / comm streams share hardware queues with the main stream (~7 % slower DDP step)")
 
 
 def install_reference_aliases():

@@ -104,6 +104,38 @@ extern "C" int pfr_weight_dgrad_layout(const void* w, void* wt, int dtype, int O
   return PFR_OK;
 }
 
+// every conv of a network in ONE launch: blockIdx.y = layer (descriptor table in HBM), grid-stride over the layer's elements
+struct WtDesc {
+  const void* w;
+  void* wt;
+  int O, R, S, I;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void weight_dgrad_batch_kernel(const WtDesc* __restrict__ descs) {
+  const WtDesc d = descs[blockIdx.y];
+  const T* __restrict__ w = reinterpret_cast<const T*>(d.w);
+  T* __restrict__ wt = reinterpret_cast<T*>(d.wt);
+  const uint32_t O = d.O, R = d.R, S = d.S, I = d.I, n = O * R * S * I;
+  const uint32_t RS = R * S;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    // i indexes the OUTPUT [ci][r][s][o] so stores are coalesced
+    const uint32_t o = i % O, rest = i / O;
+    const uint32_t tap = rest % RS, ci = rest / RS;
+    wt[i] = w[((size_t)o * RS + (RS - 1 - tap)) * I + ci];    // both taps flipped = the tap index reversed
+  }
+}
+
+extern "C" int pfr_weight_dgrad_layout_batch(const void* descs, int n_layers, int dtype, hipStream_t st) {
+  PFR_CHECK_ARG(descs && n_layers > 0 && n_layers <= 65535, "pfr_weight_dgrad_layout_batch: bad args");
+  const dim3 grid(128, n_layers);
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(weight_dgrad_batch_kernel<bf16_t>, grid, dim3(256), 0, st, (const WtDesc*)descs);
+  else
+    hipLaunchKernelGGL(weight_dgrad_batch_kernel<float>, grid, dim3(256), 0, st, (const WtDesc*)descs);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // column-reduction scaffold: thread = (chunk column, row lane)
 struct ColGeom {

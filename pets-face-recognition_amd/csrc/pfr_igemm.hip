@@ -41,7 +41,7 @@ extern "C" void pfr_debug_igemm_flags(int f) { g_igemm_dbg = f; }
 #endif
 
 template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_, bool FILT = false, bool BNB = false>
-__global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && sizeof(T) == 2) ? (BNB ? 2 : PFR_IGEMM_OCC4) : 1) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && sizeof(T) == 2 && sizeof(TO) == 2 && !PRO) ? (BNB ? 2 : PFR_IGEMM_OCC4) : 1) void igemm_kernel(IgemmParams p) {
   constexpr int KP = DT<T>::KPACK;
   constexpr int KCH = KCH_;                    // 16-byte chunks per LDS row per k-step (4: 64-B rows, 8: 128-B rows)
   constexpr int ROWB = KCH * 16;

@@ -10,9 +10,13 @@ resnet (/root/reference/losses/__init__.py:38-41 called from engine/controller.p
   * activations are NHWC in the compute dtype (bf16, or f32 for the parity path); every buffer of a step is
     allocated once per input shape and the whole step is a pre-built list of C-ABI calls (a "plan") with fixed
     device pointers — no allocator traffic, no autograd graph, trivially capturable in a hipGraph;
-  * BN-apply + ReLU of a conv's producer is fused into the consumer's operand prologue (the normalised activation
-    never exists in HBM), batch statistics come out of the producing conv's epilogue, the bottleneck tail
-    (BN + residual add + ReLU) is one pass, backward recomputes the ReLU masks instead of storing them.
+  * batch statistics come out of the producing conv's epilogue; z = relu(BN(c)) is materialised by ONE elementwise pass
+    (pfr_bn_act; the fused consumer-prologue form exists but is off — it costs ~2x kernel time); the bottleneck
+    tail (BN + projection-BN + residual add + ReLU) is one pass that also writes the ReLU sign as a bit mask, which the two
+    backward kernels of the block's last BN and the residual join in conv1's data-gradient epilogue read; inner BNs recompute
+    their ReLU mask from scale*x+shift;
+  * a step's launch lists are replayed from C (csrc/pfr_plan.hip) unless PFR_C_PLAN=0 or a launch tracer is installed;
+    two plan slots per input shape allow list inputs (two forwards before one backward), each with its own BN coefficients.
 """
 import os
 import weakref
@@ -339,18 +343,14 @@ class FEEngine:
                 self.wt_fork.record(torch.cuda.current_stream())
                 self.side.wait_event(self.wt_fork)
                 sptr = self.side.cuda_stream
-            wt_ops = [(lib.pfr_weight_dgrad_layout, (c.w.data_ptr(), c.wt.data_ptr(), self.did, c.Cout, c.R, c.S, c.Cin))
-                      for c in self.all_convs if c.need_wt]
-            cp = None
-            if self.c_plan and _TRACER[0] is None:
-                cp = getattr(self, "_wt_cplan", None)
-                if cp is None:
-                    cp = self._wt_cplan = CPlan.compile(wt_ops)
-            if cp is not None:
-                cp.run(sptr)
-            else:
-                for fn, args in wt_ops:
-                    fn(*args, sptr)
+            # one launch for every conv's data-gradient weights (descriptor table built once: the pointers are fixed)
+            tab = getattr(self, "_wt_table", None)
+            if tab is None:
+                import struct
+                convs = [c for c in self.all_convs if c.need_wt]
+                raw = b"".join(struct.pack("<QQiiii", c.w.data_ptr(), c.wt.data_ptr(), c.Cout, c.R, c.S, c.Cin) for c in convs)
+                tab = self._wt_table = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(convs))
+            lib.pfr_weight_dgrad_layout_batch(tab[0].data_ptr(), tab[1], self.did, sptr)
             self.wt_pending = use_side
             if use_side:
                 self.wt_ready.record(self.side)

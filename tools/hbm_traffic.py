@@ -45,4 +45,11 @@ for f, (a, b) in fam.items():
     out[f + "_write_bytes_per_step"] = b / steps
 out["conv_family_bytes_per_step"] = sum(fam.get("conv", [0, 0])) / steps
 out["all_kernels_bytes_per_step"] = sum(a + b for a, b in fam.values()) / steps
+# fingerprint of the kernel sources the counters were collected with (bench.py flags the file as stale when they change)
+import hashlib
+h = hashlib.sha256()
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pets-face-recognition_amd", "csrc")
+for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+    h.update(open(f, "rb").read())
+out["csrc_sha256"] = h.hexdigest()
 print(json.dumps(out, indent=1))

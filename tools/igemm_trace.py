@@ -3,7 +3,7 @@
 import sys, os, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pets_face_recognition_amd._hip import ops
-dll = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'pets-face-recognition_amd', 'csrc', 'libpfr_hip.so'))
+dll = ctypes.CDLL(os.environ.get('PFR_LIB_PATH') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'pets-face-recognition_amd', 'csrc', 'libpfr_hip.so'))
 CASES = {
     'c1x1_256_1024_h14': (256, 14, 14, 256, 1024, 1, 1, 0),
     'c1x1_64_256_h56': (256, 56, 56, 64, 256, 1, 1, 0),
