@@ -185,12 +185,20 @@ class SwinEngine:
             self.wt_fork.record(torch.cuda.current_stream())
             self.side.wait_event(self.wt_fork)
             sptr = self.side.cuda_stream
-        for r in self._all_lins():
-            if r.f is not None:
-                if r is not self.stages[0]["pm"]:
-                    lib.pfr_weight_dgrad_layout(r.w.data_ptr(), r.wt.data_ptr(), self.did, r.out, r.f, r.f, r.cinp, sptr)
-            else:
-                lib.pfr_weight_dgrad_layout(r.w.data_ptr(), r.wt.data_ptr(), self.did, r.out, 1, 1, r.inp, sptr)
+        # one launch for every layer's data-gradient weights (descriptor table built once: the pointers are fixed)
+        tab = getattr(self, "_wt_table", None)
+        if tab is None:
+            import struct
+            recs = []
+            for r in self._all_lins():
+                if r.f is not None:
+                    if r is not self.stages[0]["pm"]:
+                        recs.append((r.w.data_ptr(), r.wt.data_ptr(), r.out, r.f, r.f, r.cinp))
+                else:
+                    recs.append((r.w.data_ptr(), r.wt.data_ptr(), r.out, 1, 1, r.inp))
+            raw = b"".join(struct.pack("<QQiiii", *rec) for rec in recs)
+            tab = self._wt_table = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(recs))
+        lib.pfr_weight_dgrad_layout_batch(tab[0].data_ptr(), tab[1], self.did, sptr)
         self.wt_pending = use_side
         if use_side:
             self.wt_ready.record(self.side)
