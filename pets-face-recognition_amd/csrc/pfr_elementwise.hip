@@ -557,8 +557,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t off = (r + u * step) * C + cglob * KP;
-        vg[u] = ld16(dout + off);
-        vx[u] = ld16(x + off);
+        vg[u] = ld16_nt(dout + off);
+        vx[u] = ld16_nt(x + off);
         if (mask_mode == 1) vo[u] = ld16(out + off);
         if (mask_mode == 3) bits[u] = mk[(r + u * step) * cpr + cglob];
       }
