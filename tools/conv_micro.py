@@ -11,6 +11,10 @@ CASES = {
     'c3x3_64_h56': (256, 56, 56, 64, 64, 3, 1, 1),
     'c1x1_64_256_h56': (256, 56, 56, 64, 256, 1, 1, 0),
     'c3x3_512_h7': (256, 7, 7, 512, 512, 3, 1, 1),
+    'c3x3_128_h28': (256, 28, 28, 128, 128, 3, 1, 1),
+    'c1x1_512_128_h28': (256, 28, 28, 512, 128, 1, 1, 0),
+    'c1x1_128_512_h28': (256, 28, 28, 128, 512, 1, 1, 0),
+    'c1x1_256_64_h56': (256, 56, 56, 256, 64, 1, 1, 0),
 }
 for name, (N, H, W, C, Co, R, s, p) in CASES.items():
     if which != 'all' and which != name: continue

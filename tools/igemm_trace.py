@@ -10,6 +10,9 @@ CASES = {
     'c1x1_128_512_h28': (256, 28, 28, 128, 512, 1, 1, 0),
     'c1x1_1024_256_h14': (256, 14, 14, 1024, 256, 1, 1, 0),
     'c3x3_256_h14': (256, 14, 14, 256, 256, 3, 1, 1),
+    'c3x3_64_h56': (256, 56, 56, 64, 64, 3, 1, 1),
+    'c3x3_128_h28': (256, 28, 28, 128, 128, 3, 1, 1),
+    'c1x1_512_128_h28': (256, 28, 28, 512, 128, 1, 1, 0),
 }
 FLAGS = int(os.environ.get('DBG', '0'))
 dll.pfr_debug_igemm_flags(FLAGS)
