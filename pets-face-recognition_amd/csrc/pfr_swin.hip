@@ -858,14 +858,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
                                                                   float* __restrict__ dpos_part, WinAttn a) {
   __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS], lg[64 * WA_RS];
   __shared__ __attribute__((aligned(16))) float st_m[64], st_l[64], st_d[64];
-  __shared__ float dtab[256];
+  // position-table gradient bins as 32.32 FIXED POINT: on gfx950 a wave64 `ds_add_f32` costs 190 (idle) … 950 (loaded CU) cycles,
+  // `ds_add_u64` 14 … 46 (tools/probe/lds_atomic_probe.hip) — the float scatter was 70 % of this kernel's LDS-array time.  Integer
+  // accumulation is also order-independent.  |dS| < 2^31 and a resolution of 2^-32 are far outside what bf16 operands produce.
+  __shared__ unsigned long long dtab[256];
   __shared__ __attribute__((aligned(16))) int cj[64];
   const int lane = threadIdx.x;
   const WaUnit u = wa_decode(a, blockIdx.x);
   const int nt = a.w * a.w, C = a.heads * a.hd, w = a.w;
   const int ntab = (2 * w - 1) * (2 * w - 1);
   const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
-  for (int e = lane; e < 256; e += 64) dtab[e] = 0.f;
+  for (int e = lane; e < 256; e += 64) dtab[e] = 0ull;
   cj[lane] = lane < nt ? (lane / w) * (2 * w - 1) + lane % w : -(1 << 20);
   size_t tokoff[2];
   bool ok[2];
@@ -949,7 +952,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
           const float dsv = sa[jt][4 * g + e] * (dp[jt][4 * g + e] - dl);
           sa[jt][4 * g + e] = dsv;
           const int idx = base_i + cc[e];
-          if (idx >= 0) atomicAdd(&dtab[idx], dsv);   // (LDS atomics are the expensive part: skip the padding)
+          if (idx >= 0) {
+            const float hf = floorf(dsv);
+            const unsigned lo = (unsigned)((dsv - hf) * 4294967296.f);
+            atomicAdd(&dtab[idx], ((unsigned long long)(unsigned)(int)hf << 32) | lo);
+          }
         }
       }
     f32x16 dq;
@@ -1028,7 +1035,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     }
   }
   __syncthreads();
-  for (int e = lane; e < ntab; e += 64) dpos_part[(size_t)blockIdx.x * ntab + e] = dtab[e];
+  for (int e = lane; e < ntab; e += 64) dpos_part[(size_t)blockIdx.x * ntab + e] = (float)(long long)dtab[e] * 2.3283064365386963e-10f;
 }
 
 static bool wa_use_mfma(int dtype, int hd, int w) {
