@@ -858,17 +858,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
                                                                   float* __restrict__ dpos_part, WinAttn a) {
   __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS], lg[64 * WA_RS];
   __shared__ __attribute__((aligned(16))) float st_m[64], st_l[64], st_d[64];
-  // position-table gradient bins as 32.32 FIXED POINT: on gfx950 a wave64 `ds_add_f32` costs 190 (idle) … 950 (loaded CU) cycles,
-  // `ds_add_u64` 14 … 46 (tools/probe/lds_atomic_probe.hip) — the float scatter was 70 % of this kernel's LDS-array time.  Integer
-  // accumulation is also order-independent.  |dS| < 2^31 and a resolution of 2^-32 are far outside what bf16 operands produce.
-  __shared__ unsigned long long dtab[256];
+  // Position-table gradient bins are accumulated as 64-bit INTEGERS: on gfx950 a wave64 `ds_add_f32` costs 190 (idle) … 950
+  // (loaded CU) cycles, `ds_add_u64` 14 … 46 (tools/probe/lds_atomic_probe.hip) — the float scatter was 70 % of this kernel's
+  // LDS-array time.  Block floating point: each query half scales its dS values by the power of two that puts the largest
+  // magnitude at 2^40 (values more than 2^-40 below the largest are truncated — far beyond fp32 accumulation accuracy), so the
+  // sums are order-independent AND exactly homogeneous (doubling dO doubles every bin bit for bit, tests/test_fullsize_gpu.py).
+  __shared__ unsigned long long dtab[2][256];
   __shared__ __attribute__((aligned(16))) int cj[64];
   const int lane = threadIdx.x;
   const WaUnit u = wa_decode(a, blockIdx.x);
   const int nt = a.w * a.w, C = a.heads * a.hd, w = a.w;
   const int ntab = (2 * w - 1) * (2 * w - 1);
   const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
-  for (int e = lane; e < 256; e += 64) dtab[e] = 0ull;
+  for (int e = lane; e < 256; e += 64) { dtab[0][e] = 0ull; dtab[1][e] = 0ull; }
+  float inv_scale[2] = {0.f, 0.f};
   cj[lane] = lane < nt ? (lane / w) * (2 * w - 1) + lane % w : -(1 << 20);
   size_t tokoff[2];
   bool ok[2];
@@ -941,6 +944,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     // table index of (i, j) = base(i) + cj[j]; padded rows / columns give a negative index and are skipped
     const int yi = i / w, xi = i - yi * w;
     const int base_i = i < nt ? (w - 1 - yi) * (2 * w - 1) + (w - 1 - xi) : -(1 << 20);
+    float amax = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float dsv = sa[jt][e] * (dp[jt][e] - dl);
+        sa[jt][e] = dsv;
+        amax = fmaxf(amax, fabsf(dsv));
+      }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    // scale = 2^(40 - exponent(amax)) (1 when everything is zero / not finite); its reciprocal is exact as well
+    const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
+    const int kexp = (ex == 0 || ex == 255) ? 0 : min(40 - (ex - 127), 120);
+    const float sc = __uint_as_float((uint32_t)(kexp + 127) << 23);
+    if (it == 0) inv_scale[0] = __uint_as_float((uint32_t)(127 - kexp) << 23); else inv_scale[1] = __uint_as_float((uint32_t)(127 - kexp) << 23);
+    unsigned long long* dt = dtab[it];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -949,13 +969,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
         const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float dsv = sa[jt][4 * g + e] * (dp[jt][4 * g + e] - dl);
-          sa[jt][4 * g + e] = dsv;
           const int idx = base_i + cc[e];
           if (idx >= 0) {
-            const float hf = floorf(dsv);
-            const unsigned lo = (unsigned)((dsv - hf) * 4294967296.f);
-            atomicAdd(&dtab[idx], ((unsigned long long)(unsigned)(int)hf << 32) | lo);
+            const float xs = sa[jt][4 * g + e] * sc;                       // exact (power of two), |xs| < 2^41
+            const float hf = floorf(xs * 2.3283064365386963e-10f);         // floor(xs / 2^32)
+            const unsigned lo = (unsigned)fmaf(hf, -4294967296.f, xs);      // xs - hf*2^32 in [0, 2^32): exact
+            atomicAdd(&dt[idx], ((unsigned long long)(unsigned)(int)hf << 32) | lo);
           }
         }
       }
@@ -1035,7 +1054,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     }
   }
   __syncthreads();
-  for (int e = lane; e < ntab; e += 64) dpos_part[(size_t)blockIdx.x * ntab + e] = (float)(long long)dtab[e] * 2.3283064365386963e-10f;
+  for (int e = lane; e < ntab; e += 64)
+    dpos_part[(size_t)blockIdx.x * ntab + e] = (float)(long long)dtab[0][e] * inv_scale[0] + (float)(long long)dtab[1][e] * inv_scale[1];
 }
 
 static bool wa_use_mfma(int dtype, int hd, int w) {

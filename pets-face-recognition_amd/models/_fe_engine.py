@@ -596,18 +596,25 @@ class FEEngine:
         # ("wait", k): main waits for wgrad k (emitted before a pooled buffer it read is handed out again, before every
         # grad-ready mark and at the end).  The pool is FIFO so that a re-used buffer is the one released longest ago.
         pool = {}
+        lag = int(os.environ.get("PFR_POOL_LAG", "32"))
         pending = {}   # data_ptr -> index of the last side-stream wgrad that reads this buffer
         nside = [0]
 
         def G(shape, dtype=None):
             key = (tuple(shape), dtype or T)
             lst = pool.setdefault(key, [])
-            if lst:
-                t = lst.pop(0)
-                k = pending.pop(t.data_ptr(), None)
-                if k is not None:
-                    ops.append(("wait", (k,)))
-                return t
+            # FIFO, but a buffer whose side-stream reader was issued fewer than `lag` weight gradients ago is left alone (a
+            # fresh one is allocated instead: HBM is plentiful, 18 GB peak at bs 256) -- re-using it would make the main
+            # stream wait for the side stream, which runs behind; the wait still emitted for an old reader has long been
+            # satisfied.  Measured: lag 0 -> 32 = 22.66 -> 21.9 ms/step.
+            for i, t in enumerate(lst):
+                k = pending.get(t.data_ptr())
+                if k is None or nside[0] - k >= lag:
+                    lst.pop(i)
+                    if k is not None:
+                        del pending[t.data_ptr()]
+                        ops.append(("wait", (k,)))
+                    return t
             return self._A(plan, shape, dtype)
 
         def release(t):

@@ -46,6 +46,9 @@ class SwinEngine:
         self.fuse_gelu = os.environ.get("PFR_FUSE_GELU", "1") != "0"
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
+        # buffers per (shape, dtype) class of the backward pool before one that a side-stream op still reads is re-used (HBM is
+        # plentiful; a shallow pool makes the main stream wait for the side stream at almost every layer)
+        self.pool_depth = int(os.environ.get("PFR_POOL_DEPTH", "48"))
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
         self.grad_ready_hook = None
         self._adopt(model)
@@ -314,7 +317,7 @@ class SwinEngine:
             for i, t in enumerate(lst):              # a buffer no side op is reading
                 if t.data_ptr() not in pending:
                     return lst.pop(i)
-            if not lst or nalloc.get(key, 0) < 3:    # small rotation so that the side stream may lag behind
+            if not lst or nalloc.get(key, 0) < self.pool_depth:    # rotation so that the side stream may lag behind without stalling main
                 nalloc[key] = nalloc.get(key, 0) + 1
                 return A(shape, dtype)
             t = lst.pop(0)
