@@ -5,6 +5,8 @@
 
 static thread_local char g_err[512] = "";
 
+thread_local hipEvent_t pfr_tls_stop_event = nullptr;
+
 void pfr_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -27,6 +27,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 void pfr_set_error(const char* fmt, ...);
 
+// When non-null, the next launch of an entry point that supports it (pfr_bn_bwd_apply) attaches this event to its kernel as the
+// dispatch's own completion signal (hipExtLaunchKernel stopEvent) and clears it: the plan executor uses it for the fork that
+// follows, instead of a separate hipEventRecord whose marker packet delays the next kernel of the stream by ~7 us.
+extern thread_local hipEvent_t pfr_tls_stop_event;
+
 #define PFR_CHECK_ARG(cond, ...)            \
   do {                                      \
     if (!(cond)) {                          \

@@ -10,6 +10,7 @@
 // contiguous HBM.  Per-channel reductions keep the channel chunk in the lane and reduce over rows: per-thread
 // partials → LDS across the row-lanes of a block → one deterministic partial row per block (no atomics).
 #include "pfr_common.h"
+#include <hip/hip_ext.h>
 
 // ------------------------------------------------------------------------------------------------
 // layout / dtype conversion
@@ -708,6 +709,16 @@ extern "C" int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_apply: C %% %d != 0", kp);
   ColGeom g = col_geom(C, kp, (size_t)rows, 512);
+  hipEvent_t stop = pfr_tls_stop_event;
+  pfr_tls_stop_event = nullptr;
+  if (stop) {
+    if (dtype == PFR_BF16)
+      hipExtLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, nullptr, stop, 0, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, coef, scale, shift, mask_mode, (bf16_t*)dx, (bf16_t*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
+    else
+      hipExtLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, nullptr, stop, 0, (const float*)dout, (const float*)out, (const float*)x, coef, scale, shift, mask_mode, (float*)dx, (float*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
+    PFR_CHECK_LAUNCH();
+    return PFR_OK;
+  }
   if (dtype == PFR_BF16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, coef, scale, shift, mask_mode, (bf16_t*)dx, (bf16_t*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
   else

@@ -92,18 +92,26 @@ extern "C" int pfr_plan_run(void* plan, int begin, int end, pfr_stream_t main_st
   if (end < 0 || end > n) end = n;
   hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
   const bool use_side = ss != nullptr;
+  static const int apply_thunk = pfr_plan_thunk_index("pfr_bn_bwd_apply");
+  static const bool attach_ok = !(getenv("PFR_EVENT_ATTACH") && getenv("PFR_EVENT_ATTACH")[0] == '0');
+  int attached = -1;
   for (int i = begin; i < end; ++i) {
     const PlanOp& op = p->ops[i];
     switch (op.kind) {
       case 0:
       case 1: {
+        // a main-stream launch directly followed by a fork: let the kernel's own completion signal be the fork event
+        if (op.kind == 0 && use_side && attach_ok && op.thunk == apply_thunk && i + 1 < end && p->ops[i + 1].kind == 2) {
+          pfr_tls_stop_event = p->events[p->ops[i + 1].ev];
+          attached = i + 1;
+        }
         const int rc = g_thunks[op.thunk].fn(op.a, (op.kind == 1 && use_side) ? (void*)ss : (void*)ms);
         if (rc != PFR_OK) return rc <= -2 ? rc : -2 + (rc < 0 ? rc : 0) - 1;
         break;
       }
       case 2:
         if (use_side) {
-          if (hipEventRecord(p->events[op.ev], ms) != hipSuccess || hipStreamWaitEvent(ss, p->events[op.ev], 0) != hipSuccess) {
+          if ((attached != i && hipEventRecord(p->events[op.ev], ms) != hipSuccess) || hipStreamWaitEvent(ss, p->events[op.ev], 0) != hipSuccess) {
             pfr_set_error("pfr_plan_run: fork failed");
             return -2;
           }
