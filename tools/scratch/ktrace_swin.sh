@@ -27,12 +27,12 @@ busy += cur_e - cur_s
 print("union busy us", busy / 1e3, "idle us", (t1 - t0 - busy) / 1e3)
 # main-queue gaps > 3 us
 mainq = max(byq, key=byq.get)
-last = None; gaps = []
+last = None; gaps = []; prevn = ''
 for r in step:
     if r.get('Queue_Id') != mainq: continue
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    if last is not None and s - last > 3000: gaps.append(((s - t0) / 1e3, (s - last) / 1e3, r['Kernel_Name'][:50]))
-    last = e
+    if last is not None and s - last > 3000: gaps.append(((s - t0) / 1e3, (s - last) / 1e3, prevn[:34] + " -> " + r['Kernel_Name'][:40]))
+    last = e; prevn = r['Kernel_Name']
 print("main-queue gaps >3us:", len(gaps), "total", sum(g[1] for g in gaps))
-for g in gaps[:25]: print("  at %.0f us gap %.1f before %s" % g)
+for g in gaps[:60]: print("  at %.0f us gap %.1f before %s" % g)
 PY
