@@ -49,6 +49,22 @@ extern thread_local hipEvent_t pfr_tls_stop_event;
     }                                                                 \
   } while (0)
 
+// Exact-GELU pieces: Φ(z) = (1 + erf(z/√2))/2 and φ(z) = e^{-z²/2}/√(2π) from ONE exponential (Abramowitz & Stegun 7.1.26,
+// |erf error| <= 1.5e-7, i.e. below fp32 resolution of the products it enters).  libm's erff is a branchy ~40-instruction
+// polynomial per element; in the fused GELU epilogues of the Swin MLP GEMMs that vector-ALU work was a third of the kernel time.
+__device__ __forceinline__ void gelu_cdf_pdf(float z, float& cdf, float& pdf) {
+  const float ax = fabsf(z) * 0.70710678118654752f;
+  const float ex = __expf(-ax * ax);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float half_erfc = 0.5f * p * t * ex;
+  cdf = z >= 0.f ? 1.f - half_erfc : half_erfc;
+  pdf = 0.3989422804014327f * ex;
+}
+
 // ---- per-dtype traits: a "chunk" is always 16 bytes -------------------------------------------
 template <typename T> struct DT;
 template <> struct DT<float> {

@@ -634,15 +634,15 @@ __global__ __launch_bounds__(WS ? 320 : 256, WS ? 3 : (((BP + BQ) * KCH_ * 16 * 
             if (p.act == 2) {         // exact (erf) GELU of the STORED pre-activation; both tensors are kept for backward
               st16(reinterpret_cast<char*>(p.y2) + ((size_t)m * p.ldy + co) * sizeof(TO), v);
 #pragma unroll
-              for (int e = 0; e < KPO; ++e) f[e] = 0.5f * f[e] * (1.f + erff(f[e] * 0.70710678118654752f));
+              for (int e = 0; e < KPO; ++e) { float cdf, pdf; gelu_cdf_pdf(f[e], cdf, pdf); f[e] *= cdf; }
               v = Chunk<TO>::pack(f);
             } else if (p.act == 3) {  // GELU backward fused into the data-gradient GEMM: dz = dh ∘ gelu'(z)
               float z[KPO];
               Chunk<TO>::unpack(ld16(reinterpret_cast<const char*>(p.y2) + ((size_t)m * p.ldy + co) * sizeof(TO)), z);
 #pragma unroll
               for (int e = 0; e < KPO; ++e) {
-                const float cdf = 0.5f * (1.f + erff(z[e] * 0.70710678118654752f));
-                const float pdf = 0.3989422804014327f * __expf(-0.5f * z[e] * z[e]);
+                float cdf, pdf;
+          gelu_cdf_pdf(z[e], cdf, pdf);
                 f[e] *= cdf + z[e] * pdf;
               }
               v = Chunk<TO>::pack(f);

@@ -383,7 +383,7 @@ __global__ void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size
     float f[KP];
     Chunk<T>::unpack(ld16(x + i * KP), f);
 #pragma unroll
-    for (int e = 0; e < KP; ++e) f[e] = 0.5f * f[e] * (1.f + erff(f[e] * 0.70710678118654752f));
+    for (int e = 0; e < KP; ++e) { float cdf, pdf; gelu_cdf_pdf(f[e], cdf, pdf); f[e] *= cdf; }
     st16(y + i * KP, Chunk<T>::pack(f));
   }
 }
@@ -399,8 +399,8 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ d
 #pragma unroll
     for (int e = 0; e < KP; ++e) {
       const float v = f[e];
-      const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-      const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+      float cdf, pdf;
+      gelu_cdf_pdf(v, cdf, pdf);
       g[e] *= cdf + v * pdf;
     }
     st16(dx + i * KP, Chunk<T>::pack(g));
