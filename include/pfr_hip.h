@@ -48,7 +48,7 @@ int pfr_set_tuning(const char* key, int value);
  * the index of the entry point's thunk (pfr_plan_thunk_index("pfr_conv2d_fwd"), -1: not plannable) and its arguments as flat
  * 64-bit slots in declaration order WITHOUT the trailing stream (pointers / integers as such, floats as IEEE-754 bits).
  * kind: 0 launch on main | 1 launch on side | 2 fork (record event ev on main, side waits) | 3 record ev on side | 4 main waits
- * for ev | 5 as 4 but only when hook_stops | 6 hook stop (ev = user tag).  pfr_plan_run(begin, end <0 = all) returns -1 at the
+ * for ev | 5 as 4 but only when hook_stops == 1 (2: the hook synchronises with the side stream itself) | 6 hook stop (ev = user tag).  pfr_plan_run(begin, end <0 = all) returns -1 at the
  * end, the index of a kind-6 entry when hook_stops and it reached one (resume at index + 1), <= -2 on error. */
 int pfr_plan_thunk_index(const char* name);
 void* pfr_plan_create(int n_events);

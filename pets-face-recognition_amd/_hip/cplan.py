@@ -66,10 +66,10 @@ class CPlan:
             return None
         return CPlan(h, hooks)
 
-    def run(self, main_stream, side_stream=0, hook=None):
+    def run(self, main_stream, side_stream=0, hook=None, hook_syncs_side=False):
         pos = 0
         while True:
-            r = lib.pfr_plan_run(self.handle, pos, -1, main_stream, side_stream or 0, 1 if hook is not None else 0)
+            r = lib.pfr_plan_run(self.handle, pos, -1, main_stream, side_stream or 0, (2 if hook_syncs_side else 1) if hook is not None else 0)
             if r == -1:
                 return
             if r <= -2:

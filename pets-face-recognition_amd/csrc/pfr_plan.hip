@@ -121,7 +121,7 @@ extern "C" int pfr_plan_run(void* plan, int begin, int end, pfr_stream_t main_st
         if (use_side && hipEventRecord(p->events[op.ev], ss) != hipSuccess) { pfr_set_error("pfr_plan_run: record failed"); return -2; }
         break;
       case 5:
-        if (!hook_stops) break;
+        if (hook_stops != 1) break;   // 2: the hook makes its own (communication) stream wait for the side stream
         [[fallthrough]];
       case 4:
         if (use_side && hipStreamWaitEvent(ms, p->events[op.ev], 0) != hipSuccess) { pfr_set_error("pfr_plan_run: wait failed"); return -2; }

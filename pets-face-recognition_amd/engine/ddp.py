@@ -27,6 +27,7 @@ class BucketReducer:
         self.launched = []   # (lo, hi) ranges, for tests / introspection
         self.cuda = flat.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self.side_stream_fn = None   # callable -> the engine's side (weight-gradient) stream, or None
 
     def reset(self):
         self.hi = self.n
@@ -41,6 +42,11 @@ class BucketReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            side = self.side_stream_fn() if self.side_stream_fn is not None else None
+            if side is not None:
+                # the weight gradients of this range were enqueued on the engine's side stream: the COMMUNICATION stream waits for
+                # them, the main stream (the dgrad -> BN-backward chain) does not stall at the bucket boundary
+                self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
                 h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         else:
@@ -94,6 +100,9 @@ class FlatDDP:
             dist.broadcast(p.data, 0, group=group)
         self.reducer = BucketReducer(eng.grad, bucket_elems=bucket_mb * 1024 * 1024 // 4, group=group)
         eng.grad_ready_hook = self.reducer.ready
+        if self.reducer.cuda:
+            self.reducer.side_stream_fn = lambda: getattr(eng, "side", None)
+            eng.hook_syncs_side = True
         # The head's gradient (ArcFace weight, 20 MB at 10 000 ids) is complete BEFORE the backbone's backward starts:
         # its all-reduce is launched from a post-accumulate hook and overlaps the whole backbone backward.
         self._extra_done = set()
@@ -106,6 +115,7 @@ class FlatDDP:
         self._hooks = []
         if self.eng.grad_ready_hook == self.reducer.ready:
             self.eng.grad_ready_hook = None
+            self.eng.hook_syncs_side = False
 
     def check(self):
         """the reducer must be bound to the engine that is actually executing the model"""

@@ -140,6 +140,7 @@ class FEEngine:
         # lengthen them (3.5 -> 7.4 ms) by more than the HBM-speed reduce kernels (2.1 ms at 4.5 TB/s) cost.  DESIGN.md §6.
         self.fuse_bnb = os.environ.get("PFR_FUSE_BNB", "0") == "1"
         self.grad_ready_hook = None     # callable(lo, hi): flat-grad range [lo, hi) is final (DDP bucket hook)
+        self.hook_syncs_side = False    # True: the hook makes ITS stream wait for self.side (the main stream then never waits at a mark)
         self.bucket_elems = 6 * 1024 * 1024
         self._adopt(model)
 
@@ -918,7 +919,7 @@ class FEEngine:
             if cp is False:
                 cp = plan.meta[ck] = CPlan.compile(plan.meta[key], n_events)
             if cp is not None:
-                cp.run(stream, side, hook)
+                cp.run(stream, side, hook, self.hook_syncs_side)
                 return True
         return False
 
@@ -990,7 +991,7 @@ class FEEngine:
                     side.wait_event(e)
                 elif fn == _SREC:
                     ev[2 * args + 1].record(side)
-                elif fn == _WAIT or hook is not None:
+                elif fn == _WAIT or (hook is not None and not self.hook_syncs_side):
                     main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)

@@ -46,6 +46,7 @@ class SwinEngine:
         self.fuse_gelu = os.environ.get("PFR_FUSE_GELU", "1") != "0"
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
+        self.hook_syncs_side = False
         # buffers per (shape, dtype) class of the backward pool before one that a side-stream op still reads is re-used (HBM is
         # plentiful; a shallow pool makes the main stream wait for the side stream at almost every layer)
         self.pool_depth = int(os.environ.get("PFR_POOL_DEPTH", "48"))
@@ -559,7 +560,7 @@ class SwinEngine:
                     side.wait_event(e)
                 elif fn == _SREC:
                     ev[2 * args + 1].record(side)
-                elif fn == _WAIT or hook is not None:
+                elif fn == _WAIT or (hook is not None and not self.hook_syncs_side):
                     main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)
