@@ -251,6 +251,14 @@ int pfr_topk_rescore(const float* q, const float* g, int rows, int D, const int*
 int pfr_pair_similarity(const float* emb, int D, const long* idx_a, const long* idx_b, int P, float eps, float* out,
                         pfr_stream_t stream);
 
+/* sort / scan part of the verification metrics (engine/controller.py:112-183; torchmetrics ROC / AUROC / AveragePrecision /
+ * StatScores over the pair scores): scores fp32 [P], labels int32 [P] (0 impostor, != 0 genuine) -> sorted_scores [P] descending
+ * (ties: lower pair index first), cum_tp [P] = genuine pairs among the first i+1, run_end [P] = 1 where a run of equal scores ends
+ * (the distinct-threshold operating points).  workspace: pfr_pair_curve_ws_bytes(P). */
+long pfr_pair_curve_ws_bytes(int P);
+int pfr_pair_curve(const float* scores, const int* labels, int P, void* workspace, float* sorted_scores, int* cum_tp,
+                   unsigned char* run_end, pfr_stream_t stream);
+
 /* mean-strategy card matching (generate_tsv.py:71-78,91-125): centroid of the L2-normalised photo embeddings of each card;
  * seg [ncards+1] int64 row offsets; cent32 fp32 [ncards][D] (always written), cent (cent_dtype) optional copy */
 int pfr_card_centroids(const float* emb, const long* seg, int ncards, int D, float eps, float* cent32, void* cent,

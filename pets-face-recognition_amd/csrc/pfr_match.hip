@@ -437,3 +437,70 @@ extern "C" int pfr_card_fuse_scores(float* head_scores, const float* body_scores
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
+
+// ---- verification-pair curve (engine/controller.py:112-183: what torchmetrics' ROC / AUROC / AveragePrecision / StatScores
+// derive from the pair scores): scores sorted descending (ties: lower pair index first), the running count of genuine pairs, and
+// the end-of-run flags of equal scores — the sort/scan part of `_evaluate` on the device.  The pair set is small
+// (the reference evaluates 20 000 pairs), so ONE workgroup runs the whole bitonic network over 64-bit keys
+// (sortable score << 32 | ~index << 1 | label) in an L2-resident global scratch buffer, then a block scan.
+__global__ __launch_bounds__(1024) void pair_curve_kernel(const float* __restrict__ scores, const int* __restrict__ labels, int P,
+                                                          int Ppad, unsigned long long* __restrict__ keys,
+                                                          float* __restrict__ sorted_scores, int* __restrict__ cum_tp,
+                                                          unsigned char* __restrict__ run_end) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Ppad; i += 1024)
+    // (+ 0.f: -0.0 and +0.0 are one threshold)
+    keys[i] = i < P ? (((unsigned long long)fkey(scores[i] + 0.f) << 32) | ((uint32_t)(~(uint32_t)i) << 1) | (uint32_t)(labels[i] != 0)) : 0ull;
+  __syncthreads();
+  for (int k = 2; k <= Ppad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < Ppad; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = keys[i], b = keys[l];
+          const bool desc = ((i & k) == 0);
+          if ((a < b) == desc) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  // block scan of the labels in sorted order: thread t owns the contiguous range [t*per, (t+1)*per)
+  const int per = (P + 1023) / 1024;
+  const int lo = tid * per, hi = min(P, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += (int)(keys[i] & 1ull);
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;   // exclusive prefix
+  for (int i = lo; i < hi; ++i) {
+    const unsigned long long e = keys[i];
+    run += (int)(e & 1ull);
+    cum_tp[i] = run;
+    sorted_scores[i] = fkey_inv((uint32_t)(e >> 32));
+    run_end[i] = (i == P - 1 || (uint32_t)(keys[i + 1] >> 32) != (uint32_t)(e >> 32)) ? 1 : 0;
+  }
+}
+
+extern "C" long pfr_pair_curve_ws_bytes(int P) {
+  long n = 1;
+  while (n < P) n <<= 1;
+  return n * 8;
+}
+
+extern "C" int pfr_pair_curve(const float* scores, const int* labels, int P, void* workspace, float* sorted_scores, int* cum_tp,
+                              unsigned char* run_end, hipStream_t st) {
+  PFR_CHECK_ARG(scores && labels && workspace && sorted_scores && cum_tp && run_end && P > 0 && P <= (1 << 24), "pfr_pair_curve: bad args");
+  int n = 1;
+  while (n < P) n <<= 1;
+  hipLaunchKernelGGL(pair_curve_kernel, dim3(1), dim3(1024), 0, st, scores, labels, P, n, (unsigned long long*)workspace, sorted_scores,
+                     cum_tp, run_end);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}

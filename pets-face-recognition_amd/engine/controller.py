@@ -75,7 +75,8 @@ class Controller(nn.Module):
             scores = sim([(emb[a], emb[b]) for a, b in ci])
         else:
             scores = pair_similarity(emb, ia, ib)                       # (cos + 1) / 2, fe_dogs_config.py:89-93
-        return scores.float().cpu(), torch.as_tensor(pair_generator.labels)
+        # CUDA scores stay on the device: the sort / scan of the metric suite runs there (engine/metrics.py, pfr_pair_curve)
+        return scores.float(), torch.as_tensor(pair_generator.labels)
 
     def _recall(self, emb, classes, ks):
         dt = torch.float32 if not emb.is_cuda else getattr(self.config, 'match_dtype', torch.bfloat16)

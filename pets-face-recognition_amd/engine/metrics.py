@@ -1,24 +1,46 @@
-"""Verification metrics of the evaluation epoch (host logic over ≤ 20 000 pair scores; torch CPU, no torchmetrics /
-sklearn dependency).  Mirrors what /root/reference/engine/controller.py:67-75,114-183 gets from torchmetrics:
-ROC (fpr, tpr, thresholds), AUROC, accuracy at the threshold minimising fpr+fnr, AP, confusion matrix, P/R@thr,
-TAR@FAR, TRR@FRR."""
+"""Verification metrics of the evaluation epoch.  Mirrors what /root/reference/engine/controller.py:67-75,114-183 gets from
+torchmetrics: ROC (fpr, tpr, thresholds), AUROC, accuracy at the threshold minimising fpr+fnr, AP, confusion matrix, P/R@thr,
+TAR@FAR, TRR@FRR (no torchmetrics / sklearn dependency).
+
+The sort + running-count part runs on the device when the scores are CUDA tensors (`pfr_pair_curve`: one
+workgroup bitonic-sorts the ≤ 20 000 pair scores with their labels and scans the genuine-pair count); what is left is a handful
+of operations on the distinct-threshold operating points.  CPU tensors take the torch path below (BASELINE config 1)."""
 import torch
 
 
-def roc_curve(scores, labels):
-    """→ fpr, tpr, thresholds (descending; first point (0,0) at threshold max+1 like torchmetrics.ROC)"""
+def _curve(scores, labels):
+    """→ (score, genuine-pair count, 0-based position) at the end of every run of equal scores in descending order, n_pos, n_neg;
+    CPU double / long tensors"""
+    if scores.is_cuda:
+        from .._hip import lib
+        sc = scores.detach().float().contiguous().flatten()
+        lb = labels.detach().to(sc.device).to(torch.int32).contiguous().flatten()
+        P = sc.numel()
+        st = torch.cuda.current_stream().cuda_stream
+        ws = torch.empty(lib.pfr_pair_curve_ws_bytes(P), dtype=torch.uint8, device=sc.device)
+        ss = torch.empty(P, dtype=torch.float32, device=sc.device)
+        ct = torch.empty(P, dtype=torch.int32, device=sc.device)
+        re = torch.empty(P, dtype=torch.uint8, device=sc.device)
+        lib.pfr_pair_curve(sc.data_ptr(), lb.data_ptr(), P, ws.data_ptr(), ss.data_ptr(), ct.data_ptr(), re.data_ptr(), st)
+        ends = torch.nonzero(re).flatten()
+        npos = float(ct[-1].item())
+        return ss[ends].double().cpu(), ct[ends].double().cpu(), ends.cpu(), npos, float(P) - npos
     scores = scores.detach().double().cpu().flatten()
     labels = labels.detach().cpu().flatten().long()
     order = torch.argsort(scores, descending=True, stable=True)
     s, y = scores[order], labels[order]
     distinct = torch.nonzero(s[1:] != s[:-1]).flatten()
     ends = torch.cat([distinct, torch.tensor([s.numel() - 1])])
-    tps = torch.cumsum(y, 0)[ends].double()
+    return s[ends], torch.cumsum(y, 0)[ends].double(), ends, float(y.sum()), float((1 - y).sum())
+
+
+def roc_curve(scores, labels):
+    """→ fpr, tpr, thresholds (descending; first point (0,0) at threshold max+1 like torchmetrics.ROC)"""
+    s, tps, ends, P, N = _curve(scores, labels)
     fps = (ends + 1).double() - tps
-    P, N = float(y.sum()), float((1 - y).sum())
     tpr = torch.cat([torch.zeros(1, dtype=torch.double), tps / max(P, 1.0)])
     fpr = torch.cat([torch.zeros(1, dtype=torch.double), fps / max(N, 1.0)])
-    thr = torch.cat([s[ends[:1]] + 1, s[ends]])
+    thr = torch.cat([s[:1] + 1, s])
     return fpr, tpr, thr
 
 
@@ -29,15 +51,9 @@ def auroc(scores, labels):
 
 def average_precision(scores, labels):
     """AP = Σ (R_n − R_{n−1})·P_n over the distinct score thresholds (ties share one operating point)"""
-    scores = scores.detach().double().cpu().flatten()
-    labels = labels.detach().cpu().flatten().long()
-    order = torch.argsort(scores, descending=True, stable=True)
-    s, y = scores[order], labels[order].double()
-    distinct = torch.nonzero(s[1:] != s[:-1]).flatten()
-    ends = torch.cat([distinct, torch.tensor([s.numel() - 1])])
-    tp = torch.cumsum(y, 0)[ends]
+    _, tp, ends, P, _ = _curve(scores, labels)
     prec = tp / (ends + 1).double()
-    rec = tp / max(float(y.sum()), 1.0)
+    rec = tp / max(P, 1.0)
     prev = torch.cat([torch.zeros(1, dtype=torch.double), rec[:-1]])
     return float(((rec - prev) * prec).sum())
 

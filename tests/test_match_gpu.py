@@ -260,3 +260,25 @@ def test_calc_scores_fusion_rule_equals_reference_rows():
     r = calc_scores(*dev(list(qq)), *dev(list(gg)), k=100, chunk=256)
     _check_calc_scores(r["idx"].cpu().numpy(), r["scores"].cpu().numpy(), r["count"].cpu().numpy(), r["top1"].cpu().numpy(),
                        r["mean3"].cpu().numpy(), r["mean10"].cpu().numpy(), rows)
+
+
+@pytest.mark.gpu
+def test_pair_metrics_device_sort_scan_equals_host_path():
+    """engine/metrics on CUDA scores (pfr_pair_curve: bitonic sort + scan in one workgroup) vs the sklearn-validated torch-CPU path:
+    identical ROC points, AUROC, AP, best-threshold accuracy — heavy ties, non-power-of-two and degenerate sizes"""
+    from pets_face_recognition_amd.engine import metrics as M
+    g = torch.Generator().manual_seed(8)
+    cases = []
+    for P in (20000, 4097, 1000, 2, 1):
+        s = torch.rand(P, generator=g)
+        cases.append((s, (torch.rand(P, generator=g) < 0.5).long()))
+        cases.append(((s * 20).round() / 20, (torch.rand(P, generator=g) < 0.3).long()))      # 21 distinct values: long tie runs
+    cases.append((torch.full((513,), 0.25), (torch.arange(513) % 3 == 0).long()))             # one run
+    cases.append((torch.tensor([0.9, -0.5, float("inf"), 0.0, -0.0, 1e-30]), torch.tensor([1, 0, 1, 0, 1, 0])))
+    for s, y in cases:
+        fc, tc, thc = M.roc_curve(s, y)
+        fd, td, thd = M.roc_curve(s.to(DEV), y.to(DEV))
+        assert torch.equal(fc, fd) and torch.equal(tc, td) and torch.equal(thc.float(), thd.float()), s.numel()
+        assert M.auroc(s, y) == M.auroc(s.to(DEV), y)
+        assert M.average_precision(s, y) == M.average_precision(s.to(DEV), y.to(DEV))
+        assert M.best_threshold_accuracy(s, y, thc, fc, 1 - tc) == M.best_threshold_accuracy(s.to(DEV), y.to(DEV), thd, fd, 1 - td)
