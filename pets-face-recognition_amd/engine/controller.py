@@ -107,6 +107,7 @@ class Controller(nn.Module):
     def _evaluate(self, outputs):
         cfg = self.config
         all_metrics = {}
+        rocs = []
         for i in range(len(outputs)):
             emb, classes = self._gather(outputs[i])
             name, pair_generator = cfg.pair_generator(i)
@@ -129,8 +130,52 @@ class Controller(nn.Module):
             all_metrics[name] = metrics
             print('', *[f'{name} {k}\t{v}' for k, v in metrics.items()], sep='\n')
             self._log(name, metrics)
+            rocs.append((fpr.numpy(), tpr.numpy(), metrics['ROC AUC'], name))
+            self._plot_confmat(name, cm)
+        self._plot_rocs(rocs)
         self.last_metrics = all_metrics
         return all_metrics
+
+    # the two figures the reference's _evaluate writes per validation epoch (controller.py:185-203); skipped when matplotlib
+    # is not installed
+    def _img_dir(self):
+        d = Path(self.config.get('img_dir', '.'))
+        d.mkdir(parents=True, exist_ok=True)
+        return d
+
+    def _plot_confmat(self, name, cm):
+        try:
+            import matplotlib
+            matplotlib.use('Agg')
+            import matplotlib.pyplot as plt
+        except ImportError:
+            return
+        mat = [[cm['tn'], cm['fp']], [cm['fn'], cm['tp']]]
+        fig, ax = plt.subplots()
+        ax.imshow(mat, cmap='viridis')
+        for r in range(2):
+            for c in range(2):
+                ax.text(c, r, str(mat[r][c]), ha='center', va='center', color='w')
+        ax.set_xticks([0, 1]); ax.set_yticks([0, 1])
+        ax.set_xlabel('Predicted label'); ax.set_ylabel('True label')
+        fig.savefig(self._img_dir() / f' {name}_confmat_{self.current_epoch}.png')
+        plt.close(fig)
+
+    def _plot_rocs(self, rocs):
+        try:
+            import matplotlib
+            matplotlib.use('Agg')
+            import matplotlib.pyplot as plt
+        except ImportError:
+            return
+        fig = plt.figure(figsize=(10, 10))
+        for fpr, tpr, auc, name in rocs:
+            plt.plot(fpr, tpr, label=f'{name} AUC = {auc}', linewidth=3)
+        plt.plot([0, 1], [0, 1], 'k--', linewidth=3)
+        plt.xlabel('False positive rate'); plt.ylabel('True positive rate')
+        plt.title('ROC curves'); plt.grid(); plt.legend()
+        fig.savefig(self._img_dir() / f'roc_{self.current_epoch}.png')
+        plt.close(fig)
 
     def _log(self, name, metrics):
         if self.logger is not None and hasattr(self.logger, 'log_metrics'):

@@ -291,6 +291,21 @@ def calc_scores_db(init_db, extra_db, device="cuda", k=100, thresholds=FUSION_TH
     return rows
 
 
+TSV_COLUMNS = ('query', 'matched_1', 'matched_3', 'matched_10', 'answer')     # generate_tsv.py:129-135
+
+
+def create_table(db, device="cuda", k=100):
+    """`create_table(db)` of the reference (generate_tsv.py:128-142): db maps a folder to (initial_base_dict, extra_base_dict);
+    every folder's cards are ranked on the device (calc_scores_db) and the rows are collected into one DataFrame with the
+    reference's columns.  `create_table(db).to_csv(path, index=False, sep='\t')` is its TSV (generate_tsv.py:262-264)."""
+    import pandas as pd
+    rows = []
+    for big_folder in db:
+        init_db, extra_db = db[big_folder]
+        rows.extend(calc_scores_db(init_db, extra_db, device=device, k=k))
+    return pd.DataFrame(data=rows, columns=TSV_COLUMNS)
+
+
 def cosine_topk_sharded(q, g_local, k, g_offset, group=None, **kw):
     """Gallery sharded by rows across the ranks of `group` (each rank holds rows [g_offset, g_offset + len(g_local))),
     queries replicated: local GEMM + top-k per rank, ONE all-gather of the (score, index) lists (k·8 bytes per query

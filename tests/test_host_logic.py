@@ -81,6 +81,8 @@ def test_main_cpu_config1_runs(tmp_path):
     assert "Completed!" in r.stdout and "Val Recall@K=10" in r.stdout and "Val ROC AUC" in r.stdout
     runs = list((tmp_path / "results").iterdir())
     assert len(runs) == 1 and (runs[0] / "checkpoints" / "epoch=0.ckpt").exists() and (runs[0] / "fe_r18_cpu.py").exists()
+    imgs = sorted(p.name for p in (runs[0] / "img").iterdir())     # the reference's per-epoch figures (controller.py:185-203)
+    assert "roc_0.png" in imgs and any(n.endswith("_confmat_0.png") for n in imgs), imgs
     sd = torch.load(runs[0] / "checkpoints" / "epoch=0.ckpt")
     assert "model_loss.module.layer1.0.conv1.weight" in sd and "model_loss.add_margin.weight" in sd   # reference key names
 
