@@ -117,6 +117,13 @@ int pfr_weight_dgrad_layout_batch(const void* descs, int n_layers, int dtype, pf
 int pfr_add(const void* a, const void* b, void* y, int dtype, size_t n, pfr_stream_t stream);
 long pfr_colsum_ws_floats(long rows, int C); /* 0 for small row counts */
 int pfr_colsum(const void* x, int dtype, long rows, int C, float* out, int accumulate, float* workspace, pfr_stream_t stream);
+/* the same with the final merge deferred: pfr_colsum_partial leaves row-block partials in `workspace` (pfr_colsum_ws_floats floats,
+ * one workspace per pending tensor); pfr_colsum_parts = how many partial rows that will be (0: too few rows, use pfr_colsum);
+ * pfr_colsum_final_batch merges n partial sets in one launch.  descs: DEVICE array of {const float* part; float* out; int n; int C;
+ * int accumulate; int pad} (32 bytes each) */
+int pfr_colsum_parts(int dtype, long rows, int C);
+int pfr_colsum_partial(const void* x, int dtype, long rows, int C, float* workspace, pfr_stream_t stream);
+int pfr_colsum_final_batch(const void* descs, int n, int max_C, pfr_stream_t stream);
 int pfr_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long rows, int cols, float scale, int accumulate,
                    pfr_stream_t stream);
 

@@ -1228,6 +1228,78 @@ extern "C" int pfr_colsum(const void* x, int dtype, long rows, int C, float* out
   return PFR_OK;
 }
 
+// ---- column sums with a DEFERRED final merge: pfr_colsum_partial leaves the row-block partials in the caller's (per-tensor)
+// workspace and returns their count; pfr_colsum_final_batch merges any number of such partial sets in ONE launch (Swin: ~100 bias /
+// LayerNorm / position-table gradients per step were one tiny final launch each).
+// number of partial rows pfr_colsum_partial writes for this geometry (0: too few rows, use pfr_colsum)
+extern "C" int pfr_colsum_parts(int dtype, long rows, int C) {
+  const long nblk = colsum_blocks(rows, C);
+  if (nblk <= 0) return 0;
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  return C % kp == 0 ? col_geom(C, kp, (size_t)rows, 512).gx : (int)nblk;
+}
+extern "C" int pfr_colsum_partial(const void* x, int dtype, long rows, int C, float* workspace, hipStream_t st) {
+  PFR_CHECK_ARG(x && workspace && colsum_blocks(rows, C) > 0, "pfr_colsum_partial: null pointer or too few rows (%ld) for the partial path", rows);
+  const long nblk = colsum_blocks(rows, C);
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  if (C % kp == 0) {
+    ColGeom g = col_geom(C, kp, (size_t)rows, 512);
+    const size_t shb = (size_t)256 * kp * sizeof(float);
+    if (dtype == PFR_BF16)
+      hipLaunchKernelGGL(colsum_chunk_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), shb, st, (const bf16_t*)x, workspace, (size_t)rows, C, g.cw, g.rl, g.cpr);
+    else
+      hipLaunchKernelGGL(colsum_chunk_kernel<float>, dim3(g.gx, g.gy), dim3(256), shb, st, (const float*)x, workspace, (size_t)rows, C, g.cw, g.rl, g.cpr);
+    PFR_CHECK_LAUNCH();
+    return PFR_OK;
+  }
+  const long rpb = (rows + nblk - 1) / nblk;
+  const dim3 grid((C + 63) / 64, (unsigned)nblk);
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, workspace, rows, C, rpb);
+  else
+    hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(256), 0, st, (const float*)x, workspace, rows, C, rpb);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+struct ColsumDesc {
+  const float* part;
+  float* out;
+  int n, C, accumulate, pad;
+};
+__global__ __launch_bounds__(256) void colsum_final_batch_kernel(const ColsumDesc* __restrict__ descs) {
+  const ColsumDesc d = descs[blockIdx.y];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  if (blockIdx.x * 16 >= d.C) return;   // (uniform per workgroup)
+  __shared__ float l[16][17];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < d.C) {
+    int r = rl;
+    for (; r + 48 < d.n; r += 64) {
+      a0 += d.part[(size_t)r * d.C + c];
+      a1 += d.part[(size_t)(r + 16) * d.C + c];
+      a2 += d.part[(size_t)(r + 32) * d.C + c];
+      a3 += d.part[(size_t)(r + 48) * d.C + c];
+    }
+    for (; r < d.n; r += 16) a0 += d.part[(size_t)r * d.C + c];
+  }
+  l[rl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0 && c < d.C) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += l[r][cl];
+    d.out[c] = d.accumulate ? d.out[c] + a : a;
+  }
+}
+extern "C" int pfr_colsum_final_batch(const void* descs, int n, int max_C, hipStream_t st) {
+  PFR_CHECK_ARG(descs && n > 0 && n <= 65535 && max_C > 0, "pfr_colsum_final_batch: bad args");
+  hipLaunchKernelGGL(colsum_final_batch_kernel, dim3((max_C + 15) / 16, n), dim3(256), 0, st, (const ColsumDesc*)descs);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // optimiser steps over flat fp32 master buffers (+ compute-dtype shadow copy of the parameters)
 template <typename TS>

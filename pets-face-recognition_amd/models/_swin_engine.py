@@ -241,9 +241,29 @@ class SwinEngine:
 
         cs_need = [0]
 
+        pend_cs = []   # column sums whose final merge is deferred to the next flush: (workspace, out, partial rows, C)
+
         def colsum(ops, x, rows, C, out, dt=None):
-            cs_need[0] = max(cs_need[0], lib.pfr_colsum_ws_floats(rows, C))
-            side(ops, ("colsum", (x.data_ptr(), dt if dt is not None else did, rows, C, out.data_ptr(), 0, None)), x)
+            """bias / LayerNorm-parameter / position-table gradient = column sum of x; the partial sums run now (side stream), the
+            ~100 tiny final merges of a step are batched into one launch per DDP bucket boundary (flush_colsums)"""
+            d = dt if dt is not None else did
+            n = lib.pfr_colsum_parts(d, rows, C)
+            if n <= 0:   # a few hundred rows: one small kernel does it all
+                side(ops, ("side", (lib.pfr_colsum, (x.data_ptr(), d, rows, C, out.data_ptr(), 0, 0))), x)
+                return
+            ws = A((lib.pfr_colsum_ws_floats(rows, C),), torch.float32)   # its own workspace: alive until the batched final
+            side(ops, ("side", (lib.pfr_colsum_partial, (x.data_ptr(), d, rows, C, ws.data_ptr()))), x)
+            pend_cs.append((ws, out, n, C))
+
+        def flush_colsums(ops):
+            if not pend_cs:
+                return
+            import struct
+            raw = b"".join(struct.pack("<QQiiii", ws.data_ptr(), out.data_ptr(), n, C, 0, 0) for ws, out, n, C in pend_cs)
+            tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+            bufs.append(tab)
+            side(ops, ("side", (lib.pfr_colsum_final_batch, (tab.data_ptr(), len(pend_cs), max(c for _, _, _, c in pend_cs)))))
+            del pend_cs[:]
 
         x_nhwc = A((N, H, W, self.cp))
         cur, cshape = x_nhwc, (N, H, W, self.cp)
@@ -428,6 +448,7 @@ class SwinEngine:
                                                  f - 1, {2: 1, 4: 2}[f], Hi, Wi, Ci, 0, 0, 0, 0, 0, 0, 0, 0)))
                 release(dz)
                 dz = din
+            flush_colsums(bwd)
             if nside[0]:   # everything the side stream was given so far is final (end of backward, or a DDP bucket boundary)
                 bwd.append(("wait" if si == 0 else "mwait", (nside[0] - 1,)))
             bwd.append((None, (st["off"],)))
