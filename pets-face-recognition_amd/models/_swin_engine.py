@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from .._hip import lib, dtype_id, PfrError
 from .._hip.lib import _TRACER
+from .._hip.cplan import CPlan
 from ._fe_engine import default_compute_dtype, _ALIGN, _SIDE, _FORK, _SREC, _WAIT, _MWAIT, _side_with_ddp, PlanTicket
 
 
@@ -47,6 +48,9 @@ class SwinEngine:
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
         self.hook_syncs_side = False
+        # replay the launch lists from C (csrc/pfr_plan.hip) instead of the interpreter loop (PFR_C_PLAN=0 keeps the loop; a launch
+        # tracer always uses it)
+        self.c_plan = os.environ.get("PFR_C_PLAN", "1") != "0"
         # buffers per (shape, dtype) class of the backward pool before one that a side-stream op still reads is re-used (HBM is
         # plentiful; a shallow pool makes the main stream wait for the side stream at almost every layer)
         self.pool_depth = int(os.environ.get("PFR_POOL_DEPTH", "48"))
@@ -482,6 +486,7 @@ class SwinEngine:
             else:
                 res.append((fn, args))
         plan["bwd"] = res
+        plan.pop("c_bwd", None)
         plan["ws_ptr"] = (self.ws.data_ptr(), self.cs_ws.data_ptr())
 
     def get_plan(self, N, H, W, with_backward, slot=0):
@@ -529,10 +534,24 @@ class SwinEngine:
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh_weights(stream, for_backward=with_backward)
         lib.pfr_nchw_to_nhwc(x.data_ptr(), plan["x_nhwc"].data_ptr(), self.did, N, x.shape[1], H, W, self.cp, stream)
-        for fn, args in plan["fwd"]:
-            fn(*args, stream)
+        if not self._run_c(plan, "fwd", stream):
+            for fn, args in plan["fwd"]:
+                fn(*args, stream)
         self._last = plan
         return plan["emb"]
+
+    def _run_c(self, plan, key, stream, side=0, hook=None, n_events=0):
+        """replay plan[key] through the C executor when possible (same contract as FEEngine._run_list)"""
+        if not self.c_plan or _TRACER[0] is not None:
+            return False
+        ck = "c_" + key
+        cp = plan.get(ck, False)
+        if cp is False:
+            cp = plan[ck] = CPlan.compile(plan[key], n_events)
+        if cp is None:
+            return False
+        cp.run(stream, side, hook, self.hook_syncs_side)
+        return True
 
     def backward(self, demb, plan=None):
         plan = plan if plan is not None else self._last
@@ -558,9 +577,15 @@ class SwinEngine:
             self.wt_pending = False
         # side stream off: PFR_SIDE_STREAM=0, a launch tracer is active, or gradients are all-reduced (see FEEngine._side_ok)
         use_side = self.side_stream_enabled and _TRACER[0] is None and (hook is None or _side_with_ddp())
+        if use_side and self.side is None:
+            self.side = torch.cuda.Stream(device=self.device)
+        if self._run_c(plan, "bwd", stream, self.side.cuda_stream if use_side else 0,
+                       (lambda off: hook(off)) if hook is not None else None, 2 * plan.get("n_side", 0)):
+            if prev is not None:
+                self.grad.add_(prev)
+            self.attach_grads()
+            return
         if use_side:
-            if self.side is None:
-                self.side = torch.cuda.Stream(device=self.device)
             side, sptr = self.side, self.side.cuda_stream
             ev = self.side_events
             while len(ev) < 2 * plan.get("n_side", 0):
