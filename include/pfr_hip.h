@@ -120,7 +120,8 @@ int pfr_colsum(const void* x, int dtype, long rows, int C, float* out, int accum
 /* the same with the final merge deferred: pfr_colsum_partial leaves row-block partials in `workspace` (pfr_colsum_ws_floats floats,
  * one workspace per pending tensor); pfr_colsum_parts = how many partial rows that will be (0: too few rows, use pfr_colsum);
  * pfr_colsum_final_batch merges n partial sets in one launch.  descs: DEVICE array of {const float* part; float* out; int n; int C;
- * int accumulate; int pad} (32 bytes each) */
+ * int accumulate; int mt; int rows; int pad} (40 bytes each); mt > 0: `part` holds the [n][2][C] m-tile statistics a GEMM epilogue
+ * left (pfr_gemm_act_colstats, pfr_conv2d_fwd stats_part) for tiles of height mt over `rows` rows, and out = sum_t rows_t * mean_t */
 int pfr_colsum_parts(int dtype, long rows, int C);
 int pfr_colsum_partial(const void* x, int dtype, long rows, int C, float* workspace, pfr_stream_t stream);
 int pfr_colsum_final_batch(const void* descs, int n, int max_C, pfr_stream_t stream);
@@ -298,6 +299,10 @@ int pfr_augment_train(const unsigned char* x, int N, int H, int W, int crop_h, i
  *   act 3: y = (x·wT) * gelu'(y2)                         (data gradient of the second Linear joined with GELU backward) */
 int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
                  void* y2, pfr_stream_t stream);
+/* the same + per-m-tile column statistics of the stored y in stats_part [ceil(M / mtile)][2][N] (mtile = pfr_conv2d_mtile(M, N, K, K,
+ * dtype, dtype, 0)): a bias gradient (column sum of y) without another pass over y (pfr_colsum_final_batch, mt > 0) */
+int pfr_gemm_act_colstats(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
+                          void* y2, float* stats_part, pfr_stream_t stream);
 
 #ifdef __cplusplus
 }

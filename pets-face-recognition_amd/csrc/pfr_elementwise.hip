@@ -1265,7 +1265,8 @@ extern "C" int pfr_colsum_partial(const void* x, int dtype, long rows, int C, fl
 struct ColsumDesc {
   const float* part;
   float* out;
-  int n, C, accumulate, pad;
+  int n, C, accumulate;
+  int mt, rows, pad;   // mt > 0: `part` = [n][2][C] tile statistics (mean, M2) of m-tiles of height mt over `rows` rows: sum = Σ rows_t·mean_t
 };
 __global__ __launch_bounds__(256) void colsum_final_batch_kernel(const ColsumDesc* __restrict__ descs) {
   const ColsumDesc d = descs[blockIdx.y];
@@ -1276,13 +1277,17 @@ __global__ __launch_bounds__(256) void colsum_final_batch_kernel(const ColsumDes
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < d.C) {
     int r = rl;
-    for (; r + 48 < d.n; r += 64) {
-      a0 += d.part[(size_t)r * d.C + c];
-      a1 += d.part[(size_t)(r + 16) * d.C + c];
-      a2 += d.part[(size_t)(r + 32) * d.C + c];
-      a3 += d.part[(size_t)(r + 48) * d.C + c];
+    if (d.mt > 0) {
+      for (; r < d.n; r += 16) a0 = fmaf(d.part[(size_t)r * 2 * d.C + c], (float)min(d.mt, d.rows - r * d.mt), a0);
+    } else {
+      for (; r + 48 < d.n; r += 64) {
+        a0 += d.part[(size_t)r * d.C + c];
+        a1 += d.part[(size_t)(r + 16) * d.C + c];
+        a2 += d.part[(size_t)(r + 32) * d.C + c];
+        a3 += d.part[(size_t)(r + 48) * d.C + c];
+      }
+      for (; r < d.n; r += 16) a0 += d.part[(size_t)r * d.C + c];
     }
-    for (; r < d.n; r += 16) a0 += d.part[(size_t)r * d.C + c];
   }
   l[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();

@@ -847,8 +847,21 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int
 // Linear layer with a fused activation epilogue (Swin MLP: models/swin.py FeedForward = Linear → GELU → Linear):
 //   act 2: y = gelu(x·Wᵀ + b) and y2 = x·Wᵀ + b (the pre-activation, kept for backward)        [forward of fc1]
 //   act 3: y = (x·Wᵀ) ∘ gelu'(y2)                                                              [data gradient of fc2]
+static int gemm_act_impl(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
+                         void* y2, float* stats_part, hipStream_t stream);
 extern "C" int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias,
                             int act, void* y2, hipStream_t stream) {
+  return gemm_act_impl(x, w, y, dtype, M, K, N, bias, act, y2, nullptr, stream);
+}
+// the same, and the epilogue also leaves the per-m-tile column statistics of the stored output (tile mean, tile M2; tile height
+// pfr_conv2d_mtile(M, N, K, K, …)) — the column SUM of y (a bias gradient) is then sum_t rows_t * mean_t without another pass over y
+extern "C" int pfr_gemm_act_colstats(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias,
+                                     int act, void* y2, float* stats_part, hipStream_t stream) {
+  PFR_CHECK_ARG(stats_part, "pfr_gemm_act_colstats: null stats_part");
+  return gemm_act_impl(x, w, y, dtype, M, K, N, bias, act, y2, stats_part, stream);
+}
+static int gemm_act_impl(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
+                         void* y2, float* stats_part, hipStream_t stream) {
   PFR_CHECK_ARG(x && w && y && y2, "pfr_gemm_act: null pointer");
   PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_gemm_act: bad dtype %d", dtype);
   PFR_CHECK_ARG(act == 2 || act == 3, "pfr_gemm_act: act must be 2 (gelu, keep pre-activation) or 3 (multiply by gelu')");
@@ -861,7 +874,7 @@ extern "C" int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, lo
   p.R = 1; p.S = 1; p.OH = 1; p.OW = 1; p.ostride = 1; p.pad = 0; p.idil_log2 = 0;
   p.Cout = N; p.ldy = N;
   p.M = (int)M; p.K = K;
-  p.stats_part = nullptr; p.bias = bias; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
+  p.stats_part = stats_part; p.bias = bias; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
   p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
   p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = nullptr;
   p.bnb_mask = nullptr;

@@ -245,7 +245,7 @@ class SwinEngine:
 
         cs_need = [0]
 
-        pend_cs = []   # column sums whose final merge is deferred to the next flush: (workspace, out, partial rows, C)
+        pend_cs = []   # column sums whose final merge is deferred to the next flush: (partials, out, partial rows, C, tile height | 0, rows)
 
         def colsum(ops, x, rows, C, out, dt=None):
             """bias / LayerNorm-parameter / position-table gradient = column sum of x; the partial sums run now (side stream), the
@@ -257,16 +257,16 @@ class SwinEngine:
                 return
             ws = A((lib.pfr_colsum_ws_floats(rows, C),), torch.float32)   # its own workspace: alive until the batched final
             side(ops, ("side", (lib.pfr_colsum_partial, (x.data_ptr(), d, rows, C, ws.data_ptr()))), x)
-            pend_cs.append((ws, out, n, C))
+            pend_cs.append((ws, out, n, C, 0, 0))
 
         def flush_colsums(ops):
             if not pend_cs:
                 return
             import struct
-            raw = b"".join(struct.pack("<QQiiii", ws.data_ptr(), out.data_ptr(), n, C, 0, 0) for ws, out, n, C in pend_cs)
+            raw = b"".join(struct.pack("<QQiiiiii", ws.data_ptr(), out.data_ptr(), n, C, 0, mt, rws, 0) for ws, out, n, C, mt, rws in pend_cs)
             tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
             bufs.append(tab)
-            side(ops, ("side", (lib.pfr_colsum_final_batch, (tab.data_ptr(), len(pend_cs), max(c for _, _, _, c in pend_cs)))))
+            side(ops, ("side", (lib.pfr_colsum_final_batch, (tab.data_ptr(), len(pend_cs), max(e[3] for e in pend_cs)))))
             del pend_cs[:]
 
         x_nhwc = A((N, H, W, self.cp))
@@ -400,12 +400,18 @@ class SwinEngine:
                 wgrad(bwd, sv["h2"], (rows, 1, 1, 4 * C), dz, (rows, 1, 1, C), b["fc2"], 1, 1, b["fc2"].g)
                 dh2 = G((rows, 4 * C))
                 if self.fuse_gelu:   # dh1 = (dz·W2) ∘ gelu'(h1) in the data-gradient GEMM's epilogue
-                    bwd.append((lib.pfr_gemm_act, (dz.data_ptr(), b["fc2"].wt.data_ptr(), dh2.data_ptr(), did, rows, C, 4 * C, 0, 3,
-                                                   sv["h1"].data_ptr())))
+                    # ... which also leaves the per-m-tile column means of dh1: fc1's bias gradient = sum_t rows_t * mean_t, merged
+                    # with the other deferred column sums -- no second pass over the widest gradient tensor of the block
+                    mt = lib.pfr_conv2d_mtile(rows, 4 * C, C, C, did, did, 0)
+                    nt = (rows + mt - 1) // mt
+                    stp = A((nt, 2, 4 * C), torch.float32)
+                    bwd.append((lib.pfr_gemm_act_colstats, (dz.data_ptr(), b["fc2"].wt.data_ptr(), dh2.data_ptr(), did, rows, C, 4 * C, 0,
+                                                            3, sv["h1"].data_ptr(), stp.data_ptr())))
+                    pend_cs.append((stp, b["fc1"].dbias, nt, 4 * C, mt, rows))
                 else:
                     dgrad_lin(bwd, dz, rows, b["fc2"], dh2)
                     bwd.append((lib.pfr_gelu_bwd, (sv["h1"].data_ptr(), dh2.data_ptr(), dh2.data_ptr(), did, rows * 4 * C)))
-                colsum(bwd, dh2, rows, 4 * C, b["fc1"].dbias)
+                    colsum(bwd, dh2, rows, 4 * C, b["fc1"].dbias)
                 wgrad(bwd, sv["ln2"], (rows, 1, 1, C), dh2, (rows, 1, 1, 4 * C), b["fc1"], 1, 1, b["fc1"].g)
                 dln2 = G((rows, C))
                 dgrad_lin(bwd, dh2, rows, b["fc1"], dln2)
