@@ -368,12 +368,13 @@ class SwinEngine:
 
         def ln_bwd(ops, dy, xin, mu, rs, lnrec, dres, dx, rows, C):
             nb = lib.pfr_layernorm_bwd_blocks(rows)
-            part = G((2, nb, C), torch.float32)
+            # the kernel's per-workgroup partials ARE the partial sets of the deferred final merge (own buffer per LayerNorm: they
+            # must survive until the batched merge at the next bucket boundary)
+            part = A((2, nb, C), torch.float32)
             ops.append((lib.pfr_layernorm_bwd, (dy.data_ptr(), xin.data_ptr(), mu.data_ptr(), rs.data_ptr(), lnrec.gamma.data_ptr(),
                                                 0 if dres is None else dres.data_ptr(), dx.data_ptr(), part.data_ptr(), did, rows, C)))
-            colsum(ops, part[0], nb, C, lnrec.dgamma, 0)
-            colsum(ops, part[1], nb, C, lnrec.dbeta, 0)
-            release(part)
+            pend_cs.append((part[0], lnrec.dgamma, nb, C, 0, 0))
+            pend_cs.append((part[1], lnrec.dbeta, nb, C, 0, 0))
 
         demb = A((N, self.emb_dim))
         plan["demb"] = demb
