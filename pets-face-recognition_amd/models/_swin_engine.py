@@ -358,9 +358,14 @@ class SwinEngine:
             pool.setdefault((tuple(t.shape), t.dtype), []).append(t)
 
         def side(ops, op, *reads):
-            k = nside[0]
-            nside[0] += 1
-            ops.append(("fork", (k,)))
+            if ops and ops[-1][0] == "srec":
+                # no main-stream launch since the previous side op: it joins that op's fork (every fork is an event recorded on the
+                # main stream, i.e. a marker packet in front of the next kernel of the dependency chain)
+                k = ops.pop()[1][0]
+            else:
+                k = nside[0]
+                nside[0] += 1
+                ops.append(("fork", (k,)))
             ops.append(op)
             ops.append(("srec", (k,)))
             for r in reads:
