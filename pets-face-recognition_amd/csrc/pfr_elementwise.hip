@@ -111,18 +111,30 @@ struct WtDesc {
   void* wt;
   int O, R, S, I;
 };
+// one tap of one layer is an O x I matrix transpose (input row stride RS*I, output row stride RS*O): 64x64 tiles through LDS so
+// that both the loads (along ci) and the stores (along o) are contiguous
 template <typename T>
 __global__ __launch_bounds__(256) void weight_dgrad_batch_kernel(const WtDesc* __restrict__ descs) {
   const WtDesc d = descs[blockIdx.y];
   const T* __restrict__ w = reinterpret_cast<const T*>(d.w);
   T* __restrict__ wt = reinterpret_cast<T*>(d.wt);
-  const uint32_t O = d.O, R = d.R, S = d.S, I = d.I, n = O * R * S * I;
-  const uint32_t RS = R * S;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    // i indexes the OUTPUT [ci][r][s][o] so stores are coalesced
-    const uint32_t o = i % O, rest = i / O;
-    const uint32_t tap = rest % RS, ci = rest / RS;
-    wt[i] = w[((size_t)o * RS + (RS - 1 - tap)) * I + ci];    // both taps flipped = the tap index reversed
+  const uint32_t O = d.O, I = d.I, RS = d.R * d.S;
+  const uint32_t to = (O + 63) / 64, ti = (I + 63) / 64, ntiles = RS * to * ti;
+  __shared__ T tile[64][64 + 4 / sizeof(T)];
+  const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint32_t tap = t % RS, rest = t / RS;
+    const uint32_t o0 = (rest % to) * 64, c0 = (rest / to) * 64;
+    __syncthreads();
+    if (c0 + tx < I)
+#pragma unroll
+      for (uint32_t r = ty; r < 64; r += 4)
+        if (o0 + r < O) tile[r][tx] = w[((size_t)(o0 + r) * RS + tap) * I + c0 + tx];
+    __syncthreads();
+    if (o0 + tx < O)
+#pragma unroll
+      for (uint32_t r = ty; r < 64; r += 4)
+        if (c0 + r < I) wt[((size_t)(c0 + r) * RS + (RS - 1 - tap)) * O + o0 + tx] = tile[tx][r];    // both taps flipped = the tap index reversed
   }
 }
 

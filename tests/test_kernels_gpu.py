@@ -437,3 +437,20 @@ def test_alternative_gemm_kernels_bit_identical(case):
         assert torch.equal(y, outs[0][0])
         if st is not None:
             assert torch.allclose(st, outs[0][1], rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_dgrad_layout_batch_ragged_layers(dtype):
+    """one launch for many layers (64x64 LDS tiles): wt[ci][R-1-r][S-1-s][o] = w[o][r][s][ci], sizes that are not tile multiples"""
+    import struct
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    g = torch.Generator().manual_seed(3)
+    shapes = [(70, 3, 3, 3), (10, 1, 1, 100), (64, 1, 1, 64), (130, 3, 3, 65), (1, 1, 1, 1), (256, 4, 4, 16)]
+    ws = [torch.randn(s, generator=g).to(DEV, dtype) for s in shapes]
+    wts = [torch.full((s[3], s[1], s[2], s[0]), float("nan"), device=DEV, dtype=dtype) for s in shapes]
+    raw = b"".join(struct.pack("<QQiiii", w.data_ptr(), t.data_ptr(), s[0], s[1], s[2], s[3]) for w, t, s in zip(ws, wts, shapes))
+    tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(DEV)
+    lib.pfr_weight_dgrad_layout_batch(tab.data_ptr(), len(shapes), dtype_id(dtype), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for w, t in zip(ws, wts):
+        assert torch.equal(t, w.flip(1, 2).permute(3, 1, 2, 0).contiguous())
