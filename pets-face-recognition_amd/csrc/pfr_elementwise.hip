@@ -128,13 +128,13 @@ __global__ __launch_bounds__(256) void weight_dgrad_batch_kernel(const WtDesc* _
     __syncthreads();
     if (c0 + tx < I)
 #pragma unroll
-      for (uint32_t r = ty; r < 64; r += 4)
-        if (o0 + r < O) tile[r][tx] = w[((size_t)(o0 + r) * RS + tap) * I + c0 + tx];
+      for (uint32_t k = 0; k < 16; ++k)
+        if (const uint32_t r = ty + 4 * k; o0 + r < O) tile[r][tx] = w[((size_t)(o0 + r) * RS + tap) * I + c0 + tx];
     __syncthreads();
     if (o0 + tx < O)
 #pragma unroll
-      for (uint32_t r = ty; r < 64; r += 4)
-        if (c0 + r < I) wt[((size_t)(c0 + r) * RS + (RS - 1 - tap)) * O + o0 + tx] = tile[tx][r];    // both taps flipped = the tap index reversed
+      for (uint32_t k = 0; k < 16; ++k)
+        if (const uint32_t r = ty + 4 * k; c0 + r < I) wt[((size_t)(c0 + r) * RS + (RS - 1 - tap)) * O + o0 + tx] = tile[tx][r];    // both taps flipped = the tap index reversed
   }
 }
 
