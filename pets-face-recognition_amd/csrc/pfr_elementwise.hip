@@ -277,16 +277,41 @@ __device__ __forceinline__ float part_rows(long total, long rpp, int i) {
 }
 
 // merges parts [pbeg, pend) for 16 channels; returns (via lane pl==0) n, mean, M2.  counts: optional per-part row counts.
+// These launches sit on the dependency chain of every BatchNorm, so their latency is what matters: up to 256 parts (always, as
+// pfr_bn_finalize groups larger sets first) every thread issues ALL its loads up front from clamped addresses and keeps the values in
+// registers for the second (M2) pass — one memory round trip instead of one per part and pass.  Summation order is unchanged.
+#define PFR_MERGE_K 16
 __device__ __forceinline__ void merge_parts(const float* __restrict__ part, const float* __restrict__ counts, int pbeg,
                                             int pend, long rpp, long total, int C, int c, int cl, int pl,
                                             float (*l1)[17], float (*l2)[17], float& n_out, float& mean_out, float& m2_out) {
+  const bool fast = pend - pbeg <= 16 * PFR_MERGE_K;
+  float mu[PFR_MERGE_K], q2[PFR_MERGE_K], nk[PFR_MERGE_K];
   float a = 0.f, n = 0.f;
-  if (c < C)
+  if (fast) {
+    const int cc = c < C ? c : C - 1;
+#pragma unroll
+    for (int k = 0; k < PFR_MERGE_K; ++k) {
+      const int i = pbeg + pl + 16 * k;
+      const bool valid = c < C && i < pend;
+      const int ic = i < pend ? i : pbeg;
+      mu[k] = part[((size_t)ic * 2 + 0) * C + cc];
+      q2[k] = part[((size_t)ic * 2 + 1) * C + cc];
+      nk[k] = counts ? counts[ic] : part_rows(total, rpp, ic);
+      if (!valid) { nk[k] = 0.f; q2[k] = 0.f; }
+    }
+#pragma unroll
+    for (int k = 0; k < PFR_MERGE_K; ++k)
+      if (pbeg + pl + 16 * k < pend) {     // (same operations, in the same order, as the loop below)
+        n += nk[k];
+        a = fmaf(nk[k], mu[k], a);
+      }
+  } else if (c < C) {
     for (int i = pbeg + pl; i < pend; i += 16) {
       const float nt = counts ? counts[i] : part_rows(total, rpp, i);
       n += nt;
       a = fmaf(nt, part[((size_t)i * 2 + 0) * C + c], a);
     }
+  }
   l1[pl][cl] = a;
   l2[pl][cl] = n;
   __syncthreads();
@@ -296,12 +321,20 @@ __device__ __forceinline__ void merge_parts(const float* __restrict__ part, cons
   const float mean = sn > 0.f ? sa / sn : 0.f;
   __syncthreads();
   float m2 = 0.f;
-  if (c < C)
+  if (fast) {
+#pragma unroll
+    for (int k = 0; k < PFR_MERGE_K; ++k)
+      if (c < C && pbeg + pl + 16 * k < pend) {
+        const float d = mu[k] - mean;
+        m2 += q2[k] + nk[k] * d * d;
+      }
+  } else if (c < C) {
     for (int i = pbeg + pl; i < pend; i += 16) {
       const float nt = counts ? counts[i] : part_rows(total, rpp, i);
       const float d = part[((size_t)i * 2 + 0) * C + c] - mean;
       m2 += part[((size_t)i * 2 + 1) * C + c] + nt * d * d;
     }
+  }
   l1[pl][cl] = m2;
   __syncthreads();
   float s2 = 0.f;
@@ -341,19 +374,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   float n, mean, m2;
+  // the per-channel operands of the tail are requested before the merge (their latency overlaps the merge's own loads)
+  const int cc = c < C ? c : C - 1;
+  const float g = gamma ? gamma[cc] : 1.f, bb = beta ? beta[cc] : 0.f;
+  const float rm = running_mean ? running_mean[cc] : 0.f, rv = running_mean ? running_var[cc] : 0.f;
   merge_parts(part, counts, 0, nparts, rpp, (long)count, C, c, cl, pl, l1, l2, n, mean, m2);
   if (pl == 0 && c < C) {
     float var = fmaxf(m2 / count, 0.f);  // biased batch variance
     const float invstd = rsqrtf(var + eps);
-    const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
     mean_out[c] = mean;
     invstd_out[c] = invstd;
     scale[c] = g * invstd;
     shift[c] = bb - mean * g * invstd;
     if (running_mean) {
       const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+      running_mean[c] = (1.f - momentum) * rm + momentum * mean;
+      running_var[c] = (1.f - momentum) * rv + momentum * unb;
     }
   }
 }
@@ -618,11 +654,26 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   float a = 0.f, b = 0.f;
-  if (c < C)
-    for (int i = pl; i < nparts; i += 64) {
-      a += part[((size_t)i * 2 + 0) * C + c];
-      b += part[((size_t)i * 2 + 1) * C + c];
+  // (latency-critical like bn_finalize_kernel: batches of 8 parts per thread are requested together from clamped addresses, and the
+  // per-channel operands of the tail before the reduction)
+  const int cc = c < C ? c : C - 1;
+  const float g = gamma ? gamma[cc] : 1.f, is = invstd[cc], mu = mean[cc];
+  const float dg0 = (dgamma && accumulate) ? dgamma[cc] : 0.f, db0 = (dbeta && accumulate) ? dbeta[cc] : 0.f;
+  for (int i0 = pl; i0 < nparts; i0 += 64 * 8) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + 64 * k, ic = i < nparts ? i : pl;
+      va[k] = part[((size_t)ic * 2 + 0) * C + cc];
+      vb[k] = part[((size_t)ic * 2 + 1) * C + cc];
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (c < C && i0 + 64 * k < nparts) {
+        a += va[k];
+        b += vb[k];
+      }
+  }
   l1[pl][cl] = a;
   l2[pl][cl] = b;
   __syncthreads();
@@ -630,9 +681,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     float sg = 0.f, sgx = 0.f;
 #pragma unroll 8
     for (int i = 0; i < 64; ++i) { sg += l1[i][cl]; sgx += l2[i][cl]; }
-    const float g = gamma ? gamma[c] : 1.f, is = invstd[c], mu = mean[c];
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sgx : sgx;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sg : sg;
+    if (dgamma) dgamma[c] = accumulate ? dg0 + sgx : sgx;
+    if (dbeta) dbeta[c] = accumulate ? db0 + sg : sg;
     const float cg = g * is;
     const float cx = -g * is * is * sgx / count;
     const float c0 = -g * is * sg / count - cx * mu;

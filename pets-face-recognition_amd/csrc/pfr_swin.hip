@@ -718,6 +718,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
 // of the accumulator rows is (r&3) + 8(r>>2) + 4(lane>>5); the A operand (Vᵀ, Kᵀ, Qᵀ, dOᵀ) is read from a natural
 // [token][d] LDS tile with ds_read_b64_tr_b16 at exactly those rows, so the reduction index is permuted identically on
 // both sides.
+__constant__ int wa_dbg;
 #define WA_RS 80   // LDS row stride in bytes of a [64 tokens][32 d] bf16 tile (64 B + 16 B pad)
 
 __device__ __forceinline__ bf16x8 wa_rowfrag(const char* tile, int tok_tile, int ks, int lane) {
@@ -743,10 +744,18 @@ __device__ __forceinline__ bf16x8 wa_accfrag(const f32x16& v, int t) {   // accu
 }
 __device__ __forceinline__ int wa_accrow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-struct WaUnit { int b, gy, gx, h, var; };
+// Workgroups are dealt round-robin to the 8 XCDs (each with an L2 of its own).  The heads of one window read interleaved 64-byte
+// slices of the same [token][3C] rows: with unit = blockIdx every XCD fetched whole 128-byte lines for half their bytes (and wrote
+// half lines).  Each XCD therefore takes a CONTIGUOUS range of units, walked in order.
+__device__ __forceinline__ int wa_xcd_unit(int blk, int n) {
+  const int per = n >> 3, rem = n & 7, x = blk & 7;
+  return x * per + min(x, rem) + (blk >> 3);
+}
+struct WaUnit { int b, gy, gx, h, var, unit; };
 __device__ __forceinline__ WaUnit wa_decode(const WinAttn& a, int unit) {
   const int nwh = a.H / a.w, nww = a.W / a.w;
   WaUnit u;
+  u.unit = unit;
   u.h = unit % a.heads; unit /= a.heads;
   u.gx = unit % nww; unit /= nww;
   u.gy = unit % nwh;
@@ -754,39 +763,46 @@ __device__ __forceinline__ WaUnit wa_decode(const WinAttn& a, int unit) {
   u.var = ((u.gy == nwh - 1) ? 2 : 0) + ((u.gx == nww - 1) ? 1 : 0);
   return u;
 }
-// loads the d-chunks {half, 2+half} of this lane's two token rows of one operand into the LDS tile (zeros past nt)
-__device__ __forceinline__ void wa_load_tile(char* tile, const bf16_t* base, const size_t (&tokoff)[2], const bool (&ok)[2], size_t rowstride, int lane) {
-  const int row = lane & 31, half = lane >> 5;
+// loads one operand's [64 tokens][32 d] slice into the LDS tile (zeros past nt).  Lane = (token row lane>>2 (+16·p), 16-byte chunk
+// lane&3): the four lanes of a quad read one contiguous 64-byte head row, i.e. ONE request for the texture-address unit — with the
+// (row lane&31, chunk lane>>5) assignment of round 1 every lane was a request of its own and address processing, not bytes, bounded
+// the kernel.  toff: the window's token → row-of-the-[tokens][·] tensor table in LDS (−1 = padding).
+__device__ __forceinline__ void wa_load_tile(char* tile, const bf16_t* base, const int* toff, size_t rowstride, int lane) {
+  const int ch = lane & 3;
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int ch = half + 2 * c;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok[tt]) v = ld16(base + tokoff[tt] * rowstride + ch * 8);
-      *reinterpret_cast<u32x4*>(tile + (row + 32 * tt) * WA_RS + ch * 16) = v;
-    }
+  for (int p = 0; p < 4; ++p) {
+    const int row = (lane >> 2) + 16 * p;
+    // padding rows carry ~(a valid row) in the table: the load is UNCONDITIONAL (a branch around it makes the compiler wait for
+    // every load before the next one — 12-16 serialised round trips per wave, which was 40 % of these kernels) and zeroed by a select
+    const int tk = toff[row];
+    u32x4 v = ld16(base + (size_t)(tk < 0 ? ~tk : tk) * rowstride + ch * 8);
+    if (tk < 0) v = u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(tile + row * WA_RS + ch * 16) = v;
+  }
 }
 
 __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ tab,
                                                                   bf16_t* __restrict__ out, WinAttn a) {
   __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS];
+  __shared__ int toff[64];
   const int lane = threadIdx.x;
-  const WaUnit u = wa_decode(a, blockIdx.x);
+  const WaUnit u = wa_decode(a, (wa_dbg & 64) ? (int)blockIdx.x : wa_xcd_unit(blockIdx.x, gridDim.x));
   const int nt = a.w * a.w, C = a.heads * a.hd;
   const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
+  toff[lane] = lane < nt ? (int)wa_token_off(a, u.b, u.gy, u.gx, lane) : ~(int)wa_token_off(a, u.b, u.gy, u.gx, 0);   // one wave: LDS operations complete in order
+  __builtin_amdgcn_wave_barrier();
   size_t tokoff[2];
   bool ok[2];
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
-    const int t = (lane & 31) + 32 * tt;
-    ok[tt] = t < nt;
-    tokoff[tt] = ok[tt] ? wa_token_off(a, u.b, u.gy, u.gx, t) : 0;
+    const int tk = toff[(lane & 31) + 32 * tt];
+    ok[tt] = tk >= 0;
+    tokoff[tt] = (size_t)(ok[tt] ? tk : ~tk);       // padding rows point at a valid row (loads are unconditional, stores are not)
   }
   const bf16_t* qb = qkv + u.h * a.hd;
-  wa_load_tile(lq, qb, tokoff, ok, 3 * (size_t)C, lane);
-  wa_load_tile(lk, qb + C, tokoff, ok, 3 * (size_t)C, lane);
-  wa_load_tile(lv, qb + 2 * C, tokoff, ok, 3 * (size_t)C, lane);
+  wa_load_tile(lq, qb, toff, 3 * (size_t)C, lane);
+  wa_load_tile(lk, qb + C, toff, 3 * (size_t)C, lane);
+  wa_load_tile(lv, qb + 2 * C, toff, 3 * (size_t)C, lane);
   __syncthreads();
   // Sᵀ[j][i] = K·Qᵀ
   f32x16 sacc[2][2];   // [jt][it]
@@ -851,44 +867,76 @@ __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* 
   }
 }
 
-// backward: recomputes Sᵀ/Pᵀ (orientation 1: rows j, columns i → dQ, dpos) and S/P (orientation 2: rows i, columns j →
-// dK, dV); per-query softmax statistics travel from orientation 1 to 2 through 3x64 floats of LDS.
+// backward, ONE orientation (rows j = keys, columns i = queries, as in the forward kernel): per query half it produces Pᵀ and dSᵀ
+// in accumulator registers → dQᵀ = Kᵀ·dSᵀ directly; for dVᵀ = dOᵀ·P and dKᵀ = Qᵀ·dS the reduction runs over the queries, which sit
+// across lanes, so the two 32x32 bf16 quarters go through a 2.3 KB LDS tile each ([query][key], written as 8-byte rows, read back with
+// the transposing ds_read_b64_tr_b16 into B-operand layout).  Nothing is recomputed (round 1 rebuilt S, P and dP in the second
+// orientation: +16 MFMAs, +64 exponentials and 64 scattered bias loads per window-head).  V is only ever a row-fragment operand and
+// is held in registers straight from global memory (no LDS tile): 24 KB of LDS per wave = 6 window-heads per CU.
+#define WA_TS 72   // LDS row stride in bytes of a [32 queries][32 keys] bf16 quarter (64 B + 8 B pad: the 8-byte row writes of 32 lanes hit 32 distinct bank pairs)
+__device__ __forceinline__ bf16x8 wa_trfrag_q(const char* tile, int t, int lane) {
+  // B operand [K = query][N = key] from the quarter tile; reduction slots e ↔ query 16·t + 8·(e>>2) + 4·half + (e&3) as in wa_trfrag
+  const int g = lane >> 4, s4 = lane & 15;
+  const char* a = tile + (16 * t + (g >> 1) * 4 + (s4 >> 2)) * WA_TS + ((g & 1) * 16 + (s4 & 3) * 4) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 8 * WA_TS));
+  u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  u32x4 u = {l2[0], l2[1], h2[0], h2[1]};
+  return __builtin_bit_cast(bf16x8, u);
+}
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ tab,
                                                                   const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                                   float* __restrict__ dpos_part, WinAttn a) {
-  __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS], lg[64 * WA_RS];
-  __shared__ __attribute__((aligned(16))) float st_m[64], st_l[64], st_d[64];
+  __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lg[64 * WA_RS];
+  __shared__ __attribute__((aligned(16))) char tp[32 * WA_TS], td[32 * WA_TS];
   // Position-table gradient bins are accumulated as 64-bit INTEGERS: on gfx950 a wave64 `ds_add_f32` costs 190 (idle) … 950
   // (loaded CU) cycles, `ds_add_u64` 14 … 46 (tools/probe/lds_atomic_probe.hip) — the float scatter was 70 % of this kernel's
   // LDS-array time.  Block floating point: each query half scales its dS values by the power of two that puts the largest
-  // magnitude at 2^40 (values more than 2^-40 below the largest are truncated — far beyond fp32 accumulation accuracy), so the
+  // magnitude at 2^30 (values more than 2^-30 below the largest are truncated — finer than fp32 accumulation), so the
   // sums are order-independent AND exactly homogeneous (doubling dO doubles every bin bit for bit, tests/test_fullsize_gpu.py).
   __shared__ unsigned long long dtab[2][256];
   __shared__ __attribute__((aligned(16))) int cj[64];
+  __shared__ int toff[64];
   const int lane = threadIdx.x;
-  const WaUnit u = wa_decode(a, blockIdx.x);
+  const WaUnit u = wa_decode(a, (wa_dbg & 64) ? (int)blockIdx.x : wa_xcd_unit(blockIdx.x, gridDim.x));
   const int nt = a.w * a.w, C = a.heads * a.hd, w = a.w;
   const int ntab = (2 * w - 1) * (2 * w - 1);
   const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
   for (int e = lane; e < 256; e += 64) { dtab[0][e] = 0ull; dtab[1][e] = 0ull; }
   float inv_scale[2] = {0.f, 0.f};
   cj[lane] = lane < nt ? (lane / w) * (2 * w - 1) + lane % w : -(1 << 20);
+  toff[lane] = lane < nt ? (int)wa_token_off(a, u.b, u.gy, u.gx, lane) : ~(int)wa_token_off(a, u.b, u.gy, u.gx, 0);   // one wave: LDS operations complete in order
+  __builtin_amdgcn_wave_barrier();
   size_t tokoff[2];
   bool ok[2];
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
-    const int t = (lane & 31) + 32 * tt;
-    ok[tt] = t < nt;
-    tokoff[tt] = ok[tt] ? wa_token_off(a, u.b, u.gy, u.gx, t) : 0;
+    const int tk = toff[(lane & 31) + 32 * tt];
+    ok[tt] = tk >= 0;
+    tokoff[tt] = (size_t)(ok[tt] ? tk : ~tk);       // padding rows point at a valid row (loads are unconditional, stores are not)
   }
   const bf16_t* qb = qkv + u.h * a.hd;
-  wa_load_tile(lq, qb, tokoff, ok, 3 * (size_t)C, lane);
-  wa_load_tile(lk, qb + C, tokoff, ok, 3 * (size_t)C, lane);
-  wa_load_tile(lv, qb + 2 * C, tokoff, ok, 3 * (size_t)C, lane);
-  wa_load_tile(lg, dout + u.h * a.hd, tokoff, ok, (size_t)C, lane);
+  // V row fragments (key j = lane&31 + 32·jt, d = 16·ks + 8·(lane>>5) …): the same 16-byte chunks wa_load_tile would stage
+  bf16x8 vf[2][2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 v = ld16(qb + 2 * C + tokoff[jt] * (3 * (size_t)C) + 16 * ks + 8 * (lane >> 5));
+      if (!ok[jt]) v = u32x4{0u, 0u, 0u, 0u};
+      vf[jt][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  wa_load_tile(lq, qb, toff, 3 * (size_t)C, lane);
+  wa_load_tile(lk, qb + C, toff, 3 * (size_t)C, lane);
+  wa_load_tile(lg, dout + u.h * a.hd, toff, (size_t)C, lane);
   __syncthreads();
+  if (wa_dbg & 16) { if (lq[lane*7] == 77 && lk[lane] == 3 && lg[lane] == 5) dpos_part[0] = 1.f; return; }
 
-  // ---------------- orientation 1: rows j (keys), columns i (queries)
+  f32x16 dv[2], dk[2];   // dVᵀ / dKᵀ [d][key], accumulated over both query halves
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dv[jt][e] = 0.f; dk[jt][e] = 0.f; }
 #pragma unroll 1
   for (int it = 0; it < 2; ++it) {
     const int i = (lane & 31) + 32 * it;
@@ -901,7 +949,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 qf = wa_rowfrag(lq, it, ks, lane), gf = wa_rowfrag(lg, it, ks, lane);
         sa[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lk, jt, ks, lane), qf, sa[jt], 0, 0, 0);   // Sᵀ = K·Qᵀ
-        dp[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lv, jt, ks, lane), gf, dp[jt], 0, 0, 0);   // dPᵀ = V·dOᵀ
+        dp[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jt][ks], gf, dp[jt], 0, 0, 0);                      // dPᵀ = V·dOᵀ
       }
     }
     float mx = -INFINITY;
@@ -909,7 +957,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(btab + i * WA_MAXT + 32 * jt + 8 * g + 4 * (lane >> 5));
+        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+        if (!(wa_dbg & 8)) bb = *reinterpret_cast<const f32x4*>(btab + i * WA_MAXT + 32 * jt + 8 * g + 4 * (lane >> 5));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = fmaf(sa[jt][4 * g + e], a.scale, bb[e]);
@@ -939,8 +988,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
         dl = fmaf(sa[jt][e], dp[jt][e], dl);
       }
     dl += __shfl_xor(dl, 32, 64);
-    if (lane < 32) { st_m[i] = mx; st_l[i] = inv; st_d[i] = dl; }
-    // dSᵀ = Pᵀ∘(dPᵀ − δ_i); position-table gradient; dQᵀ = Kᵀ·dSᵀ
+    // dSᵀ = Pᵀ∘(dPᵀ − δ_i) (into dp; sa keeps Pᵀ); position-table gradient; dQᵀ = Kᵀ·dSᵀ
     // table index of (i, j) = base(i) + cj[j]; padded rows / columns give a negative index and are skipped
     const int yi = i / w, xi = i - yi * w;
     const int base_i = i < nt ? (w - 1 - yi) * (2 * w - 1) + (w - 1 - xi) : -(1 << 20);
@@ -950,17 +998,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float dsv = sa[jt][e] * (dp[jt][e] - dl);
-        sa[jt][e] = dsv;
+        dp[jt][e] = dsv;
         amax = fmaxf(amax, fabsf(dsv));
       }
 #pragma unroll
     for (int o = 32; o; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    // scale = 2^(40 - exponent(amax)) (1 when everything is zero / not finite); its reciprocal is exact as well
+    // scale = 2^(30 - exponent(amax)) (1 when everything is zero / not finite); its reciprocal is exact as well.  |x·scale| < 2^31:
+    // ONE float→int conversion (toward zero) per value, sign-extended to the 64-bit bin
     const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
-    const int kexp = (ex == 0 || ex == 255) ? 0 : min(40 - (ex - 127), 120);
+    const int kexp = (ex == 0 || ex == 255) ? 0 : min(30 - (ex - 127), 120);
     const float sc = __uint_as_float((uint32_t)(kexp + 127) << 23);
     if (it == 0) inv_scale[0] = __uint_as_float((uint32_t)(127 - kexp) << 23); else inv_scale[1] = __uint_as_float((uint32_t)(127 - kexp) << 23);
     unsigned long long* dt = dtab[it];
+    // padded rows / columns have dS == 0 exactly: they add 0 to a spare bin behind the table instead of branching around the atomic
+    const int dump = ntab + (lane & 15);
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -970,12 +1021,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int idx = base_i + cc[e];
-          if (idx >= 0) {
-            const float xs = sa[jt][4 * g + e] * sc;                       // exact (power of two), |xs| < 2^41
-            const float hf = floorf(xs * 2.3283064365386963e-10f);         // floor(xs / 2^32)
-            const unsigned lo = (unsigned)fmaf(hf, -4294967296.f, xs);      // xs - hf*2^32 in [0, 2^32): exact
-            atomicAdd(&dt[idx], ((unsigned long long)(unsigned)(int)hf << 32) | lo);
-          }
+          const int xi32 = (int)(dp[jt][4 * g + e] * sc);                    // exact product (power of two), truncated toward zero
+          if (!(wa_dbg & 1)) atomicAdd(&dt[idx >= 0 ? idx : dump], (unsigned long long)(long long)xi32);
         }
       }
     f32x16 dq;
@@ -985,8 +1032,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lk, jt, t, lane), wa_accfrag(sa[jt], t), dq, 0, 0, 0);
-    if (ok[it]) {
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lk, jt, t, lane), wa_accfrag(dp[jt], t), dq, 0, 0, 0);
+    if (ok[it] && !(wa_dbg & 2)) {
       bf16_t* ob = dqkv + tokoff[it] * (3 * (size_t)C) + u.h * a.hd;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -996,66 +1043,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
         *reinterpret_cast<bf16x4*>(ob + 8 * g + 4 * (lane >> 5)) = v;
       }
     }
-  }
-  __syncthreads();
-
-  // ---------------- orientation 2: rows i (queries), columns j (keys)
-#pragma unroll 1
-  for (int jt = 0; jt < 2; ++jt) {
-    const int j = (lane & 31) + 32 * jt;
-    f32x16 pa[2], ds[2];
+    // dVᵀ[d][j] += Σ_i dOᵀ[d][i]·P[i][j],  dKᵀ[d][j] += Σ_i Qᵀ[d][i]·dS[i][j]   (i over this query half), one key quarter at a time
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { pa[it][e] = 0.f; ds[it][e] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 kf = wa_rowfrag(lk, jt, ks, lane), vf = wa_rowfrag(lv, jt, ks, lane);
-        pa[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lq, it, ks, lane), kf, pa[it], 0, 0, 0);   // S = Q·Kᵀ
-        ds[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lg, it, ks, lane), vf, ds[it], 0, 0, 0);   // dP = dO·Vᵀ
-      }
+    for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int i0 = 32 * it + 8 * g + 4 * (lane >> 5);
-        const f32x4 m4 = *reinterpret_cast<const f32x4*>(st_m + i0), l4 = *reinterpret_cast<const f32x4*>(st_l + i0),
-                    d4 = *reinterpret_cast<const f32x4*>(st_d + i0);
+        bf16x4 pv, sv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float sv = fmaf(pa[it][4 * g + e], a.scale, btab[(i0 + e) * WA_MAXT + j]);
-          const float pv = __expf(sv - m4[e]) * l4[e];   // −inf bias → 0
-          pa[it][4 * g + e] = pv;
-          ds[it][4 * g + e] = pv * (ds[it][4 * g + e] - d4[e]);
+          pv[e] = (bf16_t)sa[jt][4 * g + e];
+          sv[e] = (bf16_t)dp[jt][4 * g + e];
         }
+        const int off = (lane & 31) * WA_TS + (8 * g + 4 * (lane >> 5)) * 2;     // [query lane&31][key 8g + 4·half …+3]
+        *reinterpret_cast<bf16x4*>(tp + off) = pv;
+        *reinterpret_cast<bf16x4*>(td + off) = sv;
       }
-    }
-    f32x16 dv, dk;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { dv[e] = 0.f; dk[e] = 0.f; }
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lg, it, t, lane), wa_accfrag(pa[it], t), dv, 0, 0, 0);   // dVᵀ = dOᵀ·P
-        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lq, it, t, lane), wa_accfrag(ds[it], t), dk, 0, 0, 0);   // dKᵀ = Qᵀ·dS
+        dv[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lg, it, t, lane), wa_trfrag_q(tp, t, lane), dv[jt], 0, 0, 0);
+        dk[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lq, it, t, lane), wa_trfrag_q(td, t, lane), dk[jt], 0, 0, 0);
       }
-    if (ok[jt]) {
+    }
+  }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+    if (ok[jt] && !(wa_dbg & 2)) {
       bf16_t* ob = dqkv + tokoff[jt] * (3 * (size_t)C) + u.h * a.hd;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         bf16x4 vk, vv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          vk[e] = (bf16_t)(dk[4 * g + e] * a.scale);
-          vv[e] = (bf16_t)dv[4 * g + e];
+          vk[e] = (bf16_t)(dk[jt][4 * g + e] * a.scale);
+          vv[e] = (bf16_t)dv[jt][4 * g + e];
         }
         *reinterpret_cast<bf16x4*>(ob + C + 8 * g + 4 * (lane >> 5)) = vk;
         *reinterpret_cast<bf16x4*>(ob + 2 * C + 8 * g + 4 * (lane >> 5)) = vv;
       }
     }
-  }
-  __syncthreads();
+  // (no barrier: one wave, LDS operations complete in order — a __syncthreads() here would also wait for the dQ/dK/dV stores)
+  __builtin_amdgcn_wave_barrier();
+  if (!(wa_dbg & 4) || dtab[0][lane] == 12345ull)
   for (int e = lane; e < ntab; e += 64)
-    dpos_part[(size_t)blockIdx.x * ntab + e] = (float)(long long)dtab[0][e] * inv_scale[0] + (float)(long long)dtab[1][e] * inv_scale[1];
+    dpos_part[(size_t)u.unit * ntab + e] = (float)(long long)dtab[0][e] * inv_scale[0] + (float)(long long)dtab[1][e] * inv_scale[1];
 }
 
 static bool wa_use_mfma(int dtype, int hd, int w) {
@@ -1105,6 +1135,7 @@ extern "C" int pfr_window_attn_bwd(const void* qkv, const float* pos, const void
   if (int rc = wa_check(B, H, W, heads, head_dim, window, shift)) return rc;
   WinAttn a{B, H, W, heads, head_dim, window, shift, scale};
   const dim3 grid((unsigned)(B * (H / window) * (W / window) * heads));
+  { static int once = 0; if (!once) { once = 1; int v = getenv("PFR_WA_DBG") ? atoi(getenv("PFR_WA_DBG")) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(wa_dbg), &v, sizeof(int)); } }
   if (wa_use_mfma(dtype, head_dim, window)) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
   else if (dtype == PFR_BF16) hipLaunchKernelGGL(window_attn_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
   else hipLaunchKernelGGL(window_attn_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, pos, (const float*)dout, (float*)dqkv, dpos_part, a);
