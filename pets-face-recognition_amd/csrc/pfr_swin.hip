@@ -718,7 +718,6 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
 // of the accumulator rows is (r&3) + 8(r>>2) + 4(lane>>5); the A operand (Vᵀ, Kᵀ, Qᵀ, dOᵀ) is read from a natural
 // [token][d] LDS tile with ds_read_b64_tr_b16 at exactly those rows, so the reduction index is permuted identically on
 // both sides.
-__constant__ int wa_dbg;
 #define WA_RS 80   // LDS row stride in bytes of a [64 tokens][32 d] bf16 tile (64 B + 16 B pad)
 
 __device__ __forceinline__ bf16x8 wa_rowfrag(const char* tile, int tok_tile, int ks, int lane) {
@@ -786,7 +785,7 @@ __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* 
   __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS];
   __shared__ int toff[64];
   const int lane = threadIdx.x;
-  const WaUnit u = wa_decode(a, (wa_dbg & 64) ? (int)blockIdx.x : wa_xcd_unit(blockIdx.x, gridDim.x));
+  const WaUnit u = wa_decode(a, wa_xcd_unit(blockIdx.x, gridDim.x));
   const int nt = a.w * a.w, C = a.heads * a.hd;
   const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
   toff[lane] = lane < nt ? (int)wa_token_off(a, u.b, u.gy, u.gx, lane) : ~(int)wa_token_off(a, u.b, u.gy, u.gx, 0);   // one wave: LDS operations complete in order
@@ -872,7 +871,8 @@ __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* 
 // across lanes, so the two 32x32 bf16 quarters go through a 2.3 KB LDS tile each ([query][key], written as 8-byte rows, read back with
 // the transposing ds_read_b64_tr_b16 into B-operand layout).  Nothing is recomputed (round 1 rebuilt S, P and dP in the second
 // orientation: +16 MFMAs, +64 exponentials and 64 scattered bias loads per window-head).  V is only ever a row-fragment operand and
-// is held in registers straight from global memory (no LDS tile): 24 KB of LDS per wave = 6 window-heads per CU.
+// is held in registers straight from global memory (no LDS tile); the bins are folded into per-lane float sums after each
+// query half: 20 KB of LDS per wave = 8 window-heads per CU (round 1: 25.6 KB, 6).
 #define WA_TS 72   // LDS row stride in bytes of a [32 queries][32 keys] bf16 quarter (64 B + 8 B pad: the 8-byte row writes of 32 lanes hit 32 distinct bank pairs)
 __device__ __forceinline__ bf16x8 wa_trfrag_q(const char* tile, int t, int lane) {
   // B operand [K = query][N = key] from the quarter tile; reduction slots e ↔ query 16·t + 8·(e>>2) + 4·half + (e&3) as in wa_trfrag
@@ -888,22 +888,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
                                                                   const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                                   float* __restrict__ dpos_part, WinAttn a) {
   __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lg[64 * WA_RS];
-  __shared__ __attribute__((aligned(16))) char tp[32 * WA_TS], td[32 * WA_TS];
+  __shared__ __attribute__((aligned(16))) char tp[32 * WA_TS];   // P quarter, then (same bytes, LDS operations are in order) the dS quarter
   // Position-table gradient bins are accumulated as 64-bit INTEGERS: on gfx950 a wave64 `ds_add_f32` costs 190 (idle) … 950
   // (loaded CU) cycles, `ds_add_u64` 14 … 46 (tools/probe/lds_atomic_probe.hip) — the float scatter was 70 % of this kernel's
   // LDS-array time.  Block floating point: each query half scales its dS values by the power of two that puts the largest
   // magnitude at 2^30 (values more than 2^-30 below the largest are truncated — finer than fp32 accumulation), so the
   // sums are order-independent AND exactly homogeneous (doubling dO doubles every bin bit for bit, tests/test_fullsize_gpu.py).
-  __shared__ unsigned long long dtab[2][256];
+  __shared__ unsigned long long dtab[256];   // 20 KB of LDS per wave in total: 8 window-heads per CU
   __shared__ __attribute__((aligned(16))) int cj[64];
   __shared__ int toff[64];
   const int lane = threadIdx.x;
-  const WaUnit u = wa_decode(a, (wa_dbg & 64) ? (int)blockIdx.x : wa_xcd_unit(blockIdx.x, gridDim.x));
+  const WaUnit u = wa_decode(a, wa_xcd_unit(blockIdx.x, gridDim.x));
   const int nt = a.w * a.w, C = a.heads * a.hd, w = a.w;
   const int ntab = (2 * w - 1) * (2 * w - 1);
   const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
-  for (int e = lane; e < 256; e += 64) { dtab[0][e] = 0ull; dtab[1][e] = 0ull; }
-  float inv_scale[2] = {0.f, 0.f};
+  for (int e = lane; e < 256; e += 64) dtab[e] = 0ull;
+  float dacc[4] = {0.f, 0.f, 0.f, 0.f};   // this lane's bins (e = lane + 64·k) over both query halves
   cj[lane] = lane < nt ? (lane / w) * (2 * w - 1) + lane % w : -(1 << 20);
   toff[lane] = lane < nt ? (int)wa_token_off(a, u.b, u.gy, u.gx, lane) : ~(int)wa_token_off(a, u.b, u.gy, u.gx, 0);   // one wave: LDS operations complete in order
   __builtin_amdgcn_wave_barrier();
@@ -930,7 +930,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
   wa_load_tile(lk, qb + C, toff, 3 * (size_t)C, lane);
   wa_load_tile(lg, dout + u.h * a.hd, toff, (size_t)C, lane);
   __syncthreads();
-  if (wa_dbg & 16) { if (lq[lane*7] == 77 && lk[lane] == 3 && lg[lane] == 5) dpos_part[0] = 1.f; return; }
 
   f32x16 dv[2], dk[2];   // dVᵀ / dKᵀ [d][key], accumulated over both query halves
 #pragma unroll
@@ -957,8 +956,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-        if (!(wa_dbg & 8)) bb = *reinterpret_cast<const f32x4*>(btab + i * WA_MAXT + 32 * jt + 8 * g + 4 * (lane >> 5));
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(btab + i * WA_MAXT + 32 * jt + 8 * g + 4 * (lane >> 5));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = fmaf(sa[jt][4 * g + e], a.scale, bb[e]);
@@ -1008,8 +1006,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
     const int kexp = (ex == 0 || ex == 255) ? 0 : min(30 - (ex - 127), 120);
     const float sc = __uint_as_float((uint32_t)(kexp + 127) << 23);
-    if (it == 0) inv_scale[0] = __uint_as_float((uint32_t)(127 - kexp) << 23); else inv_scale[1] = __uint_as_float((uint32_t)(127 - kexp) << 23);
-    unsigned long long* dt = dtab[it];
+    const float inv_sc = __uint_as_float((uint32_t)(127 - kexp) << 23);
+    unsigned long long* dt = dtab;
     // padded rows / columns have dS == 0 exactly: they add 0 to a spare bin behind the table instead of branching around the atomic
     const int dump = ntab + (lane & 15);
 #pragma unroll
@@ -1022,9 +1020,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
         for (int e = 0; e < 4; ++e) {
           const int idx = base_i + cc[e];
           const int xi32 = (int)(dp[jt][4 * g + e] * sc);                    // exact product (power of two), truncated toward zero
-          if (!(wa_dbg & 1)) atomicAdd(&dt[idx >= 0 ? idx : dump], (unsigned long long)(long long)xi32);
+          atomicAdd(&dt[min((unsigned)idx, (unsigned)dump)], (unsigned long long)(long long)xi32);   // negative index → huge unsigned → spare bin
         }
       }
+    // fold this half's bins into the lane's float sums and clear them for the next half (its scale differs)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dacc[q] = fmaf((float)(long long)dtab[lane + 64 * q], inv_sc, dacc[q]);
+      dtab[lane + 64 * q] = 0ull;
+    }
     f32x16 dq;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[e] = 0.f;
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lk, jt, t, lane), wa_accfrag(dp[jt], t), dq, 0, 0, 0);
-    if (ok[it] && !(wa_dbg & 2)) {
+    if (ok[it]) {
       bf16_t* ob = dqkv + tokoff[it] * (3 * (size_t)C) + u.h * a.hd;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1048,26 +1052,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16x4 pv, sv;
+        bf16x4 pv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pv[e] = (bf16_t)sa[jt][4 * g + e];
-          sv[e] = (bf16_t)dp[jt][4 * g + e];
-        }
-        const int off = (lane & 31) * WA_TS + (8 * g + 4 * (lane >> 5)) * 2;     // [query lane&31][key 8g + 4·half …+3]
-        *reinterpret_cast<bf16x4*>(tp + off) = pv;
-        *reinterpret_cast<bf16x4*>(td + off) = sv;
+        for (int e = 0; e < 4; ++e) pv[e] = (bf16_t)sa[jt][4 * g + e];
+        *reinterpret_cast<bf16x4*>(tp + (lane & 31) * WA_TS + (8 * g + 4 * (lane >> 5)) * 2) = pv;     // [query lane&31][key 8g + 4·half …+3]
+      }
+      bf16x8 pb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) pb[t] = wa_trfrag_q(tp, t, lane);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 sv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[e] = (bf16_t)dp[jt][4 * g + e];
+        *reinterpret_cast<bf16x4*>(tp + (lane & 31) * WA_TS + (8 * g + 4 * (lane >> 5)) * 2) = sv;
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        dv[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lg, it, t, lane), wa_trfrag_q(tp, t, lane), dv[jt], 0, 0, 0);
-        dk[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lq, it, t, lane), wa_trfrag_q(td, t, lane), dk[jt], 0, 0, 0);
+        dv[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lg, it, t, lane), pb[t], dv[jt], 0, 0, 0);
+        dk[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lq, it, t, lane), wa_trfrag_q(tp, t, lane), dk[jt], 0, 0, 0);
       }
     }
   }
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt)
-    if (ok[jt] && !(wa_dbg & 2)) {
+    if (ok[jt]) {
       bf16_t* ob = dqkv + tokoff[jt] * (3 * (size_t)C) + u.h * a.hd;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1081,11 +1090,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
         *reinterpret_cast<bf16x4*>(ob + 2 * C + 8 * g + 4 * (lane >> 5)) = vv;
       }
     }
-  // (no barrier: one wave, LDS operations complete in order — a __syncthreads() here would also wait for the dQ/dK/dV stores)
-  __builtin_amdgcn_wave_barrier();
-  if (!(wa_dbg & 4) || dtab[0][lane] == 12345ull)
-  for (int e = lane; e < ntab; e += 64)
-    dpos_part[(size_t)u.unit * ntab + e] = (float)(long long)dtab[0][e] * inv_scale[0] + (float)(long long)dtab[1][e] * inv_scale[1];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane + 64 * q < ntab) dpos_part[(size_t)u.unit * ntab + lane + 64 * q] = dacc[q];
 }
 
 static bool wa_use_mfma(int dtype, int hd, int w) {
@@ -1135,7 +1142,6 @@ extern "C" int pfr_window_attn_bwd(const void* qkv, const float* pos, const void
   if (int rc = wa_check(B, H, W, heads, head_dim, window, shift)) return rc;
   WinAttn a{B, H, W, heads, head_dim, window, shift, scale};
   const dim3 grid((unsigned)(B * (H / window) * (W / window) * heads));
-  { static int once = 0; if (!once) { once = 1; int v = getenv("PFR_WA_DBG") ? atoi(getenv("PFR_WA_DBG")) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(wa_dbg), &v, sizeof(int)); } }
   if (wa_use_mfma(dtype, head_dim, window)) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
   else if (dtype == PFR_BF16) hipLaunchKernelGGL(window_attn_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
   else hipLaunchKernelGGL(window_attn_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, pos, (const float*)dout, (float*)dqkv, dpos_part, a);
