@@ -169,6 +169,16 @@ int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x, const flo
 int pfr_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int dtype, int N,
                             int H, int W, int C, int relu, pfr_stream_t stream);
 int pfr_maxpool_bwd(const void* dy, const uint8_t* idx, void* dz, int dtype, int N, int H, int W, int C, pfr_stream_t stream);
+/* The stem tail backward without the [N,H,W,C] max-pool gradient tensor (reference: torch autograd of
+ * models/resnet.py maxpool(relu(bn1(conv1(x)))) — MaxPool2DWithIndicesBackward + ThresholdBackward + NativeBatchNormBackward):
+ * g = maxpool_bwd(dpool, idx) where scale*x + shift > 0, gathered from the pooled gradient inside the BatchNorm-backward reduce
+ * and apply passes.  part / coef exactly as pfr_bn_bwd_reduce / pfr_bn_bwd_apply (pfr_bn_bwd_finalize runs between the two);
+ * results are bit-identical to pfr_maxpool_bwd + pfr_bn_bwd_reduce(mask_mode 2) + pfr_bn_bwd_apply(mask_mode 2). */
+int pfr_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* invstd,
+                           const float* scale, const float* shift, int dtype, int N, int H, int W, int C, float* part,
+                           pfr_stream_t stream);
+int pfr_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const float* coef, const float* scale,
+                          const float* shift, void* dx, int dtype, int N, int H, int W, int C, pfr_stream_t stream);
 int pfr_avgpool_fwd(const void* x, void* y, int dtype, int N, int HW, int C, pfr_stream_t stream);
 int pfr_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int HW, int C, pfr_stream_t stream);
 

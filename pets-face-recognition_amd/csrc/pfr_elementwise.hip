@@ -22,6 +22,16 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   const size_t n = i / HW, pix = i % HW;
   T* dst = y + i * Cp;
   constexpr int KP = DT<T>::KPACK;
+  if (C == 3 && Cp == KP) {   // RGB frames: three unconditional plane loads in flight, one 16-byte store
+    const float* src = x + n * 3 * HW + pix;
+    const float r = src[0], g = src[HW], b = src[2 * (size_t)HW];
+    float v[KP];
+#pragma unroll
+    for (int e = 0; e < KP; ++e) v[e] = 0.f;
+    v[0] = r; v[1] = g; v[2] = b;
+    st16(dst, Chunk<T>::pack(v));
+    return;
+  }
   if (Cp % KP == 0) {   // 16-byte stores
     for (int c0 = 0; c0 < Cp; c0 += KP) {
       float v[KP];
@@ -1063,6 +1073,218 @@ extern "C" int pfr_maxpool_bwd(const void* dy, const uint8_t* idx, void* dz, int
     hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, idx, (bf16_t*)dz, N, H, W, C, OH, OW);
   else
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, idx, (float*)dz, N, H, W, C, OH, OW);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// ---- stem tail backward WITHOUT the max-pool gradient tensor: the gradient arriving at the stem BatchNorm is
+// g = maxpool_bwd(dpool, idx) ∘ [scale·x + shift > 0].  pfr_maxpool_bwd + pfr_bn_bwd_reduce + pfr_bn_bwd_apply write that
+// [N,H,W,C] tensor once and read it twice (1.2 GB at 256 x 112² x 64 bf16); the two kernels below gather it from the
+// quarter-size pooled gradient instead (the ≤ 4 covering windows of a pixel, all loads issued up front) and are otherwise the
+// reduce / apply kernels: same thread layout, same summation order, the gathered value rounded to T as the stored tensor
+// was — partial sums and dx are bit-identical to the three-launch path.
+template <typename T>
+struct PoolTaps {
+  u32x4 gv[4];
+  uint64_t pk[4];
+  int tap[4];
+  bool ok[4];
+};
+// (n, h, w) of a thread's rows are walked with carries (one division per thread, not per row)
+struct PixWalk {
+  int n, h, w, dn, dh, dw;
+  __device__ __forceinline__ void init(uint32_t r, uint32_t step, int H, int W) {
+    w = (int)(r % (uint32_t)W); const uint32_t q1 = r / (uint32_t)W; h = (int)(q1 % (uint32_t)H); n = (int)(q1 / (uint32_t)H);
+    dw = (int)(step % (uint32_t)W); const uint32_t q2 = step / (uint32_t)W; dh = (int)(q2 % (uint32_t)H); dn = (int)(q2 / (uint32_t)H);
+  }
+  __device__ __forceinline__ void advance(int H, int W) {
+    w += dw; h += dh; n += dn;
+    if (w >= W) { w -= W; ++h; }
+    if (h >= H) { h -= H; ++n; }
+  }
+};
+template <typename T>
+__device__ __forceinline__ void pool_issue(PoolTaps<T>& t, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const PixWalk& pw,
+                                           int cc, int cpr, int OH, int OW) {
+  constexpr int KP = DT<T>::KPACK;
+  const int n = pw.n, h = pw.h, w = pw.w;
+  const int oh0 = (h + 1) >> 1, r0 = h + 1 - 2 * oh0, ow0 = ((int)w + 1) >> 1, s0 = (int)w + 1 - 2 * ow0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int dh = q >> 1, dw = q & 1;
+    const int oh = oh0 - dh, ow = ow0 - dw;
+    const int rr = r0 + 2 * dh, sx = s0 + 2 * dw;
+    t.ok[q] = oh >= 0 && oh < OH && ow >= 0 && ow < OW && rr < 3 && sx < 3;
+    t.tap[q] = rr * 3 + sx;
+    const int ohc = min(max(oh, 0), OH - 1), owc = min(max(ow, 0), OW - 1);
+    const size_t o = (((size_t)n * OH + ohc) * OW + owc) * cpr + cc;
+    t.gv[q] = ld16(dpool + o * KP);
+    if constexpr (KP == 8) t.pk[q] = *reinterpret_cast<const uint64_t*>(idx + o * 8);
+    else t.pk[q] = *reinterpret_cast<const uint32_t*>(idx + o * 4);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void pool_sum(const PoolTaps<T>& t, float (&acc)[DT<T>::KPACK]) {
+  constexpr int KP = DT<T>::KPACK;
+#pragma unroll
+  for (int e = 0; e < KP; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float g[KP];
+    Chunk<T>::unpack(t.gv[q], g);
+#pragma unroll
+    for (int e = 0; e < KP; ++e)
+      if (t.ok[q] && (int)((t.pk[q] >> (8 * e)) & 0xff) == t.tap[q]) acc[e] += g[e];
+  }
+  Chunk<T>::unpack(Chunk<T>::pack(acc), acc);   // as pfr_maxpool_bwd stored it
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                 const T* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ part,
+                                                                 uint32_t rows, int C, int H, int W, int OH, int OW, int cw, int rl,
+                                                                 int cpr) {
+  constexpr int KP = DT<T>::KPACK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
+  const int cglob = blockIdx.y * cw + col;
+  float v[2][KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) { v[0][e] = 0.f; v[1][e] = 0.f; }
+  if (cglob < cpr) {
+    float mu[KP], is[KP], sc[KP], sh[KP];
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      mu[e] = mean[cglob * KP + e];
+      is[e] = invstd[cglob * KP + e];
+      sc[e] = scale[cglob * KP + e];
+      sh[e] = shift[cglob * KP + e];
+    }
+    auto body = [&](const PoolTaps<T>& t, u32x4 vx) {
+      float g[KP], xv[KP];
+      pool_sum<T>(t, g);
+      Chunk<T>::unpack(vx, xv);
+#pragma unroll
+      for (int e = 0; e < KP; ++e) {
+        const float gg = fmaf(xv[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+        v[0][e] += gg;
+        v[1][e] = fmaf(gg, (xv[e] - mu[e]) * is[e], v[1][e]);
+      }
+    };
+    const uint32_t step = gridDim.x * (uint32_t)rl;
+    uint32_t r = blockIdx.x * (uint32_t)rl + rlane;
+    PixWalk pw;
+    pw.init(r, step, H, W);
+    for (; r + step < rows; r += 2 * step) {   // two rows per thread in flight (nine loads each)
+      PoolTaps<T> t0, t1;
+      pool_issue<T>(t0, dpool, idx, pw, cglob, cpr, OH, OW);
+      pw.advance(H, W);
+      pool_issue<T>(t1, dpool, idx, pw, cglob, cpr, OH, OW);
+      pw.advance(H, W);
+      const u32x4 x0 = ld16_nt(x + (size_t)r * C + cglob * KP), x1 = ld16_nt(x + (size_t)(r + step) * C + cglob * KP);
+      body(t0, x0);
+      body(t1, x1);
+    }
+    for (; r < rows; r += step) {
+      PoolTaps<T> t0;
+      pool_issue<T>(t0, dpool, idx, pw, cglob, cpr, OH, OW);
+      pw.advance(H, W);
+      body(t0, ld16(x + (size_t)r * C + cglob * KP));
+    }
+  }
+  col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                const T* __restrict__ x, const float* __restrict__ coef,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                T* __restrict__ dx, uint32_t rows, int C, int H, int W, int OH, int OW,
+                                                                int cw, int rl, int cpr) {
+  constexpr int KP = DT<T>::KPACK;
+  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
+  const int cglob = blockIdx.y * cw + col;
+  if (cglob >= cpr) return;
+  float cg[KP], cx[KP], c0[KP], sc[KP], sh[KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) {
+    const int c = cglob * KP + e;
+    cg[e] = coef[c];
+    cx[e] = coef[C + c];
+    c0[e] = coef[2 * C + c];
+    sc[e] = scale[c];
+    sh[e] = shift[c];
+  }
+  auto body = [&](const PoolTaps<T>& t, u32x4 vx, size_t off) {
+    float g[KP], xv[KP];
+    pool_sum<T>(t, g);
+    Chunk<T>::unpack(vx, xv);
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      const float gg = fmaf(xv[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+      xv[e] = fmaf(cg[e], gg, fmaf(cx[e], xv[e], c0[e]));
+    }
+    st16(dx + off, Chunk<T>::pack(xv));
+  };
+  const uint32_t step = gridDim.x * (uint32_t)rl;
+  uint32_t r = blockIdx.x * (uint32_t)rl + rlane;
+  PixWalk pw;
+  pw.init(r, step, H, W);
+  for (; r + step < rows; r += 2 * step) {
+    PoolTaps<T> t0, t1;
+    pool_issue<T>(t0, dpool, idx, pw, cglob, cpr, OH, OW);
+    pw.advance(H, W);
+    pool_issue<T>(t1, dpool, idx, pw, cglob, cpr, OH, OW);
+    pw.advance(H, W);
+    const size_t o0 = (size_t)r * C + cglob * KP, o1 = (size_t)(r + step) * C + cglob * KP;
+    const u32x4 x0 = ld16_nt(x + o0), x1 = ld16_nt(x + o1);
+    body(t0, x0, o0);
+    body(t1, x1, o1);
+  }
+  for (; r < rows; r += step) {
+    PoolTaps<T> t0;
+    pool_issue<T>(t0, dpool, idx, pw, cglob, cpr, OH, OW);
+    pw.advance(H, W);
+    const size_t o0 = (size_t)r * C + cglob * KP;
+    body(t0, ld16(x + o0), o0);
+  }
+}
+
+// dpool [N,OH,OW,C] (OH = (H+2-3)/2+1 …: the 3x3 / stride 2 / pad 1 pooling of pfr_bn_relu_maxpool_fwd), idx its argmax taps,
+// x [N,H,W,C] the raw stem convolution output; part: pfr_colreduce_blocks(C, dtype, N·H·W) x [2][C] as pfr_bn_bwd_reduce
+extern "C" int pfr_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* invstd,
+                                      const float* scale, const float* shift, int dtype, int N, int H, int W, int C, float* part,
+                                      hipStream_t st) {
+  PFR_CHECK_ARG(dpool && idx && x && mean && invstd && scale && shift && part, "pfr_bn_bwd_reduce_pool: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_reduce_pool: C %% %d != 0", kp);
+  const size_t rows = (size_t)N * H * W;
+  PFR_CHECK_ARG(rows > 0 && rows < (1ull << 31), "pfr_bn_bwd_reduce_pool: N*H*W out of range");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  ColGeom g = col_geom(C, kp, rows);
+  const size_t shb = (size_t)256 * 2 * kp * sizeof(float);
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), shb, st, (const bf16_t*)dpool, idx, (const bf16_t*)x, mean, invstd, scale, shift, part, (uint32_t)rows, C, H, W, OH, OW, g.cw, g.rl, g.cpr);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<float>, dim3(g.gx, g.gy), dim3(256), shb, st, (const float*)dpool, idx, (const float*)x, mean, invstd, scale, shift, part, (uint32_t)rows, C, H, W, OH, OW, g.cw, g.rl, g.cpr);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+extern "C" int pfr_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const float* coef, const float* scale,
+                                     const float* shift, void* dx, int dtype, int N, int H, int W, int C, hipStream_t st) {
+  PFR_CHECK_ARG(dpool && idx && x && coef && scale && shift && dx, "pfr_bn_bwd_apply_pool: null pointer");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_apply_pool: C %% %d != 0", kp);
+  const size_t rows = (size_t)N * H * W;
+  PFR_CHECK_ARG(rows > 0 && rows < (1ull << 31), "pfr_bn_bwd_apply_pool: N*H*W out of range");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  ColGeom g = col_geom(C, kp, rows, 512);
+  if (dtype == PFR_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)dpool, idx, (const bf16_t*)x, coef, scale, shift, (bf16_t*)dx, (uint32_t)rows, C, H, W, OH, OW, g.cw, g.rl, g.cpr);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, (const float*)dpool, idx, (const float*)x, coef, scale, shift, (float*)dx, (uint32_t)rows, C, H, W, OH, OW, g.cw, g.rl, g.cpr);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

@@ -139,6 +139,9 @@ class FEEngine:
         # kernels are bound by their vector-memory path into LDS, not by HBM, so the extra x reads and the registers of the sums
         # lengthen them (3.5 -> 7.4 ms) by more than the HBM-speed reduce kernels (2.1 ms at 4.5 TB/s) cost.  DESIGN.md §6.
         self.fuse_bnb = os.environ.get("PFR_FUSE_BNB", "0") == "1"
+        # stem tail backward without the max-pool gradient tensor (-1.1 GB of HBM traffic per step at bs 256): measured neutral
+        # (0.57 vs 0.62 ms; the gather is vector-ALU bound), bit-identical, opt-in like PFR_FUSE_BNB
+        self.fuse_pool = os.environ.get("PFR_FUSE_POOL", "0") == "1"
         self.grad_ready_hook = None     # callable(lo, hi): flat-grad range [lo, hi) is final (DDP bucket hook)
         self.hook_syncs_side = False    # True: the hook makes ITS stream wait for self.side (the main stream then never waits at a mark)
         self.bucket_elems = 6 * 1024 * 1024
@@ -784,9 +787,26 @@ class FEEngine:
         # stem
         c1, s1, idx, pshape = saved["stem"]
         dz = G(s1)
-        ops.append((lib.pfr_maxpool_bwd, (dcur.data_ptr(), idx.data_ptr(), dz.data_ptr(), self.did, N, s1[1], s1[2], s1[3])))
-        release(dcur)
-        bn_bwd(dz, None, c1, s1, stbn, 2, dz, None, acc)
+        if self.fuse_pool:
+            # the max-pool gradient is gathered from the pooled gradient inside the BN-backward passes (never materialised)
+            rows1 = s1[0] * s1[1] * s1[2]
+            nb = lib.pfr_colreduce_blocks(s1[3], self.did, rows1)
+            part = G((nb, 2, s1[3]), torch.float32)
+            ops.append((lib.pfr_bn_bwd_reduce_pool, (dcur.data_ptr(), idx.data_ptr(), c1.data_ptr(), stbn.coef[0].data_ptr(),
+                                                     stbn.coef[1].data_ptr(), stbn.coef[2].data_ptr(), stbn.coef[3].data_ptr(),
+                                                     self.did, N, s1[1], s1[2], s1[3], part.data_ptr())))
+            ops.append((lib.pfr_bn_bwd_finalize, (part.data_ptr(), nb, s1[3], float(rows1), stbn.gamma.data_ptr(), stbn.coef[0].data_ptr(),
+                                                  stbn.coef[1].data_ptr(), stbn.dgamma.data_ptr(), stbn.dbeta.data_ptr(),
+                                                  stbn.bcoef.data_ptr(), acc)))
+            ops.append((lib.pfr_bn_bwd_apply_pool, (dcur.data_ptr(), idx.data_ptr(), c1.data_ptr(), stbn.bcoef.data_ptr(),
+                                                    stbn.coef[2].data_ptr(), stbn.coef[3].data_ptr(), dz.data_ptr(), self.did,
+                                                    N, s1[1], s1[2], s1[3])))
+            release(part)
+            release(dcur)
+        else:
+            ops.append((lib.pfr_maxpool_bwd, (dcur.data_ptr(), idx.data_ptr(), dz.data_ptr(), self.did, N, s1[1], s1[2], s1[3])))
+            release(dcur)
+            bn_bwd(dz, None, c1, s1, stbn, 2, dz, None, acc)
         if use_s2d:
             wgrad(x_nhwc, xin_shape, dz, s1, self.s2d, out=self.s2d.g)
             ops.append(("wait", (nside[0] - 1,)))   # the un-packing below reads what the stem wgrad wrote

@@ -454,3 +454,47 @@ def test_weight_dgrad_layout_batch_ragged_layers(dtype):
     torch.cuda.synchronize()
     for w, t in zip(ws, wts):
         assert torch.equal(t, w.flip(1, 2).permute(3, 1, 2, 0).contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 18, 18, 64), (2, 17, 21, 16), (5, 112, 112, 64)])
+def test_stem_pool_bn_backward_fused_equals_three_launches(dtype, shape):
+    """pfr_bn_bwd_reduce_pool / pfr_bn_bwd_apply_pool gather the max-pool gradient on the fly: partial sums and dx must be
+    bit-identical to pfr_maxpool_bwd + pfr_bn_bwd_reduce(mask 2) + pfr_bn_bwd_apply(mask 2)"""
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    N, H, W, C = shape
+    did = dtype_id(dtype)
+    g = torch.Generator().manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(N, H, W, C, generator=g).to(DEV, dtype)
+    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    mean = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    invstd = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(N, OH, OW, C, device=DEV, dtype=dtype)
+    idx = torch.empty(N, OH, OW, C, device=DEV, dtype=torch.uint8)
+    lib.pfr_bn_relu_maxpool_fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), idx.data_ptr(), did, N, H, W, C, 1, st)
+    dpool = torch.randn(N, OH, OW, C, generator=g).to(DEV, dtype)
+    rows = N * H * W
+    nb = lib.pfr_colreduce_blocks(C, did, rows)
+    # three launches
+    dz = torch.empty_like(x)
+    lib.pfr_maxpool_bwd(dpool.data_ptr(), idx.data_ptr(), dz.data_ptr(), did, N, H, W, C, st)
+    part_a = torch.zeros(nb, 2, C, device=DEV)
+    lib.pfr_bn_bwd_reduce(dz.data_ptr(), 0, x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), 2, did,
+                          rows, C, part_a.data_ptr(), st)
+    coef = torch.randn(3, C, generator=g).to(DEV).contiguous()
+    dx_a = torch.empty_like(x)
+    lib.pfr_bn_bwd_apply(dz.data_ptr(), 0, x.data_ptr(), coef.data_ptr(), scale.data_ptr(), shift.data_ptr(), 2, dx_a.data_ptr(), 0, did, rows, C, st)
+    # fused
+    part_b = torch.zeros(nb, 2, C, device=DEV)
+    lib.pfr_bn_bwd_reduce_pool(dpool.data_ptr(), idx.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                               shift.data_ptr(), did, N, H, W, C, part_b.data_ptr(), st)
+    dx_b = torch.empty_like(x)
+    lib.pfr_bn_bwd_apply_pool(dpool.data_ptr(), idx.data_ptr(), x.data_ptr(), coef.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                              dx_b.data_ptr(), did, N, H, W, C, st)
+    torch.cuda.synchronize()
+    assert torch.equal(part_a, part_b)
+    assert torch.equal(dx_a, dx_b)
+    assert dz.abs().sum() > 0
