@@ -69,14 +69,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const T* __restrict
                                                              float* __restrict__ mean, float* __restrict__ rstd, long rows,
                                                              int C, float eps, int G, int cpr) {
   constexpr int KP = DT<T>::KPACK;
+  // rows in flight per lane group: the row loop is a chain of memory round trips (load → statistics → store), so a lane keeps
+  // the chunks of several rows in flight at once (unconditional loads from clamped addresses) — 31.7 → ? µs at 100 352 x 192
+  constexpr int RB = CPL <= 1 ? 4 : 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G, rpw = 64 / G;
   float gm[CPL][KP], bt[CPL][KP];
   bool okc[CPL];
+  int cch[CPL];
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
     const int c = sub + G * k;
     okc[k] = c < cpr;
+    cch[k] = okc[k] ? c : 0;
 #pragma unroll
     for (int e = 0; e < KP; ++e) {
       gm[k][e] = okc[k] ? gamma[c * KP + e] : 0.f;
@@ -85,41 +90,53 @@ __global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const T* __restrict
   }
   const float invC = 1.f / (float)C;
   const long stride = (long)gridDim.x * 4 * rpw;
-  for (long row = ((long)blockIdx.x * 4 + wave) * rpw + grp; row < rows; row += stride) {
-    float f[CPL][KP];
-    float s = 0.f;
+  for (long row0 = ((long)blockIdx.x * 4 + wave) * rpw + grp; row0 < rows; row0 += RB * stride) {
+    u32x4 raw[RB][CPL];
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      if (okc[k]) Chunk<T>::unpack(ld16(x + row * C + (sub + G * k) * KP), f[k]);
+    for (int b = 0; b < RB; ++b) {
+      const long row = row0 + b * stride < rows ? row0 + b * stride : row0;
 #pragma unroll
-      for (int e = 0; e < KP; ++e) {
-        if (!okc[k]) f[k][e] = 0.f;
-        s += f[k][e];
-      }
-    }
-    for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o, 64);
-    const float mu = s * invC;
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k)
-#pragma unroll
-      for (int e = 0; e < KP; ++e) {
-        const float d = okc[k] ? f[k][e] - mu : 0.f;
-        v = fmaf(d, d, v);
-      }
-    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
-    const float rs = rsqrtf(v * invC + eps);
-    if (sub == 0) {
-      if (mean) mean[row] = mu;
-      if (rstd) rstd[row] = rs;
+      for (int k = 0; k < CPL; ++k) raw[b][k] = ld16(x + row * C + cch[k] * KP);
     }
 #pragma unroll
-    for (int k = 0; k < CPL; ++k)
-      if (okc[k]) {
+    for (int b = 0; b < RB; ++b) {
+      const long row = row0 + b * stride;
+      if (row >= rows) break;
+      float f[CPL][KP];
+      float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < KP; ++e) f[k][e] = fmaf((f[k][e] - mu) * rs, gm[k][e], bt[k][e]);
-        st16(y + row * C + (sub + G * k) * KP, Chunk<T>::pack(f[k]));
+      for (int k = 0; k < CPL; ++k) {
+        Chunk<T>::unpack(raw[b][k], f[k]);
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          if (!okc[k]) f[k][e] = 0.f;
+          s += f[k][e];
+        }
       }
+      for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o, 64);
+      const float mu = s * invC;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k)
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          const float d = okc[k] ? f[k][e] - mu : 0.f;
+          v = fmaf(d, d, v);
+        }
+      for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+      const float rs = rsqrtf(v * invC + eps);
+      if (sub == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+      }
+#pragma unroll
+      for (int k = 0; k < CPL; ++k)
+        if (okc[k]) {
+#pragma unroll
+          for (int e = 0; e < KP; ++e) f[k][e] = fmaf((f[k][e] - mu) * rs, gm[k][e], bt[k][e]);
+          st16(y + row * C + (sub + G * k) * KP, Chunk<T>::pack(f[k]));
+        }
+    }
   }
 }
 

@@ -498,3 +498,20 @@ def test_stem_pool_bn_backward_fused_equals_three_launches(dtype, shape):
     assert torch.equal(part_a, part_b)
     assert torch.equal(dx_a, dx_b)
     assert dz.abs().sum() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(5, 3, 7, 9, 8), (4, 3, 6, 6, 4), (96, 3, 4, 4, 8), (7, 20, 2, 2, 24), (3, 5, 3, 3, 7), (2, 16, 5, 5, 16)])
+def test_nchw_to_nhwc_channel_padding(dtype, shape):
+    """fp32 NCHW → compute-dtype NHWC with the channel dimension zero-padded to Cp (16-byte-store and scalar paths)"""
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    N, C, H, W, Cp = shape
+    if dtype == torch.float32 and Cp == 8 and C == 3:
+        Cp = 4
+    x = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(5)).to(DEV)
+    y = torch.full((N, H, W, Cp), float("nan"), device=DEV, dtype=dtype)
+    lib.pfr_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), dtype_id(dtype), N, C, H, W, Cp, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = torch.zeros(N, H, W, Cp, device=DEV, dtype=dtype)
+    ref[..., :C] = x.permute(0, 2, 3, 1).to(dtype)
+    assert torch.equal(y, ref)
