@@ -40,7 +40,7 @@ extern "C" void pfr_debug_igemm_flags(int f) { g_igemm_dbg = f; }
 #define PFR_IGEMM_NST 2
 #endif
 
-template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_, bool FILT = false, bool BNB = false>
+template <typename T, typename TO, int BQ, int BP, bool PRO, bool FAST, int KCH_, int NW, int WP, int NST_, bool FILT = false, bool BNB = false, bool EPRE = false>
 __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && sizeof(T) == 2 && sizeof(TO) == 2 && !PRO) ? (BNB ? 2 : PFR_IGEMM_OCC4) : 1) void igemm_kernel(IgemmParams p) {
   constexpr int KP = DT<T>::KPACK;
   constexpr int KCH = KCH_;                    // 16-byte chunks per LDS row per k-step (4: 64-B rows, 8: 128-B rows)
@@ -421,15 +421,50 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       bsh[e] = need ? p.bnb_coef[0][3 * p.Cout + co + e] : 0.f;
     }
   }
+  // EPRE instantiation (launches whose epilogue reads operand rows back: the residual + its ReLU bit mask of the data-gradient
+  // join, the accumulate target, the GELU pre-activation): those rows are PREFETCHED four at a time with unconditional loads from
+  // clamped addresses — inside the per-row control flow every such load is followed by a full vmcnt(0) wait, one memory round trip
+  // per row (8-16 per tile).  A separate instantiation because the 32 extra VGPRs cost the plain launches occupancy.
+  constexpr int ITERS = (BQ + RPP - 1) / RPP;
+  constexpr int GRP = EPRE ? (ITERS < 4 ? ITERS : 4) : 1;
+  const bool all_vec = (p.Cout % KPO == 0) && ((p.ldy * (int)sizeof(TO)) % 16 == 0);
+  // second stream: the accumulate target OR the GELU pre-activation (both at once keeps the per-row loads)
+  const bool pre = EPRE && all_vec && (p.residual || p.accumulate || p.act == 3) && !(p.accumulate && p.act == 3);
+  const int cc = co < p.Cout ? co : 0;
 #pragma unroll 4
-  for (int rr = rl; rr < BQ; rr += RPP) {
+  for (int base = 0; base < ITERS; base += GRP) {
+  int ms[GRP];
+  bool okr[GRP];
+  u32x4 pr[GRP], pb[GRP];
+  unsigned pmk[GRP];
+#pragma unroll
+  for (int i = 0; i < GRP; ++i) {
+    const int rr = rl + (base + i) * RPP;
     int m = m0 + rr;
-    if (m >= mlim || co >= p.Cout) continue;
+    okr[i] = rr < BQ && m < mlim && co < p.Cout;
+    if (!okr[i]) m = m0;
     if (p.pclass) {
       uint32_t n_img, oh, ow;
       decode(m, n_img, oh, ow);
       m = (int)((n_img * p.OH + oh) * p.OW + ow);
     }
+    ms[i] = m;
+    if constexpr (EPRE) {
+      if (pre) {
+        const size_t eo = ((size_t)m * p.ldy + cc) * sizeof(TO);
+        if (p.residual) {
+          pr[i] = ld16(reinterpret_cast<const char*>(p.residual) + eo);
+          if (p.res_mask) pmk[i] = p.res_mask[(size_t)m * (p.ldy / KPO) + cc / KPO];
+        }
+        if (p.accumulate || p.act == 3) pb[i] = ld16((p.accumulate ? yb : reinterpret_cast<const char*>(p.y2)) + eo);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GRP; ++i) {
+    if (!okr[i]) continue;
+    const int rr = rl + (base + i) * RPP;
+    const int m = ms[i];
     u32x4 v = *reinterpret_cast<const u32x4*>(smem + rr * OROWB + oc * 16);
     float f[KPO];
     Chunk<TO>::unpack(v, f);
@@ -439,14 +474,16 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       if (p.residual) {
         float g[KPO];
         const char* rsrc = reinterpret_cast<const char*>(p.residual) + ((size_t)m * p.ldy + co) * sizeof(TO);
-        if (vec_ok) {
+        if (pre) {
+          Chunk<TO>::unpack(pr[i], g);
+        } else if (vec_ok) {
           Chunk<TO>::unpack(ld16(rsrc), g);
         } else {
 #pragma unroll
           for (int e = 0; e < KPO; ++e) g[e] = (co + e < p.Cout) ? to_f32(reinterpret_cast<const TO*>(rsrc)[e]) : 0.f;
         }
         if (p.res_mask) {   // residual-branch gradient join: only where the block's ReLU was active
-          const unsigned bits = p.res_mask[(size_t)m * (p.ldy / KPO) + co / KPO];
+          const unsigned bits = pre ? pmk[i] : (unsigned)p.res_mask[(size_t)m * (p.ldy / KPO) + co / KPO];
 #pragma unroll
           for (int e = 0; e < KPO; ++e) g[e] = (bits >> e) & 1u ? g[e] : 0.f;
         }
@@ -455,7 +492,9 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       }
       if (p.accumulate) {
         float g[KPO];
-        if (vec_ok) {
+        if (pre) {
+          Chunk<TO>::unpack(pb[i], g);
+        } else if (vec_ok) {
           Chunk<TO>::unpack(ld16(dst), g);
         } else {
 #pragma unroll
@@ -478,7 +517,7 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
         v = Chunk<TO>::pack(f);
       } else if (p.act == 3) {  // GELU backward fused into the data-gradient GEMM: dz = dh ∘ gelu'(z)
         float z[KPO];
-        Chunk<TO>::unpack(ld16(reinterpret_cast<const char*>(p.y2) + ((size_t)m * p.ldy + co) * sizeof(TO)), z);
+        Chunk<TO>::unpack(pre ? pb[i] : ld16(reinterpret_cast<const char*>(p.y2) + ((size_t)m * p.ldy + co) * sizeof(TO)), z);
 #pragma unroll
         for (int e = 0; e < KPO; ++e) {
           float cdf, pdf;
@@ -523,6 +562,7 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       for (int e = 0; e < KPO; ++e)
         if (co + e < p.Cout) reinterpret_cast<TO*>(dst)[e] = from_f32<TO>(f[e]);
     }
+  }
   }
   TSTAMP(5);
   if (p.stats_part) {
@@ -617,6 +657,16 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
       if (p.bnb_part[0]) {
         if (!fast || p.pclass) { pfr_set_error("conv2d: BN-backward sums need the k-step-uniform, non-parity-class path"); return PFR_ERR_UNSUPPORTED; }
         hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true, KCH, NW, WP, NST, false, true>), grid, block, 0, st, p);
+        PFR_CHECK_LAUNCH();
+        return PFR_OK;
+      }
+    }
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+      static const bool epre_on = !(getenv("PFR_IGEMM_EPRE") && getenv("PFR_IGEMM_EPRE")[0] == '0');
+      // (measured: −10 % on the data-gradient joins of ResNet-50 = +0.5 % on the step; the GELU-backward GEMMs of Swin-T gain 4 % in
+      // isolation but the step does not, and a plain forward residual add is 3 % SLOWER with it — both keep the plain kernel)
+      if (fast && epre_on && (p.res_mask || p.accumulate) && p.act != 3 && p.Cout % 8 == 0 && p.ldy % 8 == 0) {
+        hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true, KCH, NW, WP, NST, false, false, true>), grid, block, 0, st, p);
         PFR_CHECK_LAUNCH();
         return PFR_OK;
       }
