@@ -227,6 +227,14 @@ int pfr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
 int pfr_layernorm_bwd_blocks(long rows); /* part is fp32 [2][blocks][C]: dgamma partial rows, then dbeta partial rows (sum each half with pfr_colsum) */
 int pfr_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                       const void* dres, void* dx, float* part, int dtype, long rows, int C, pfr_stream_t stream);
+/* the same pass that also leaves the per-workgroup column sums of dx (dxsum_part [pfr_layernorm_bwd_blocks(rows)][C], may be NULL):
+ * torch autograd computes the bias gradient of the nn.Linear / patch-merging layer in front of the LayerNorm as a separate
+ * reduction over that gradient (models/swin.py:157-190 blocks, 84-99 PatchMerging); pfr_layernorm_bwd_dxsum_ok(dtype, C) = 1 when
+ * the channel count takes the kernel that can do it */
+int pfr_layernorm_bwd_dxsum(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                            const void* dres, void* dx, float* part, float* dxsum_part, int dtype, long rows, int C,
+                            pfr_stream_t stream);
+int pfr_layernorm_bwd_dxsum_ok(int dtype, int C);
 int pfr_gelu_fwd(const void* x, void* y, int dtype, size_t n, pfr_stream_t stream);
 int pfr_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, size_t n, pfr_stream_t stream);
 /* bias(+mask) table of one attention block: tab fp32 [4][64][64] (-inf outside w*w x w*w); variant 2*(last window row)+(last window

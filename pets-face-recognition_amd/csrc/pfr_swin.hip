@@ -248,13 +248,13 @@ template <typename T, int CPL>
 __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, const T* __restrict__ dres,
-                                                             T* __restrict__ dx, float* __restrict__ part, long rows, int C,
-                                                             int G, int cpr) {
+                                                             T* __restrict__ dx, float* __restrict__ part, float* __restrict__ dxsum, long rows,
+                                                             int C, int G, int cpr) {
   constexpr int KP = DT<T>::KPACK;
-  extern __shared__ float sh[];  // [4 waves][2][C]
+  extern __shared__ float sh[];  // [4 waves][3][C]   (third row set: column sums of the stored dx, optional)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G, rpw = 64 / G;
-  float gm[CPL][KP], ag[CPL][KP], ab[CPL][KP];
+  float gm[CPL][KP], ag[CPL][KP], ab[CPL][KP], ad[CPL][KP];
   bool okc[CPL];
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
       gm[k][e] = okc[k] ? gamma[c * KP + e] : 0.f;
       ag[k][e] = 0.f;
       ab[k][e] = 0.f;
+      ad[k][e] = 0.f;
     }
   }
   const float invC = 1.f / (float)C;
@@ -309,7 +310,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
           ag[k][e] = fmaf(dv[k][e], xh[k][e], ag[k][e]);
           ab[k][e] += dv[k][e];
         }
-        st16(dx + off, Chunk<T>::pack(o));
+        const u32x4 po = Chunk<T>::pack(o);
+        st16(dx + off, po);
+        if (dxsum) {   // Σ rows of dx AS STORED: the bias gradient of the layer that produced this LayerNorm's input
+          Chunk<T>::unpack(po, o);
+#pragma unroll
+          for (int e = 0; e < KP; ++e) ad[k][e] += o[e];
+        }
       }
   }
   // lane groups of the wave own the same channels: fold them (xor offsets ≥ G), then the 4 waves through LDS
@@ -320,6 +327,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
       for (int o = G; o < 64; o <<= 1) {
         ag[k][e] += __shfl_xor(ag[k][e], o, 64);
         ab[k][e] += __shfl_xor(ab[k][e], o, 64);
+        if (dxsum) ad[k][e] += __shfl_xor(ad[k][e], o, 64);
       }
   if (grp == 0) {
 #pragma unroll
@@ -327,16 +335,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
       if (okc[k]) {
 #pragma unroll
         for (int e = 0; e < KP; ++e) {
-          sh[(wave * 2 + 0) * C + (sub + G * k) * KP + e] = ag[k][e];
-          sh[(wave * 2 + 1) * C + (sub + G * k) * KP + e] = ab[k][e];
+          sh[(wave * 3 + 0) * C + (sub + G * k) * KP + e] = ag[k][e];
+          sh[(wave * 3 + 1) * C + (sub + G * k) * KP + e] = ab[k][e];
+          sh[(wave * 3 + 2) * C + (sub + G * k) * KP + e] = ad[k][e];
         }
       }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+  for (int c = threadIdx.x; c < (dxsum ? 3 : 2) * C; c += 256) {
     const int q = c / C, cc = c % C;
-    const float v = sh[(0 * 2 + q) * C + cc] + sh[(1 * 2 + q) * C + cc] + sh[(2 * 2 + q) * C + cc] + sh[(3 * 2 + q) * C + cc];
-    part[((size_t)q * gridDim.x + blockIdx.x) * C + cc] = v;
+    const float v = sh[(0 * 3 + q) * C + cc] + sh[(1 * 3 + q) * C + cc] + sh[(2 * 3 + q) * C + cc] + sh[(3 * 3 + q) * C + cc];
+    if (q < 2) part[((size_t)q * gridDim.x + blockIdx.x) * C + cc] = v;
+    else dxsum[(size_t)blockIdx.x * C + cc] = v;
   }
 }
 
@@ -364,8 +374,17 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
   return PFR_ERR_UNSUPPORTED;
 }
 
-extern "C" int pfr_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                 const void* dres, void* dx, float* part, int dtype, long rows, int C, hipStream_t st) {
+// 1 when the chunked kernel (which can also emit the column sums of dx) takes this geometry
+extern "C" int pfr_layernorm_bwd_dxsum_ok(int dtype, int C) {
+  LnGeom g;
+  return ln_geom(C, dtype == PFR_BF16 ? 8 : 4, &g) ? 1 : 0;
+}
+
+// dxsum_part (optional, [pfr_layernorm_bwd_blocks(rows)][C]): per-workgroup column sums of dx as stored — the bias gradient of the
+// Linear (or patch-merging conv) whose output this LayerNorm normalises comes out of this pass instead of a second read of dx
+extern "C" int pfr_layernorm_bwd_dxsum(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                       const void* dres, void* dx, float* part, float* dxsum_part, int dtype, long rows, int C,
+                                       hipStream_t st) {
   PFR_CHECK_ARG(dy && x && mean && rstd && gamma && dx && part, "pfr_layernorm_bwd: null pointer");
   const int nb = pfr_layernorm_bwd_blocks(rows);
   const int rpb = (int)((rows + nb - 1) / nb);
@@ -373,9 +392,9 @@ extern "C" int pfr_layernorm_bwd(const void* dy, const void* x, const float* mea
     LnGeom g;
     const int kp = dtype == PFR_BF16 ? 8 : 4;
     if (ln_geom(C, kp, &g)) {
-      const size_t shb = (size_t)8 * C * sizeof(float);
+      const size_t shb = (size_t)12 * C * sizeof(float);
 #define PFR_LNB(TT, K)                                                                                                  \
-  if (g.cpl == K) hipLaunchKernelGGL((layernorm_bwd2_kernel<TT, K>), dim3(nb), dim3(256), shb, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, part, rows, C, g.G, g.cpr);
+  if (g.cpl == K) hipLaunchKernelGGL((layernorm_bwd2_kernel<TT, K>), dim3(nb), dim3(256), shb, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, part, dxsum_part, rows, C, g.G, g.cpr);
       if (dtype == PFR_BF16) { PFR_LNB(bf16_t, 1) PFR_LNB(bf16_t, 2) PFR_LNB(bf16_t, 3) PFR_LNB(bf16_t, 4) }
       else { PFR_LNB(float, 1) PFR_LNB(float, 2) PFR_LNB(float, 3) PFR_LNB(float, 4) }
 #undef PFR_LNB
@@ -383,11 +402,16 @@ extern "C" int pfr_layernorm_bwd(const void* dy, const void* x, const float* mea
       return PFR_OK;
     }
   }
+  PFR_CHECK_ARG(!dxsum_part, "pfr_layernorm_bwd_dxsum: this channel count takes the generic kernel (no dx column sums): see pfr_layernorm_bwd_dxsum_ok");
   int rc = dtype == PFR_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, part, rows, C, nb, rpb, st)
                              : ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, part, rows, C, nb, rpb, st);
   if (rc != PFR_OK) return rc;
   PFR_CHECK_LAUNCH();
   return PFR_OK;
+}
+extern "C" int pfr_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                 const void* dres, void* dx, float* part, int dtype, long rows, int C, hipStream_t st) {
+  return pfr_layernorm_bwd_dxsum(dy, x, mean, rstd, gamma, dres, dx, part, nullptr, dtype, rows, C, st);
 }
 
 // ------------------------------------------------------------------------------------------------ GELU (exact, erf)

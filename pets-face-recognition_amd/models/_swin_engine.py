@@ -54,6 +54,7 @@ class SwinEngine:
         # buffers per (shape, dtype) class of the backward pool before one that a side-stream op still reads is re-used (HBM is
         # plentiful; a shallow pool makes the main stream wait for the side stream at almost every layer)
         self.pool_depth = int(os.environ.get("PFR_POOL_DEPTH", "48"))
+        self.ln_dxsum = os.environ.get("PFR_LN_DXSUM", "1") == "1"   # bias gradients from the LayerNorm-backward pass that produced their input
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
         self.grad_ready_hook = None
         self._adopt(model)
@@ -371,15 +372,27 @@ class SwinEngine:
             for r in reads:
                 side_reads.append((k, r.data_ptr()))
 
-        def ln_bwd(ops, dy, xin, mu, rs, lnrec, dres, dx, rows, C):
+        def ln_bwd(ops, dy, xin, mu, rs, lnrec, dres, dx, rows, C, want_sum=False):
+            """→ (partials, rows of partials) of the column sums of dx when want_sum and the kernel can emit them, else None"""
             nb = lib.pfr_layernorm_bwd_blocks(rows)
             # the kernel's per-workgroup partials ARE the partial sets of the deferred final merge (own buffer per LayerNorm: they
             # must survive until the batched merge at the next bucket boundary)
             part = A((2, nb, C), torch.float32)
-            ops.append((lib.pfr_layernorm_bwd, (dy.data_ptr(), xin.data_ptr(), mu.data_ptr(), rs.data_ptr(), lnrec.gamma.data_ptr(),
-                                                0 if dres is None else dres.data_ptr(), dx.data_ptr(), part.data_ptr(), did, rows, C)))
+            dsum = A((nb, C), torch.float32) if (want_sum and self.ln_dxsum and lib.pfr_layernorm_bwd_dxsum_ok(did, C)) else None
+            ops.append((lib.pfr_layernorm_bwd_dxsum, (dy.data_ptr(), xin.data_ptr(), mu.data_ptr(), rs.data_ptr(), lnrec.gamma.data_ptr(),
+                                                      0 if dres is None else dres.data_ptr(), dx.data_ptr(), part.data_ptr(),
+                                                      0 if dsum is None else dsum.data_ptr(), did, rows, C)))
             pend_cs.append((part[0], lnrec.dgamma, nb, C, 0, 0))
             pend_cs.append((part[1], lnrec.dbeta, nb, C, 0, 0))
+            return None if dsum is None else (dsum, nb)
+
+        def bias_grad(ops, g, rows, C, dbias, gsum):
+            """bias gradient = column sum of g: from the LayerNorm-backward pass that produced g when it left the sums (gsum), else
+            a column-sum pass of its own on the side stream"""
+            if gsum is not None:
+                pend_cs.append((gsum[0], dbias, gsum[1], C, 0, 0))
+            else:
+                colsum(ops, g, rows, C, dbias)
 
         demb = A((N, self.emb_dim))
         plan["demb"] = demb
@@ -391,6 +404,7 @@ class SwinEngine:
         dgrad_lin(bwd, demb, N, hf, dhln)
         dpooled = G((N, Cf))
         ln_bwd(bwd, dhln, pooled, hmu, hrs, self.head_ln, None, dpooled, N, Cf)
+        dz_sum = None   # column sums of dz left by the pass that produced it (None: avgpool / patch-merging data gradient)
         release(dhln)
         dz = G(cshape)
         bwd.append((lib.pfr_avgpool_bwd, (dpooled.data_ptr(), dz.data_ptr(), did, N, Hh * Ww, Cf)))
@@ -402,7 +416,7 @@ class SwinEngine:
             rows = N * OH * OW
             for b, sv in zip(reversed(st["blocks"]), reversed(srec["blocks"])):
                 # ---- MLP branch: z = fc2(gelu(fc1(ln2(y)))) + y
-                colsum(bwd, dz.view(rows, C), rows, C, b["fc2"].dbias)
+                bias_grad(bwd, dz.view(rows, C), rows, C, b["fc2"].dbias, dz_sum)
                 wgrad(bwd, sv["h2"], (rows, 1, 1, 4 * C), dz, (rows, 1, 1, C), b["fc2"], 1, 1, b["fc2"].g)
                 dh2 = G((rows, 4 * C))
                 if self.fuse_gelu:   # dh1 = (dz·W2) ∘ gelu'(h1) in the data-gradient GEMM's epilogue
@@ -423,11 +437,11 @@ class SwinEngine:
                 dgrad_lin(bwd, dh2, rows, b["fc1"], dln2)
                 release(dh2)
                 dy = G((rows, C))
-                ln_bwd(bwd, dln2, sv["y"], sv["mu2"], sv["rs2"], b["ln2"], dz, dy, rows, C)
+                dy_sum = ln_bwd(bwd, dln2, sv["y"], sv["mu2"], sv["rs2"], b["ln2"], dz, dy, rows, C, want_sum=True)
                 release(dln2)
                 release(dz)
                 # ---- attention branch: y = to_out(attn(to_qkv(ln1(x)))) + x
-                colsum(bwd, dy, rows, C, b["out"].dbias)
+                bias_grad(bwd, dy, rows, C, b["out"].dbias, dy_sum)
                 wgrad(bwd, sv["att"], (rows, 1, 1, C), dy, (rows, 1, 1, C), b["out"], 1, 1, b["out"].g)
                 datt = G((rows, C))
                 dgrad_lin(bwd, dy, rows, b["out"], datt)
@@ -446,7 +460,7 @@ class SwinEngine:
                 dgrad_lin(bwd, dqkv, rows, b["qkv"], dln1)
                 release(dqkv)
                 dx = G((rows, C))
-                ln_bwd(bwd, dln1, sv["x"], sv["mu1"], sv["rs1"], b["ln1"], dy, dx, rows, C)
+                dz_sum = ln_bwd(bwd, dln1, sv["x"], sv["mu1"], sv["rs1"], b["ln1"], dy, dx, rows, C, want_sum=True)
                 release(dln1)
                 release(dy)
                 dz = dx
@@ -454,7 +468,7 @@ class SwinEngine:
             pm, f = st["pm"], st["f"]
             Ni, Hi, Wi, Ci = srec["inshape"]
             if pm.dbias is not None:
-                colsum(bwd, dz, rows, C, pm.dbias)
+                bias_grad(bwd, dz, rows, C, pm.dbias, dz_sum)
             g_conv = pm.g_conv
             wgrad(bwd, srec["in"], (Ni, Hi, Wi, Ci), dz, (N, OH, OW, C), pm, f, f, g_conv)
             side(bwd, ("side", (lib.pfr_nhwc_to_nchw_f32, (g_conv.data_ptr(), pm.g.data_ptr(), pm.out, pm.cin, f * f, pm.cinp, 0))))
@@ -464,6 +478,7 @@ class SwinEngine:
                                                  f - 1, {2: 1, 4: 2}[f], Hi, Wi, Ci, 0, 0, 0, 0, 0, 0, 0, 0)))
                 release(dz)
                 dz = din
+            dz_sum = None
             flush_colsums(bwd)
             if nside[0]:   # everything the side stream was given so far is final (end of backward, or a DDP bucket boundary)
                 bwd.append(("wait" if si == 0 else "mwait", (nside[0] - 1,)))
