@@ -486,6 +486,14 @@ struct WinAttn {
 // bias(+mask) table of one attention block: tab[variant][i][j], variant = 2*(last window row) + (last window column),
 // rows padded to WA_MAXT = 64 with −inf outside the w² x w² block (one tiny launch per block and step instead of integer
 // divisions per score element in every workgroup).
+// second copy in the MFMA kernels' ACCESS order: a wave reads, for one query half `it`, key tile jt and row group g, the four
+// biases of keys 32jt + 8g + 4·half … +3 for query 32it + (lane&31) — in [var][it][jt][g][half][query][4] order those 64 16-byte
+// pieces are 1 KB contiguous (one coalesced request stream instead of 32 rows 256 bytes apart: the bias reads were the largest
+// consumer of the texture-address unit in both attention kernels)
+__device__ __forceinline__ size_t wa_perm_index(int var, int i, int j) {
+  const int it = i >> 5, il = i & 31, jt = j >> 5, jl = j & 31;
+  return ((((((size_t)var * 2 + it) * 2 + jt) * 4 + (jl >> 3)) * 2 + ((jl >> 2) & 1)) * 32 + il) * 4 + (jl & 3);
+}
 __global__ void window_bias_table_kernel(const float* __restrict__ pos, float* __restrict__ tab, int w, int shift) {
   const int nt = w * w;
   constexpr int ntp = WA_MAXT;
@@ -502,6 +510,7 @@ __global__ void window_bias_table_kernel(const float* __restrict__ pos, float* _
     }
   }
   tab[e] = b;
+  tab[4 * ntp * ntp + wa_perm_index(var, i, j)] = b;
 }
 
 __device__ __forceinline__ size_t wa_token_off(const WinAttn& a, int b, int gy, int gx, int t) {
@@ -821,58 +830,82 @@ __device__ __forceinline__ void wa_load_tile(char* tile, const bf16_t* base, con
   }
 }
 
+// Output rows through LDS: an accumulator holds 4 consecutive d of one token per lane (8-byte pieces, four store instructions per
+// 64-byte head row, 32 separate rows each); staged as [token][d] (stride WA_TS) the wave stores 16 bytes per lane with the four
+// lanes of a quad on one row.  `tile`: which 32-token half; rows with a negative table entry (padding) are not stored.
+#define WA_TS 72   // LDS row stride in bytes of a [32 tokens][32 x bf16] staging / quarter tile (64 B + 8 B pad)
+__device__ __forceinline__ void wa_store_tile(char* stage, const f32x16& acc, float mul, bf16_t* dst, const int* toff, int tile,
+                                              size_t rowstride, int lane) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[4 * g + e] * mul);
+    *reinterpret_cast<bf16x4*>(stage + (lane & 31) * WA_TS + (8 * g + 4 * (lane >> 5)) * 2) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (lane >> 2) + 16 * p;
+    const int tk = toff[32 * tile + row];
+    const char* src = stage + row * WA_TS + (lane & 3) * 16;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 8);
+    if (tk >= 0) st16(dst + (size_t)tk * rowstride + (lane & 3) * 8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ tab,
                                                                   bf16_t* __restrict__ out, WinAttn a) {
-  __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS];
+  __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS], lo[32 * WA_TS];
   __shared__ int toff[64];
   const int lane = threadIdx.x;
   const WaUnit u = wa_decode(a, wa_xcd_unit(blockIdx.x, gridDim.x));
   const int nt = a.w * a.w, C = a.heads * a.hd;
-  const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
+  const float* ptab = tab + (size_t)(4 + u.var) * WA_MAXT * WA_MAXT + (lane >> 5) * 128 + (lane & 31) * 4;   // access-order copy
   toff[lane] = lane < nt ? (int)wa_token_off(a, u.b, u.gy, u.gx, lane) : ~(int)wa_token_off(a, u.b, u.gy, u.gx, 0);   // one wave: LDS operations complete in order
   __builtin_amdgcn_wave_barrier();
-  size_t tokoff[2];
-  bool ok[2];
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int tk = toff[(lane & 31) + 32 * tt];
-    ok[tt] = tk >= 0;
-    tokoff[tt] = (size_t)(ok[tt] ? tk : ~tk);       // padding rows point at a valid row (loads are unconditional, stores are not)
-  }
   const bf16_t* qb = qkv + u.h * a.hd;
   wa_load_tile(lq, qb, toff, 3 * (size_t)C, lane);
   wa_load_tile(lk, qb + C, toff, 3 * (size_t)C, lane);
+  // the bias rows of the first query half are requested with the tiles (those of the second half while the first is computed):
+  // behind the barrier they were a second, fully exposed round trip per half (33 of 128 µs at 128 x 56² x 3 heads); they come from
+  // the access-order copy of the table (wa_perm_index): 1 KB contiguous per instruction
+  f32x4 bbv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bbv[q] = *reinterpret_cast<const f32x4*>(ptab + q * 256);
   wa_load_tile(lv, qb + 2 * C, toff, 3 * (size_t)C, lane);
   __syncthreads();
-  // Sᵀ[j][i] = K·Qᵀ
-  f32x16 sacc[2][2];   // [jt][it]
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    // Sᵀ[j][i] = K·Qᵀ for this query half
+    f32x16 sacc[2];
+    f32x16 oacc;
 #pragma unroll
-  for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[jt][it][e] = 0.f;
+      for (int e = 0; e < 16; ++e) sacc[jt][e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        sacc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lk, jt, ks, lane), wa_rowfrag(lq, it, ks, lane), sacc[jt][it], 0, 0, 0);
+        sacc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_rowfrag(lk, jt, ks, lane), wa_rowfrag(lq, it, ks, lane), sacc[jt], 0, 0, 0);
     }
-  f32x16 oacc[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int i = (lane & 31) + 32 * it;
     float mx = -INFINITY;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(btab + i * WA_MAXT + 32 * jt + 8 * g + 4 * (lane >> 5));
+        const f32x4 bb = bbv[4 * jt + g];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(sacc[jt][it][4 * g + e], a.scale, bb[e]);
-          sacc[jt][it][4 * g + e] = v;
+          const float v = fmaf(sacc[jt][4 * g + e], a.scale, bb[e]);
+          sacc[jt][4 * g + e] = v;
           mx = fmaxf(mx, v);
         }
       }
+    if (it == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bbv[q] = *reinterpret_cast<const f32x4*>(ptab + (8 + q) * 256);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (mx == -INFINITY) mx = 0.f;   // padded query row: every score is −inf
     float sum = 0.f;
@@ -880,30 +913,21 @@ __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* 
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = __expf(sacc[jt][it][e] - mx);
-        sacc[jt][it][e] = pv;
+        const float pv = __expf(sacc[jt][e] - mx);
+        sacc[jt][e] = pv;
         sum += pv;
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[it][e] = 0.f;
+    for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
     // Oᵀ[d][i] = Σ_j Vᵀ[d][j]·Pᵀ[j][i]   (normalised afterwards: one multiply per output instead of per probability)
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        oacc[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lv, jt, t, lane), wa_accfrag(sacc[jt][it], t), oacc[it], 0, 0, 0);
-    if (ok[it]) {
-      bf16_t* ob = out + tokoff[it] * C + u.h * a.hd;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(oacc[it][4 * g + e] * inv);
-        *reinterpret_cast<bf16x4*>(ob + 8 * g + 4 * (lane >> 5)) = v;
-      }
-    }
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lv, jt, t, lane), wa_accfrag(sacc[jt], t), oacc, 0, 0, 0);
+    wa_store_tile(lo, oacc, inv, out + u.h * a.hd, toff, it, (size_t)C, lane);
   }
 }
 
@@ -914,7 +938,6 @@ __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* 
 // orientation: +16 MFMAs, +64 exponentials and 64 scattered bias loads per window-head).  V is only ever a row-fragment operand and
 // is held in registers straight from global memory (no LDS tile); the bins are folded into per-lane float sums after each
 // query half: 20 KB of LDS per wave = 8 window-heads per CU (round 1: 25.6 KB, 6).
-#define WA_TS 72   // LDS row stride in bytes of a [32 queries][32 keys] bf16 quarter (64 B + 8 B pad: the 8-byte row writes of 32 lanes hit 32 distinct bank pairs)
 __device__ __forceinline__ bf16x8 wa_trfrag_q(const char* tile, int t, int lane) {
   // B operand [K = query][N = key] from the quarter tile; reduction slots e ↔ query 16·t + 8·(e>>2) + 4·half + (e&3) as in wa_trfrag
   const int g = lane >> 4, s4 = lane & 15;
@@ -942,7 +965,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
   const WaUnit u = wa_decode(a, wa_xcd_unit(blockIdx.x, gridDim.x));
   const int nt = a.w * a.w, C = a.heads * a.hd, w = a.w;
   const int ntab = (2 * w - 1) * (2 * w - 1);
-  const float* btab = tab + (size_t)u.var * WA_MAXT * WA_MAXT;
+  const float* ptab = tab + (size_t)(4 + u.var) * WA_MAXT * WA_MAXT + (lane >> 5) * 128 + (lane & 31) * 4;   // access-order copy
   for (int e = lane; e < 256; e += 64) dtab[e] = 0ull;
   float dacc[4] = {0.f, 0.f, 0.f, 0.f};   // this lane's bins (e = lane + 64·k) over both query halves
   cj[lane] = lane < nt ? (lane / w) * (2 * w - 1) + lane % w : -(1 << 20);
@@ -997,7 +1020,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(btab + i * WA_MAXT + 32 * jt + 8 * g + 4 * (lane >> 5));
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(ptab + (8 * it + 4 * jt + g) * 256);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = fmaf(sa[jt][4 * g + e], a.scale, bb[e]);
@@ -1078,16 +1101,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_trfrag(lk, jt, t, lane), wa_accfrag(dp[jt], t), dq, 0, 0, 0);
-    if (ok[it]) {
-      bf16_t* ob = dqkv + tokoff[it] * (3 * (size_t)C) + u.h * a.hd;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(dq[4 * g + e] * a.scale);
-        *reinterpret_cast<bf16x4*>(ob + 8 * g + 4 * (lane >> 5)) = v;
-      }
-    }
+    wa_store_tile(tp, dq, a.scale, dqkv + u.h * a.hd, toff, it, 3 * (size_t)C, lane);
     // dVᵀ[d][j] += Σ_i dOᵀ[d][i]·P[i][j],  dKᵀ[d][j] += Σ_i Qᵀ[d][i]·dS[i][j]   (i over this query half), one key quarter at a time
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
@@ -1116,21 +1130,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
     }
   }
 #pragma unroll
-  for (int jt = 0; jt < 2; ++jt)
-    if (ok[jt]) {
-      bf16_t* ob = dqkv + tokoff[jt] * (3 * (size_t)C) + u.h * a.hd;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 vk, vv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vk[e] = (bf16_t)(dk[jt][4 * g + e] * a.scale);
-          vv[e] = (bf16_t)dv[jt][4 * g + e];
-        }
-        *reinterpret_cast<bf16x4*>(ob + C + 8 * g + 4 * (lane >> 5)) = vk;
-        *reinterpret_cast<bf16x4*>(ob + 2 * C + 8 * g + 4 * (lane >> 5)) = vv;
-      }
-    }
+  for (int jt = 0; jt < 2; ++jt) {
+    wa_store_tile(tp, dk[jt], a.scale, dqkv + C + u.h * a.hd, toff, jt, 3 * (size_t)C, lane);
+    wa_store_tile(tp, dv[jt], 1.f, dqkv + 2 * C + u.h * a.hd, toff, jt, 3 * (size_t)C, lane);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     if (lane + 64 * q < ntab) dpos_part[(size_t)u.unit * ntab + lane + 64 * q] = dacc[q];
@@ -1149,12 +1152,12 @@ static int wa_check(int B, int H, int W, int heads, int hd, int w, int shift) {
 
 extern "C" long pfr_window_bias_table_floats(int window) {
   (void)window;
-  return 4L * WA_MAXT * WA_MAXT;
+  return 8L * WA_MAXT * WA_MAXT;   // natural [4][64][64] + the MFMA kernels' access-order copy
 }
-// tab: fp32 [4][64][64], recomputed whenever pos changes (once per block and step)
+// tab: fp32 [4][64][64] (+ the permuted copy), recomputed whenever pos changes (once per block and step)
 extern "C" int pfr_window_bias_table(const float* pos, float* tab, int window, int shift, hipStream_t st) {
   PFR_CHECK_ARG(pos && tab && window * window <= WA_MAXT, "pfr_window_bias_table: bad args");
-  const long n = pfr_window_bias_table_floats(window);
+  const long n = 4L * WA_MAXT * WA_MAXT;
   hipLaunchKernelGGL(window_bias_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pos, tab, window, shift);
   PFR_CHECK_LAUNCH();
   return PFR_OK;

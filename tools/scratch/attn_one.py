@@ -22,4 +22,9 @@ e0.record()
 for _ in range(10):
     lib.pfr_window_attn_bwd(qkv.data_ptr(), tab.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), dpart.data_ptr(), 1, B, H, W, heads, hd, w, shift, hd ** -0.5, st)
 e1.record(); torch.cuda.synchronize()
-print("attn bwd us", e0.elapsed_time(e1) * 100, "units", nblk)
+print("attn", "bwd us", e0.elapsed_time(e1) * 100, "units", nblk)
+e0.record()
+for _ in range(10):
+    lib.pfr_window_attn_fwd(qkv.data_ptr(), tab.data_ptr(), out.data_ptr(), 1, B, H, W, heads, hd, w, shift, hd ** -0.5, st)
+e1.record(); torch.cuda.synchronize()
+print("attn fwd us", e0.elapsed_time(e1) * 100)
