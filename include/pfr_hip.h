@@ -237,8 +237,9 @@ int pfr_layernorm_bwd_dxsum(const void* dy, const void* x, const float* mean, co
 int pfr_layernorm_bwd_dxsum_ok(int dtype, int C);
 int pfr_gelu_fwd(const void* x, void* y, int dtype, size_t n, pfr_stream_t stream);
 int pfr_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, size_t n, pfr_stream_t stream);
-/* bias(+mask) table of one attention block: tab fp32 [4][64][64] (-inf outside w*w x w*w); variant 2*(last window row)+(last window
- * column); built from the (2w-1)x(2w-1) relative-position table `pos` (models/swin.py:65-70,93-95,117-118) and the shifted-window
+/* bias(+mask) table of one attention block: tab fp32 [4][64][64] (-inf outside w*w x w*w) followed by a second copy of the same
+ * values in the MFMA kernels' access order (pfr_window_bias_table_floats = both; always allocate that many floats and pass the
+ * buffer whole to pfr_window_attn_fwd / _bwd); variant 2*(last window row)+(last window column); built from the (2w-1)x(2w-1) relative-position table `pos` (models/swin.py:65-70,93-95,117-118) and the shifted-window
  * masks (create_mask, models/swin.py:49-62,86-90,122-124); rebuild whenever pos changed */
 long pfr_window_bias_table_floats(int window);
 int pfr_window_bias_table(const float* pos, float* tab, int window, int shift, pfr_stream_t stream);
