@@ -200,3 +200,38 @@ def test_gemm_with_fused_gelu_epilogues(dtype):
     pr = pre.clone().requires_grad_(True)
     F.gelu(pr).backward(dy @ w)
     assert rel(out, pr.grad) < t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(300, 96), (4099, 192), (257, 768)])
+def test_layernorm_bwd_dxsum_partials(dtype, rows, C):
+    """pfr_layernorm_bwd_dxsum: dx and the dγ/dβ partials are those of pfr_layernorm_bwd, and the extra partial rows sum to the
+    column sums of dx as stored (the bias gradient of the layer in front of the LayerNorm)"""
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    dev = "cuda:0"
+    did = dtype_id(dtype)
+    if not lib.pfr_layernorm_bwd_dxsum_ok(did, C):
+        pytest.skip("generic LayerNorm kernel for this channel count")
+    g = torch.Generator().manual_seed(2)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(rows, C, generator=g).to(dev, dtype)
+    dy = torch.randn(rows, C, generator=g).to(dev, dtype)
+    dres = torch.randn(rows, C, generator=g).to(dev, dtype)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = torch.zeros(C, device=dev)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
+    lib.pfr_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), did, rows, C, 1e-5, st)
+    nb = lib.pfr_layernorm_bwd_blocks(rows)
+    dx_a = torch.empty_like(x); part_a = torch.zeros(2, nb, C, device=dev)
+    lib.pfr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dres.data_ptr(), dx_a.data_ptr(),
+                          part_a.data_ptr(), did, rows, C, st)
+    dx_b = torch.empty_like(x); part_b = torch.zeros(2, nb, C, device=dev); dsum = torch.full((nb, C), float("nan"), device=dev)
+    lib.pfr_layernorm_bwd_dxsum(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dres.data_ptr(),
+                                dx_b.data_ptr(), part_b.data_ptr(), dsum.data_ptr(), did, rows, C, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_b) and torch.equal(part_a, part_b)
+    ref = dx_b.double().sum(0)
+    got = dsum.double().sum(0)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-4 * float(dx_b.float().abs().max()) * rows ** 0.5)
