@@ -576,13 +576,16 @@ extern "C" int pfr_bn_act_mask(const void* x1, const float* a1, const float* b1,
 
 // ---- backward reduce: g = dout * mask ; partials of Σ g and Σ g·x̂  (x̂ = (x − mean)·invstd)
 // mask_mode 0: none; 1: out > 0 (materialised post-activation tensor); 2: scale·x + shift > 0 (recomputed)
-template <typename T>
+// MASK is a template parameter: with a run-time mode the optional loads (`if (mode == 3) bits = …`) sit in branches and hipcc drains
+// the memory queue (vmcnt(0)) behind the first row of every four-row batch — two round trips per batch instead of one
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            int mask_mode, float* __restrict__ part, size_t rows, int C,
+                                                            float* __restrict__ part, size_t rows, int C,
                                                             int cw, int rl, int cpr) {
+  constexpr int mask_mode = MASK;
   constexpr int KP = DT<T>::KPACK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
@@ -628,6 +631,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         if (mask_mode == 1) vo[u] = ld16(out + off);
         if (mask_mode == 3) bits[u] = mk[(r + u * step) * cpr + cglob];
       }
+      __builtin_amdgcn_sched_barrier(0);   // all loads of the batch are issued before any of them is consumed
 #pragma unroll
       for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u], bits[u]);
     }
@@ -651,10 +655,12 @@ extern "C" int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* 
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_reduce: C %% %d != 0", kp);
   ColGeom g = col_geom(C, kp, (size_t)rows);
   const size_t shb = (size_t)256 * 2 * kp * sizeof(float);
-  if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), shb, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, mean, invstd, scale, shift, mask_mode, part, (size_t)rows, C, g.cw, g.rl, g.cpr);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.gx, g.gy), dim3(256), shb, st, (const float*)dout, (const float*)out, (const float*)x, mean, invstd, scale, shift, mask_mode, part, (size_t)rows, C, g.cw, g.rl, g.cpr);
+#define PFR_BNR(TT, M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, M>), dim3(g.gx, g.gy), dim3(256), shb, st, (const TT*)dout, (const TT*)out, (const TT*)x, mean, invstd, scale, shift, part, (size_t)rows, C, g.cw, g.rl, g.cpr)
+#define PFR_BNR4(TT) do { switch (mask_mode) { case 0: PFR_BNR(TT, 0); break; case 1: PFR_BNR(TT, 1); break; case 2: PFR_BNR(TT, 2); break; default: PFR_BNR(TT, 3); } } while (0)
+  PFR_CHECK_ARG(mask_mode >= 0 && mask_mode <= 3, "pfr_bn_bwd_reduce: bad mask_mode");
+  if (dtype == PFR_BF16) PFR_BNR4(bf16_t); else PFR_BNR4(float);
+#undef PFR_BNR4
+#undef PFR_BNR
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
@@ -719,12 +725,13 @@ extern "C" int pfr_bn_bwd_finalize(const float* part, int nparts, int C, float c
 }
 
 // ---- backward apply: g = dout·mask ; dx = cg·g + cx·x + c0 ; optional gres = g  (gradient of the residual input)
-template <typename T>
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                            const T* __restrict__ x, const float* __restrict__ coef,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           int mask_mode, T* __restrict__ dx, T* __restrict__ gres,
+                                                           T* __restrict__ dx, T* __restrict__ gres,
                                                            size_t rows, int C, int cw, int rl, int cpr) {
+  constexpr int mask_mode = MASK;   // (compile time: see bn_bwd_reduce_kernel)
   constexpr int KP = DT<T>::KPACK;
   const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
   const int cglob = blockIdx.y * cw + col;
@@ -770,6 +777,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       if (mask_mode == 1) vo[u] = ld16(out + off);
       if (mask_mode == 3) bits[u] = mk[(r + u * step) * cpr + cglob];
     }
+    __builtin_amdgcn_sched_barrier(0);   // all loads of the batch are issued before any of them is consumed
 #pragma unroll
     for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u], bits[u], (r + u * step) * C + cglob * KP);
   }
@@ -785,23 +793,21 @@ extern "C" int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x
                                 const float* shift, int mask_mode, void* dx, void* gres, int dtype, long rows, int C,
                                 hipStream_t st) {
   PFR_CHECK_ARG(dout && x && coef && dx, "pfr_bn_bwd_apply: null pointer");
+  PFR_CHECK_ARG(mask_mode >= 0 && mask_mode <= 3, "pfr_bn_bwd_apply: bad mask_mode");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_apply: C %% %d != 0", kp);
   ColGeom g = col_geom(C, kp, (size_t)rows, 512);
   hipEvent_t stop = pfr_tls_stop_event;
   pfr_tls_stop_event = nullptr;
-  if (stop) {
-    if (dtype == PFR_BF16)
-      hipExtLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, nullptr, stop, 0, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, coef, scale, shift, mask_mode, (bf16_t*)dx, (bf16_t*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
-    else
-      hipExtLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, nullptr, stop, 0, (const float*)dout, (const float*)out, (const float*)x, coef, scale, shift, mask_mode, (float*)dx, (float*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
-    PFR_CHECK_LAUNCH();
-    return PFR_OK;
-  }
-  if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, coef, scale, shift, mask_mode, (bf16_t*)dx, (bf16_t*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, coef, scale, shift, mask_mode, (float*)dx, (float*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr);
+#define PFR_BNA(TT, M)                                                                                                                        \
+  do {                                                                                                                                        \
+    if (stop) hipExtLaunchKernelGGL((bn_bwd_apply_kernel<TT, M>), dim3(g.gx, g.gy), dim3(256), 0, st, nullptr, stop, 0, (const TT*)dout, (const TT*)out, (const TT*)x, coef, scale, shift, (TT*)dx, (TT*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr); \
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, M>), dim3(g.gx, g.gy), dim3(256), 0, st, (const TT*)dout, (const TT*)out, (const TT*)x, coef, scale, shift, (TT*)dx, (TT*)gres, (size_t)rows, C, g.cw, g.rl, g.cpr); \
+  } while (0)
+#define PFR_BNA4(TT) do { switch (mask_mode) { case 0: PFR_BNA(TT, 0); break; case 1: PFR_BNA(TT, 1); break; case 2: PFR_BNA(TT, 2); break; default: PFR_BNA(TT, 3); } } while (0)
+  if (dtype == PFR_BF16) PFR_BNA4(bf16_t); else PFR_BNA4(float);
+#undef PFR_BNA4
+#undef PFR_BNA
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
