@@ -68,9 +68,20 @@ extern "C" int pfr_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C
 
 template <typename TI, typename TOo>
 __global__ void cast_kernel(const TI* __restrict__ x, TOo* __restrict__ y, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) y[i] = from_f32<TOo>(to_f32(x[i]));
+  size_t done = 0;
+  if constexpr (sizeof(TI) == 4 && sizeof(TOo) == 2) {   // fp32 master weights -> bf16 shadow: 8 values per thread, 2 x 16-byte loads, one 16-byte store
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+      const size_t n8 = n / 8;
+      for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+        float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        st16(y + 8 * i, Chunk<TOo>::pack(f));
+      }
+      done = 8 * n8;
+    }
+  }
+  for (size_t i = done + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = from_f32<TOo>(to_f32(x[i]));
 }
 
 extern "C" int pfr_cast(const void* x, int src_dtype, void* y, int dst_dtype, size_t n, hipStream_t st) {
@@ -1608,12 +1619,42 @@ extern "C" int pfr_colsum_final_batch(const void* descs, int n, int max_C, hipSt
 
 // ------------------------------------------------------------------------------------------------
 // optimiser steps over flat fp32 master buffers (+ compute-dtype shadow copy of the parameters)
+// four parameters per thread (16-byte loads of p / g / momentum issued together, one 8- or 16-byte shadow store): the scalar version
+// made three dependent 4-byte round trips per parameter
 template <typename TS>
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, TS* __restrict__ shadow,
                            size_t n, float lr, float momentum, float wd, float gscale, int first) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(mom) |
+                     reinterpret_cast<uintptr_t>(shadow)) & 15) == 0;
+  const size_t n4 = vec ? n / 4 : 0;
+  const bool use_mom = momentum != 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 w = reinterpret_cast<const f32x4*>(p)[i];
+    const f32x4 gr = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+    if (use_mom && !first) m = reinterpret_cast<const f32x4*>(mom)[i];
+    f32x4 b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = fmaf(wd, w[e], gr[e] * gscale);
+      b[e] = use_mom ? (first ? d : fmaf(momentum, m[e], d)) : d;
+      w[e] = fmaf(-lr, b[e], w[e]);
+    }
+    if (use_mom) reinterpret_cast<f32x4*>(mom)[i] = b;
+    reinterpret_cast<f32x4*>(p)[i] = w;
+    if (shadow) {
+      if constexpr (sizeof(TS) == 2) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)w[e];
+        *reinterpret_cast<bf16x4*>(shadow + 4 * i) = v;
+      } else {
+        reinterpret_cast<f32x4*>(shadow)[i] = w;
+      }
+    }
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float w = p[i];
     float d = fmaf(wd, w, g[i] * gscale);
     float b = d;
