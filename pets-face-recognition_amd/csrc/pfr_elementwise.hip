@@ -1436,6 +1436,14 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
   float a0 = 0.f, a1 = 0.f;
   if (c < C) {
     long r = r0 + rl;
+    for (; r + 28 < r1; r += 32) {   // eight rows per thread requested together
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = to_f32(x[(size_t)(r + 4 * k) * C + c]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) { a0 += v[k]; a1 += v[k + 1]; }
+    }
     for (; r + 4 < r1; r += 8) {
       a0 += to_f32(x[(size_t)r * C + c]);
       a1 += to_f32(x[(size_t)(r + 4) * C + c]);
