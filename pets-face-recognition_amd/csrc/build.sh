@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 ARCH=gfx950
-FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast"
+FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast ${PFR_EXTRA_FLAGS}"
 mkdir -p build
 pids=()
 python3 ../../tools/gen_thunks.py > /dev/null

@@ -631,12 +631,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     };
     const size_t step = (size_t)gridDim.x * rl;
     size_t r = (size_t)blockIdx.x * rl + rlane;
-    for (; r + 3 * step < rows; r += 4 * step) {   // four rows per thread in flight
-      u32x4 vg[4], vx[4], vo[4];
-      unsigned bits[4] = {0, 0, 0, 0};
+#ifndef PFR_BNR_ROWS
+#define PFR_BNR_ROWS 4
+#endif
+    constexpr int UB = PFR_BNR_ROWS;
+    for (; r + (UB - 1) * step < rows; r += UB * step) {   // UB rows per thread in flight
+      u32x4 vg[UB], vx[UB], vo[UB];
+      unsigned bits[UB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UB; ++u) {
         const size_t off = (r + u * step) * C + cglob * KP;
+        bits[u] = 0;
         vg[u] = ld16_nt(dout + off);
         vx[u] = ld16_nt(x + off);
         if (mask_mode == 1) vo[u] = ld16(out + off);
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       }
       __builtin_amdgcn_sched_barrier(0);   // all loads of the batch are issued before any of them is consumed
 #pragma unroll
-      for (int u = 0; u < 4; ++u) body(vg[u], vx[u], vo[u], bits[u]);
+      for (int u = 0; u < UB; ++u) body(vg[u], vx[u], vo[u], bits[u]);
     }
     for (; r < rows; r += step) {
       const size_t off = r * C + cglob * KP;
