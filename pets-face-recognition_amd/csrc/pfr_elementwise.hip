@@ -507,7 +507,8 @@ extern "C" int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, c
 
 // ---- apply: y = act( a1[c]*x1 + b1[c]  (+ a2[c]*x2 + b2[c]  |  + x2) )
 // thread = (channel chunk, row lane): the per-channel coefficients are loaded once into registers, rows are streamed.
-template <typename T>
+// HAS2 (second operand present) is a template parameter and the load batch ends with a scheduling barrier: see bn_bwd_reduce_kernel
+template <typename T, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, const float* __restrict__ a1,
                                                      const float* __restrict__ b1, const T* __restrict__ x2,
                                                      const float* __restrict__ a2, const float* __restrict__ b2,
@@ -529,12 +530,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, c
     const size_t off = row * C + cglob * KP;
     float f[KP], g[KP];
     Chunk<T>::unpack(v1, f);
-    if (x2) Chunk<T>::unpack(v2, g);
+    if constexpr (HAS2) Chunk<T>::unpack(v2, g);
     unsigned bits = 0;
 #pragma unroll
     for (int e = 0; e < KP; ++e) {
       float z = fmaf(f[e], A1[e], B1[e]);
-      if (x2) z += fmaf(g[e], A2[e], B2[e]);
+      if constexpr (HAS2) z += fmaf(g[e], A2[e], B2[e]);
       bits |= (z > 0.f ? 1u : 0u) << e;
       f[e] = relu ? fmaxf(z, 0.f) : z;
     }
@@ -550,15 +551,16 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, c
     for (int u = 0; u < 4; ++u) {
       const size_t off = (r + u * step) * C + cglob * KP;
       v1[u] = ld16_nt(x1 + off);   // the conv output is not needed again before the backward pass
-      if (x2) v2[u] = ld16_nt(x2 + off);
+      if constexpr (HAS2) v2[u] = ld16_nt(x2 + off);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) body(v1[u], v2[u], r + u * step);
   }
   for (; r < rows; r += step) {
     const size_t off = r * C + cglob * KP;
     u32x4 v2 = {};
-    if (x2) v2 = ld16(x2 + off);
+    if constexpr (HAS2) v2 = ld16(x2 + off);
     body(ld16(x1 + off), v2, r);
   }
 }
@@ -577,10 +579,10 @@ extern "C" int pfr_bn_act_mask(const void* x1, const float* a1, const float* b1,
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_act: C %% %d != 0", kp);
   ColGeom g = col_geom(C, kp, (size_t)rows, 512);   // pure streaming: many resident waves (no partial rows to merge)
-  if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)x1, a1, b1, (const bf16_t*)x2, a2, b2, (bf16_t*)y, mask, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
-  else
-    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, (const float*)x1, a1, b1, (const float*)x2, a2, b2, (float*)y, mask, (size_t)rows, C, g.cw, g.rl, g.cpr, relu);
+#define PFR_BNACT(TT, H2) hipLaunchKernelGGL((bn_act_kernel<TT, H2>), dim3(g.gx, g.gy), dim3(256), 0, st, (const TT*)x1, a1, b1, (const TT*)x2, a2, b2, (TT*)y, mask, (size_t)rows, C, g.cw, g.rl, g.cpr, relu)
+  if (dtype == PFR_BF16) { if (x2) PFR_BNACT(bf16_t, true); else PFR_BNACT(bf16_t, false); }
+  else { if (x2) PFR_BNACT(float, true); else PFR_BNACT(float, false); }
+#undef PFR_BNACT
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
