@@ -317,16 +317,22 @@ __device__ __forceinline__ void merge_parts(const float* __restrict__ part, cons
   float a = 0.f, n = 0.f;
   if (fast) {
     const int cc = c < C ? c : C - 1;
+    const float* cptr = counts ? counts : part;   // (any readable floats when there are no counts: multiplied by 0)
+    const float csel = counts ? 1.f : 0.f;
 #pragma unroll
     for (int k = 0; k < PFR_MERGE_K; ++k) {
       const int i = pbeg + pl + 16 * k;
-      const bool valid = c < C && i < pend;
       const int ic = i < pend ? i : pbeg;
       mu[k] = part[((size_t)ic * 2 + 0) * C + cc];
       q2[k] = part[((size_t)ic * 2 + 1) * C + cc];
-      nk[k] = counts ? counts[ic] : part_rows(total, rpp, ic);
-      if (!valid) { nk[k] = 0.f; q2[k] = 0.f; }
+      // row count of the part: from `counts` or computed.  Blended arithmetically (csel is 0 or 1) so that the load is always used:
+      // a select lets the compiler move the load back into a branch, and a load in a branch is followed by a full vmcnt(0) wait
+      nk[k] = fmaf(cptr[ic], csel, (1.f - csel) * part_rows(total, rpp, ic));
     }
+    __builtin_amdgcn_sched_barrier(0);   // (the compiler otherwise sinks each load to its first use: one round trip per part again)
+#pragma unroll
+    for (int k = 0; k < PFR_MERGE_K; ++k)
+      if (!(c < C && pbeg + pl + 16 * k < pend)) { nk[k] = 0.f; q2[k] = 0.f; }
 #pragma unroll
     for (int k = 0; k < PFR_MERGE_K; ++k)
       if (pbeg + pl + 16 * k < pend) {     // (same operations, in the same order, as the loop below)
