@@ -55,6 +55,9 @@ extern "C" int pfr_l2norm_fwd(const void* x, int in_dtype, void* xn, void* xnT, 
 
 // gallery / query preparation of the match: ONE pass over fp32 rows (float4 loads kept in registers) writes the normalised
 // row in bf16 (GEMM operand) AND in fp32 (exact re-scoring operand).  D % 4 == 0, D <= 2048.
+// NK = 16-byte-x4 chunks per lane (2 for D <= 512, 8 up to 2048): the loads are unconditional (clamped index, zeroed by a select) so
+// that they are all in flight together — a load in a branch is followed by a full wait, i.e. one memory round trip per chunk
+template <int NK>
 __global__ __launch_bounds__(256) void l2norm_dual_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb, float* __restrict__ xf,
                                                           float* __restrict__ inv_norm, int rows, int D, float eps) {
   const int lane = threadIdx.x & 63;
@@ -62,22 +65,22 @@ __global__ __launch_bounds__(256) void l2norm_dual_kernel(const float* __restric
   if (row >= rows) return;
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
   const int n4 = D >> 2;
-  f32x4 v[8];
+  f32x4 v[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) v[k] = xr[min(lane + 64 * k, n4 - 1)];
+  __builtin_amdgcn_sched_barrier(0);
   float ss = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = lane + 64 * k;
-    if (i < n4) {
-      v[k] = xr[i];
+  for (int k = 0; k < NK; ++k) {
+    if (lane + 64 * k >= n4) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ss = fmaf(v[k][e], v[k][e], ss);
-    }
+    for (int e = 0; e < 4; ++e) ss = fmaf(v[k][e], v[k][e], ss);
   }
   ss = wave_sum(ss);
   const float inv = 1.f / fmaxf(sqrtf(ss), eps);
   if (lane == 0 && inv_norm) inv_norm[row] = inv;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < NK; ++k) {
     const int i = lane + 64 * k;
     if (i < n4) {
       f32x4 o = v[k] * inv;
@@ -95,7 +98,8 @@ extern "C" int pfr_l2norm_dual(const float* x, void* xn_bf16, float* xn_f32, flo
                                hipStream_t st) {
   PFR_CHECK_ARG(x && (xn_bf16 || xn_f32) && rows > 0, "pfr_l2norm_dual: null pointer");
   PFR_CHECK_ARG(D % 4 == 0 && D <= 2048, "pfr_l2norm_dual: D must be a multiple of 4 and <= 2048");
-  hipLaunchKernelGGL(l2norm_dual_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, (bf16_t*)xn_bf16, xn_f32, inv_norm, rows, D, eps);
+  if (D <= 512) hipLaunchKernelGGL(l2norm_dual_kernel<2>, dim3((rows + 3) / 4), dim3(256), 0, st, x, (bf16_t*)xn_bf16, xn_f32, inv_norm, rows, D, eps);
+  else hipLaunchKernelGGL(l2norm_dual_kernel<8>, dim3((rows + 3) / 4), dim3(256), 0, st, x, (bf16_t*)xn_bf16, xn_f32, inv_norm, rows, D, eps);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }
