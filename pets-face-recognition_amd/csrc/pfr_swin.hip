@@ -274,12 +274,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
     const float mu = mean[row], rs = rstd[row];
     float xh[CPL][KP], dv[CPL][KP];
     float a = 0.f, b = 0.f;
+    u32x4 rx[CPL], rd[CPL], rr[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {     // all operands of the row requested together (clamped chunk for lanes beyond the row)
+      const size_t off = (size_t)row * C + (okc[k] ? sub + G * k : 0) * KP;
+      rx[k] = ld16_nt(x + off);   // last uses of the saved activation and of dy
+      rd[k] = ld16_nt(dy + off);
+      if (dres) rr[k] = ld16_nt(dres + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       if (okc[k]) {
-        const size_t off = (size_t)row * C + (sub + G * k) * KP;
-        Chunk<T>::unpack(ld16_nt(x + off), xh[k]);   // last uses of the saved activation and of dy
-        Chunk<T>::unpack(ld16_nt(dy + off), dv[k]);
+        Chunk<T>::unpack(rx[k], xh[k]);
+        Chunk<T>::unpack(rd[k], dv[k]);
       }
 #pragma unroll
       for (int e = 0; e < KP; ++e) {
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
       if (okc[k]) {
         const size_t off = (size_t)row * C + (sub + G * k) * KP;
         float r[KP], o[KP];
-        if (dres) Chunk<T>::unpack(ld16_nt(dres + off), r);
+        if (dres) Chunk<T>::unpack(rr[k], r);
 #pragma unroll
         for (int e = 0; e < KP; ++e) {
           float v = rs * (dv[k][e] * gm[k][e] - a - xh[k][e] * b);
