@@ -460,6 +460,7 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       }
     }
   }
+  if constexpr (EPRE) __builtin_amdgcn_sched_barrier(0);   // the prefetch group is issued before any of it is consumed
 #pragma unroll
   for (int i = 0; i < GRP; ++i) {
     if (!okr[i]) continue;
