@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
       Chunk<T>::unpack(gv[q], g);
 #pragma unroll
       for (int e = 0; e < KP; ++e)
-        if (ok[q] && (int)((pk[q] >> (8 * e)) & 0xff) == tap[q]) acc[e] += g[e];
+        acc[e] += (ok[q] && (int)((pk[q] >> (8 * e)) & 0xff) == tap[q]) ? g[e] : 0.f;   // (a select: the branchy form costs an exec-mask save / restore per element)
     }
     st16(dz + i * KP, Chunk<T>::pack(acc));
   }
@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void pool_sum(const PoolTaps<T>& t, float (&acc)[DT<T
     Chunk<T>::unpack(t.gv[q], g);
 #pragma unroll
     for (int e = 0; e < KP; ++e)
-      if (t.ok[q] && (int)((t.pk[q] >> (8 * e)) & 0xff) == t.tap[q]) acc[e] += g[e];
+      acc[e] += (t.ok[q] && (int)((t.pk[q] >> (8 * e)) & 0xff) == t.tap[q]) ? g[e] : 0.f;
   }
   Chunk<T>::unpack(Chunk<T>::pack(acc), acc);   // as pfr_maxpool_bwd stored it
 }
