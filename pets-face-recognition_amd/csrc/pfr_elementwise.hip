@@ -188,6 +188,8 @@ struct ColGeom {
 };
 static ColGeom col_geom(int C, int kp, size_t rows, size_t target = 512) {
   ColGeom g;
+  static const int tgt_env = getenv("PFR_BN_TARGET") ? atoi(getenv("PFR_BN_TARGET")) : 0;   // experiment: workgroups per streaming launch
+  if (tgt_env > 0) target = (size_t)tgt_env;
 
   g.cpr = C / kp;
   int cw = 1;
@@ -584,7 +586,9 @@ extern "C" int pfr_bn_act_mask(const void* x1, const float* a1, const float* b1,
   PFR_CHECK_ARG(x1 && a1 && b1 && y, "pfr_bn_act: null pointer");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_act: C %% %d != 0", kp);
-  ColGeom g = col_geom(C, kp, (size_t)rows, 512);   // pure streaming: many resident waves (no partial rows to merge)
+  // workgroups per launch (measured with the load batches intact): three-stream passes (two reads + one write) are fastest with ONE
+  // workgroup per CU (256), the read-write pass with two; 384 or >= 768 lose 1-6 %
+  ColGeom g = col_geom(C, kp, (size_t)rows, x2 ? 256 : 512);
 #define PFR_BNACT(TT, H2) hipLaunchKernelGGL((bn_act_kernel<TT, H2>), dim3(g.gx, g.gy), dim3(256), 0, st, (const TT*)x1, a1, b1, (const TT*)x2, a2, b2, (TT*)y, mask, (size_t)rows, C, g.cw, g.rl, g.cpr, relu)
   if (dtype == PFR_BF16) { if (x2) PFR_BNACT(bf16_t, true); else PFR_BNACT(bf16_t, false); }
   else { if (x2) PFR_BNACT(float, true); else PFR_BNACT(float, false); }
@@ -820,7 +824,7 @@ extern "C" int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x
   PFR_CHECK_ARG(mask_mode >= 0 && mask_mode <= 3, "pfr_bn_bwd_apply: bad mask_mode");
   const int kp = dtype == PFR_BF16 ? 8 : 4;
   PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_apply: C %% %d != 0", kp);
-  ColGeom g = col_geom(C, kp, (size_t)rows, 512);
+  ColGeom g = col_geom(C, kp, (size_t)rows, 256);   // one workgroup per CU (see pfr_bn_act_mask)
   hipEvent_t stop = pfr_tls_stop_event;
   pfr_tls_stop_event = nullptr;
 #define PFR_BNA(TT, M)                                                                                                                        \
