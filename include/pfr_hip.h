@@ -70,6 +70,8 @@ int pfr_plan_run(void* plan, int begin, int end, pfr_stream_t main_stream, pfr_s
  *   mtile = pfr_conv2d_mtile(M, Cout, R*S*C, C, dtype, out_dtype, pro_scale != 0)  (input of pfr_bn_finalize; deterministic, no atomics):
  *   the m-tile height of the kernel that takes this geometry, or half of it for the persistent kernel (one partial per wave row). */
 int pfr_conv2d_mtile(int M, int Cout, int K, int C, int dtype, int out_dtype, int fused_prologue); /* K = R*S*C */
+/* the same query for pfr_gemm_act_colstats (a launch with an activation epilogue always takes the tile kernel) */
+int pfr_gemm_act_mtile(long M, int K, int N, int dtype);
 int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W, int C,
                    int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int ldy,
                    const float* bias, const void* residual, int accumulate, int out_relu, const float* pro_scale,

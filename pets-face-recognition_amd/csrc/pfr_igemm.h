@@ -56,6 +56,13 @@ int igemm_ws_mode();
 void igemm_ws_set_mode(int v);
 bool igemm_ws_eligible(const IgemmParams& p, int dtype, int out_dtype);
 int igemm_ws_launch(IgemmParams& p, hipStream_t st);
+// weight-stationary streaming kernel for HBM-bound 1x1 convolutions (pfr_sconv.hip): PFR_SCONV / pfr_set_tuning("sconv"): 0 off,
+// 1 heuristic (default), 2 whenever eligible.  sconv_try_launch returns 1 when it does not take the launch; sconv_mtile the rows per
+// statistics partial of a post-op-free 1x1 launch it WOULD take (0: not its geometry) — both decide on geometry alone.
+int sconv_mode();
+void sconv_set_mode(int v);
+int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
+int sconv_mtile(int M, int N, int K, int dtype, int out_dtype);
 // parity-class mode of the persistent kernel: data gradient of a stride-2 conv (input dilation 1 << 1) over even output sizes
 static inline bool igemm_pclass_ok(const IgemmParams& p) {
   return p.idil_log2 == 1 && p.ostride == 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part;

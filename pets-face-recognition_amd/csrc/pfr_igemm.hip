@@ -754,11 +754,20 @@ static int pick_ws(int M, int Cout, int K, int C, int dtype, int out_dtype, int 
 template <typename T, typename TO>
 static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   int bq, bp;
-  if (igemm_ws_mode() && igemm_ws_eligible(p, dtype, out_dtype) &&
+  // A launch that publishes statistics AND has post-ops (pfr_gemm_act_colstats) takes the plain tile kernel: its partial
+  // granularity is what pfr_gemm_act_mtile reports (the alternative kernels decide on flags pfr_conv2d_mtile cannot see).
+  const bool stats_postop = p.stats_part && (p.bias || p.act || p.accumulate || p.residual || p.out_relu);
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+    if (!stats_postop) {
+      const int rc = sconv_try_launch(p, dtype, out_dtype, st);
+      if (rc != 1) return rc;
+    }
+  }
+  if (!stats_postop && igemm_ws_mode() && igemm_ws_eligible(p, dtype, out_dtype) &&
       (igemm_pclass_ok(p) || pick_ws(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr)))
     return igemm_ws_launch(p, st);
   const int pcl = igemm_pclass_ok(p) ? 1 : 0;
-  if (!p.bnb_part[0] && pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp)) {
+  if (!stats_postop && !p.bnb_part[0] && pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp)) {
     const int rc = igemm_p_launch(p, dtype, out_dtype, bq, bp, st);
     if (rc != 1) return rc;
   }
@@ -779,6 +788,10 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
 // the m-tile height, or half of it when the persistent kernel (one partial per wave row) takes the launch
 extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int C, int dtype, int out_dtype, int fused_prologue) {
   int bq, bp;
+  if (K == C && !fused_prologue) {   // 1x1: the streaming kernel publishes one partial per workgroup row range
+    const int mt = sconv_mtile(M, Cout, K, dtype, out_dtype);
+    if (mt) return mt;
+  }
   if (pick_ws(M, Cout, K, C, dtype, out_dtype, fused_prologue)) return 64;   // one partial per memory wave (64 rows)
   // (statistics and the parity-class mode exclude each other, so the heuristic never picks the persistent kernel for a
   //  launch that publishes statistics; PFR_IGEMM_P=2 does)
@@ -900,6 +913,12 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int
 //   act 3: y = (x·Wᵀ) ∘ gelu'(y2)                                                              [data gradient of fc2]
 static int gemm_act_impl(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
                          void* y2, float* stats_part, hipStream_t stream);
+// rows per statistics partial of pfr_gemm_act_colstats for this geometry (a launch with post-ops always takes the tile kernel)
+extern "C" int pfr_gemm_act_mtile(long M, int K, int N, int dtype) {
+  int bq;
+  pick_tile((int)M, N, K, dtype, dtype, &bq);
+  return bq;
+}
 extern "C" int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias,
                             int act, void* y2, hipStream_t stream) {
   return gemm_act_impl(x, w, y, dtype, M, K, N, bias, act, y2, nullptr, stream);

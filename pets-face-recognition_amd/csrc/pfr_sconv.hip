@@ -1,0 +1,419 @@
+// pfr_sconv.hip — weight-stationary STREAMING 1x1 convolution / GEMM on MFMA for the HBM-bound layers (bf16).
+//
+// Replaces, for the geometries it takes, the same reference calls as pfr_igemm.hip: `nn.Conv2d(k=1)` forward and its autograd
+// input gradient inside torchvision's Bottleneck (/root/reference/configs/dog_fe/fe_dogs_config.py:102-103), incl. the residual
+// join of the block's first conv (`out += identity; relu` backward).  y[m][n] = sum_k x[m][k] * w[n][k]  (+ res[m][n] where mask).
+//
+// Why another kernel: at batch 256 the 1x1 convolutions of layer1-3 move 130-980 MB for 20-60 us of MFMA work — their ceiling is
+// HBM.  The tile kernels reach 3.3-4.5 TB/s on them: every 128-row tile re-stages its weight panel through LDS (a third to a half
+// of the LDS-DMA volume), keeps at most one k-step (12-16 KB) of loads in flight behind a workgroup barrier, and pays a
+// prologue/epilogue per tile.  tools/probe/stream_probe.hip shows what the memory system gives a PERSISTENT workgroup whose waves
+// each own a private LDS-DMA ring: 6.3-6.5 TB/s read-only, 5.6-5.9 TB/s with an output stream — this kernel is that skeleton
+// with the MFMAs and the epilogue hung into it:
+//   * grid = npanels x nranges = 256 persistent workgroups of 4 waves (one per SIMD, up to 512 registers each);
+//   * the weight panel [NP couts][K] is loaded into LDS ONCE per workgroup (<= 64 KiB, XOR-swizzled 16-byte chunks);
+//   * a workgroup owns the contiguous row range [r*R, (r+1)*R); its wave w walks the 32*TQ-row blocks w, w+4, ... of it.  The rows
+//     of a block arrive as K/64 "granules" ([32*TQ rows][64 k] = 4*TQ KiB, full 128-byte lines) through the wave's PRIVATE ring
+//     of NS slots with counted `s_waitcnt vmcnt(n)` — no workgroup barrier anywhere in the loop, waves drift freely, so one
+//     wave's MFMAs overlap another's epilogue and a third's DMA issue;
+//   * epilogue per wave: accumulators -> bf16 -> private 4 KiB LDS window -> whole 128-byte row segments -> buffer stores;
+//     BatchNorm statistics (shifted sums of the values AS STORED) stay in registers over all blocks of the wave and leave as ONE
+//     (mean, M2) partial per workgroup: pfr_bn_finalize sees <= 256 partials of R rows (one launch, no group merge).
+// Results are bit-identical to igemm_kernel's (same k order inside and across MFMAs); statistics partials differ only in how the
+// rows are grouped.
+#include "pfr_igemm.h"
+#include <stdlib.h>
+
+struct SconvParams {
+  const void* x;
+  const void* w;
+  void* y;
+  int M, K, N;            // output rows, reduction length (= input channels), output channels (ldy == N)
+  int H, W, OH, OW, ostride;   // ostride > 1: row m = (n, oh, ow) reads input pixel (n, oh*ostride, ow*ostride)
+  float* stats_part;      // [nranges][2][N] (mean, M2) or nullptr
+  const void* res;        // join: residual-branch gradient [M][N] bf16, or nullptr
+  const unsigned char* res_mask;   // join: its ReLU bit mask [M][N/8]
+  int npanels, nranges, R;    // R: rows per range (multiple of the 32-row block height)
+  int npw;                    // couts of a workgroup's weight panel (64, 128 or 256)
+  int xbytes;                 // bytes of x (buffer bound: rows past the end read zeros)
+  FastDiv div_ohow, div_ow;
+};
+
+// TP: 32-cout accumulator tiles per wave (the wave's column slice is TP*32 couts), NS: ring slots per wave, STATS: BatchNorm partials
+template <int TP, int NS, bool STATS>
+__global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
+  constexpr int NPV = TP * 32;           // couts per wave
+  constexpr int GB = 4096;               // granule bytes: [32 rows][64 k] bf16
+  constexpr int GI = 4;                  // DMA instructions per granule
+  constexpr int NCG = NPV / 64;          // 64-cout column groups of the epilogue
+  constexpr int SB = NPV / 16;           // store instructions per block (32 rows x NPV couts x 2 B / 1 KiB)
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = p.K, RB = K * 2;                 // weight row bytes
+  const int KG = K >> 6;                         // granules per block
+  const int NPW = p.npw;                         // couts of the workgroup's weight panel
+  const int wbytes = NPW * RB;
+  const int nsub = NPW / NPV;                    // column slices per panel (1, 2 or 4): wave -> (slice, row lane)
+  const int sub = wave % nsub, wrow = wave / nsub, nrw = 8 / nsub;
+
+  // (panel, range) of this workgroup: the panels of one range run on the same XCD (block b is observed on XCD b % 8 — speed only)
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q8 = b >> 3;
+  const int pn = q8 % p.npanels, rq = q8 / p.npanels;
+  const int r = rq * 8 + xcd;
+  const int n0 = pn * NPW + sub * NPV;           // first cout of this wave
+  const int row_lo = r * p.R;
+  const int row_hi = row_lo + p.R < p.M ? row_lo + p.R : p.M;
+  if (r >= p.nranges || row_lo >= p.M) return;
+  const int nblk = (row_hi - row_lo + 31) >> 5;
+
+  __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.N * RB, 0x00020000);
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.xbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.M * p.N * 2, 0x00020000);
+  const uint32_t OOBB = 0xF0000000u;
+
+  // ---- weight panel -> LDS (once): linear LDS image, XOR swizzle on the source side
+  {
+    const int ninst = wbytes >> 10;
+    for (int t = wave; t < ninst; t += 8) {
+      const int L = (t << 10) + (lane << 4);
+      const int row = L / RB, pc = (L - row * RB) >> 4;
+      const int lc = (K == 64) ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 15));
+      const uint32_t off = (uint32_t)((pn * NPW + row) * RB + (lc << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + (t << 10)), 16, (int)off, 0, 0, 0);
+    }
+  }
+
+  // ---- per-lane constants (LDS byte addresses are 32-bit)
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int sx = (frow >> 1) & 7;                                     // swizzle of a granule / window row (128-byte rows)
+  const int sw = (K == 64) ? ((frow >> 1) & 7) : (frow & 15);         // swizzle of a weight row
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t ring0 = lds0 + wbytes + wave * (NS * GB);            // this wave's ring (wave-uniform)
+  char* const ringp = smem + wbytes + wave * (NS * GB);
+  // fragment read offsets inside a granule for k16 step s: row frow, chunk (2s + fhalf) ^ sx
+  uint32_t xo[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) xo[s] = (uint32_t)(frow * 128 + (((2 * s + fhalf) ^ sx) << 4));
+  const uint32_t wlane = lds0 + (uint32_t)((sub * NPV + frow) * RB);  // weight row of this lane (tile i adds i*32*RB)
+  // epilogue window (the ring slot the block's last granule came through): write side (row frow) / read-back side
+  const uint32_t ew_w = (uint32_t)(frow * 128 + (sx << 4) + fhalf * 8);          // ^ (c << 4) for chunk c
+  const int e_row = lane >> 3, e_ch = lane & 7;
+  const uint32_t ew_r = (uint32_t)(e_row * 128 + ((e_ch ^ (e_row >> 1)) << 4)); // pass ps: + ps*1024, ^ ((ps & 1) << 6)
+  const uint32_t y_lane = (uint32_t)((e_row * p.N + e_ch * 8) * 2);              // lane part of the output byte offset
+
+  // ---- loader state
+  const int g_row = lane >> 3, g_pc = lane & 7;                       // DMA: row within an 8-row instruction, physical chunk
+  int l_blk = wrow, l_kc = 0;
+  uint32_t rowoff[GI];
+  auto set_rows = [&](int blk) {
+#pragma unroll
+    for (int t = 0; t < GI; ++t) {
+      const int m = row_lo + blk * 32 + t * 8 + g_row;
+      uint32_t off = OOBB;
+      if (blk < nblk) {
+        uint32_t xr = (uint32_t)m;
+        if (p.ostride != 1) {
+          const uint32_t n_img = fdiv((uint32_t)m, p.div_ohow);
+          const uint32_t rem = (uint32_t)m - n_img * (uint32_t)(p.OH * p.OW);
+          const uint32_t oh = fdiv(rem, p.div_ow), ow = rem - oh * p.OW;
+          xr = (n_img * p.H + oh * p.ostride) * p.W + ow * p.ostride;
+        }
+        const int lc = g_pc ^ ((t * 4 + (g_row >> 1)) & 7);
+        off = xr * (uint32_t)RB + (uint32_t)(lc << 4);     // rows past the end lie beyond num_records: zero-filled
+      }
+      rowoff[t] = off;
+    }
+  };
+  set_rows(l_blk);
+  auto issue = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < GI; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(ringp + slot * GB + t * 1024), 16,
+                                               (int)(rowoff[t] + (uint32_t)(l_kc << 7)), 0, 0, 0);
+    if (++l_kc == KG) {
+      l_kc = 0;
+      l_blk += nrw;
+      set_rows(l_blk);
+    }
+  };
+
+  // ---- ring prologue: NS-1 granules in flight; the weight panel is complete behind them
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- statistics state (per lane: 8 couts of every column group, fixed over all rows)
+  f32x2 s1[NCG][4], s2[NCG][4], ksh[NCG][4];
+#pragma unroll
+  for (int g = 0; g < NCG; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[g][e] = (f32x2){0.f, 0.f}; s2[g][e] = (f32x2){0.f, 0.f}; ksh[g][e] = (f32x2){0.f, 0.f}; }
+
+  int slot = 0;
+  uint32_t hist = 0;   // bit i: iteration (now - 1 - i) ended with an epilogue (its SB stores are younger than older DMAs)
+  const int my_blocks = nblk > wrow ? (nblk - wrow + nrw - 1) / nrw : 0;
+
+  auto wait_granule = [&]() {
+    // the granule to consume has landed when only the NS-1 younger granules and the stores of the epilogues of the last
+    // NS-1 iterations are outstanding (gfx950 retires a wave's loads and stores in issue order)
+#ifdef PFR_SCONV_SAFEWAIT
+    const int ne = 0;
+#else
+    const int ne = __builtin_popcount(hist & ((1u << (NS - 1)) - 1));
+#endif
+    if (ne == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI) : "memory");
+    else if (ne == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + SB > 63 ? 63 : (NS - 1) * GI + SB) : "memory");
+    else if (ne == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + 2 * SB > 63 ? 63 : (NS - 1) * GI + 2 * SB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + 3 * SB > 63 ? 63 : (NS - 1) * GI + 3 * SB) : "memory");
+    hist <<= 1;
+  };
+  typedef __attribute__((address_space(3))) const u32x4* lds_cptr;
+  typedef __attribute__((address_space(3))) u32x2* lds_w8ptr;
+
+#pragma unroll 1
+  for (int bi = 0; bi < my_blocks; ++bi) {
+    const int m0 = row_lo + (wrow + nrw * bi) * 32;
+    f32x16 acc[TP];
+    // ---- granules of the block: the first one starts the accumulators from a constant-zero C operand
+#pragma unroll 1
+    for (int kc = 0; kc < KG; ++kc) {
+      issue((slot + NS - 1) % NS);
+      wait_granule();
+      const uint32_t gbase = ring0 + slot * GB;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const u32x4 fq = *(lds_cptr)(uintptr_t)(gbase + xo[s]);
+        const uint32_t wa = wlane + ((((uint32_t)(kc * 8 + 2 * s) | (uint32_t)fhalf) ^ (uint32_t)sw) << 4);
+        u32x4 fp[TP];
+#pragma unroll
+        for (int i = 0; i < TP; ++i) fp[i] = *(lds_cptr)(uintptr_t)(wa + i * 32 * RB);
+        if (s == 0 && kc == 0) {
+#pragma unroll
+          for (int i = 0; i < TP; ++i) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fp[i]), __builtin_bit_cast(bf16x8, fq), z, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fp[i]), __builtin_bit_cast(bf16x8, fq), acc[i], 0, 0, 0);
+        }
+      }
+      slot = (slot + 1) % NS;
+    }
+    // MFMA results are written back pass by pass and the MFMA -> VALU read-after-write distance is SOFTWARE-managed on CDNA.
+    // hipcc counts those wait states along the code LAYOUT; it laid the epilogue block in front of the loop it follows and
+    // missed the hazard across the back edge (observed: the last pass of the last MFMA — 8 registers x 16 lanes — read stale
+    // by the conversions below, a few hundred rows per launch).  16 explicit wait states, tied to the accumulators.
+#pragma unroll
+    for (int i = 0; i < TP; ++i) asm volatile("s_nop 15" : "+v"(acc[i]));
+    // ---- epilogue: the slot of the block's last granule is free until the next DMA is issued into it: it is the staging window
+    hist |= 1u;
+    const uint32_t wbase = ring0 + ((slot + NS - 1) % NS) * GB;
+    const uint32_t ybase = (uint32_t)((m0 * p.N + n0) * 2);
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) {
+      // accumulators (lane: row frow, couts 8*qd + 4*fhalf + 0..3 of tile i) -> window [row][128 B], chunk ^ ((row >> 1) & 7)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x16& a = acc[2 * g + ii];
+          bf16x4 v;
+          v[0] = (bf16_t)a[4 * qd];
+          v[1] = (bf16_t)a[4 * qd + 1];
+          v[2] = (bf16_t)a[4 * qd + 2];
+          v[3] = (bf16_t)a[4 * qd + 3];
+          *(lds_w8ptr)(uintptr_t)(wbase + (ew_w ^ (uint32_t)((ii * 4 + qd) << 4))) = __builtin_bit_cast(u32x2, v);
+        }
+      }
+      if (STATS && bi == 0) {   // shift of the statistics: the wave's first stored row (row 0 of the window: swizzle 0)
+        const u32x4 v = *(lds_cptr)(uintptr_t)(wbase + (uint32_t)(e_ch << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ksh[g][e] = (f32x2){__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u)};
+      }
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const u32x4 v = *(lds_cptr)(uintptr_t)(wbase + ((ew_r ^ (uint32_t)((ps & 1) << 6)) + ps * 1024));
+        if (STATS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 f = {__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u)};
+            const f32x2 d = f - ksh[g][e];
+            s1[g][e] += d;
+            s2[g][e] = __builtin_elementwise_fma(d, d, s2[g][e]);
+          }
+        }
+        // rows past M lie beyond num_records: the store is dropped
+        __builtin_amdgcn_raw_buffer_store_b128(v, yrsrc, (int)(y_lane + (uint32_t)(g * 128)), (int)(ybase + (uint32_t)(ps * 8 * p.N * 2)), 0);
+      }
+    }
+    // MEASURED on gfx950: a buffer_store_dwordx4 reads its data VGPRs from the register file LATE when the vector-memory queue is
+    // deep (here up to ~28 DMA / store instructions in flight per wave) — the DMA address arithmetic of the next iteration, which
+    // hipcc places in the same registers, overwrote the last quad lanes of the first data dword of this block's last stores
+    // (~1000 rows of 800 k wrong, each holding an x byte offset instead of two outputs).  hipcc assumes store data is read at
+    // issue and emits no wait; the read-out IS tracked by EXP_CNT: waiting for it costs nothing measurable.
+    asm volatile("s_waitcnt expcnt(0)" ::: "memory");
+  }
+  // drain: the dummy granules issued past the end must have landed before the LDS is reused or released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (STATS) {
+    __syncthreads();   // every wave is past its last panel read and ring use: the LDS is reused below
+    // rows this wave processed; those past M contributed y = 0, i.e. d = -ksh: taken out again below
+    int nproc = my_blocks * 32, ninv = 0;
+    if (my_blocks > 0) {
+      const int last_end = row_lo + (wrow + nrw * (my_blocks - 1)) * 32 + 32;
+      ninv = last_end > p.M ? last_end - p.M : 0;
+    }
+    const float nval = (float)(nproc - ninv), finv = (float)ninv;
+    float* red = reinterpret_cast<float*>(smem);   // [8 waves][3][NPV]: mean, M2, n
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float a = s1[g][e][h], q = s2[g][e][h];
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {   // lanes with equal e_ch hold partials of the same couts
+            a += __shfl_xor(a, o, 64);
+            q += __shfl_xor(q, o, 64);
+          }
+          const float k = ksh[g][e][h];
+          a += finv * k;
+          q -= finv * k * k;
+          if (lane < 8) {
+            const int c = g * 64 + lane * 8 + e * 2 + h;
+            red[(wave * 3 + 0) * NPV + c] = nval > 0.f ? k + a / nval : 0.f;
+            red[(wave * 3 + 1) * NPV + c] = nval > 0.f ? q - a * a / nval : 0.f;
+            red[(wave * 3 + 2) * NPV + c] = nval;
+          }
+        }
+    __syncthreads();
+    // merge the row lanes of every column slice (Chan): thread -> (slice, cout)
+    for (int c = tid; c < NPW; c += 512) {
+      const int sl = c / NPV, cc = c - sl * NPV;
+      float n = 0.f, a = 0.f;
+      for (int wr = 0; wr < nrw; ++wr) {
+        const int w = wr * nsub + sl;
+        const float nw = red[(w * 3 + 2) * NPV + cc];
+        n += nw;
+        a = fmaf(nw, red[(w * 3 + 0) * NPV + cc], a);
+      }
+      const float mean = n > 0.f ? a / n : 0.f;
+      float m2 = 0.f;
+      for (int wr = 0; wr < nrw; ++wr) {
+        const int w = wr * nsub + sl;
+        const float nw = red[(w * 3 + 2) * NPV + cc];
+        const float d = red[(w * 3 + 0) * NPV + cc] - mean;
+        m2 += red[(w * 3 + 1) * NPV + cc] + nw * d * d;
+      }
+      p.stats_part[((size_t)r * 2 + 0) * p.N + pn * NPW + c] = mean;
+      p.stats_part[((size_t)r * 2 + 1) * p.N + pn * NPW + c] = m2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int g_sconv_mode = -1;   // PFR_SCONV / pfr_set_tuning("sconv"): 0 off, 1 heuristic (default), 2 whenever eligible
+int sconv_mode() {
+  if (g_sconv_mode < 0) {
+    const char* e = getenv("PFR_SCONV");
+    g_sconv_mode = e ? atoi(e) : 1;
+  }
+  return g_sconv_mode;
+}
+void sconv_set_mode(int v) { g_sconv_mode = v; }
+
+// panel width for (N, K): the widest of 256 / 128 / 64 couts that divides N and keeps the panel within 64 KiB
+static int sconv_panel(int N, int K) {
+  for (int np = 256; np >= 64; np >>= 1)
+    if (N % np == 0 && (long)np * K * 2 <= 65536) return np;
+  return 0;
+}
+
+struct SconvPlan {
+  int np, npanels, nranges, R, ns, tp;
+};
+// geometry-only eligibility (what pfr_conv2d_mtile can see as well): bf16, K in {64, 128, 256, 512}, panel fits, enough rows
+bool sconv_plan(int M, int N, int K, int dtype, int out_dtype, SconvPlan* sp) {
+  const int mode = sconv_mode();
+  if (mode == 0 || dtype != PFR_BF16 || out_dtype != PFR_BF16) return false;
+  if (K != 64 && K != 128 && K != 256 && K != 512) return false;
+  if (N % 64 != 0 || (long)M * N * 2 >= ((long)1 << 31) || (long)M * K * 2 >= ((long)1 << 31)) return false;
+  const int np = sconv_panel(N, K);
+  if (!np) return false;
+  const int npanels = N / np;
+  if (npanels > 32 || (256 % npanels) != 0) return false;
+  // re-reading x once per panel must stay cheaper than what the tile kernels do: at most 8 panels, and K <= 256 unless 2 panels
+  if (mode == 1) {
+    if (npanels > 8 || (K == 512 && npanels > 2)) return false;
+    if (M < 256 * 64) return false;    // too few rows per workgroup for a pipeline
+  }
+  int nranges = 256 / npanels;
+  long R = ((long)M + nranges - 1) / nranges;
+  R = (R + 31) / 32 * 32;
+  nranges = (int)((M + R - 1) / R);
+  const long wbytes = (long)np * K * 2;
+  int ns = (int)((160 * 1024 - wbytes) / (8 * 4096));
+  if (ns > 4) ns = 4;
+  if (ns < 2) return false;
+  sp->np = np; sp->npanels = npanels; sp->nranges = nranges; sp->R = (int)R; sp->ns = ns;
+  sp->tp = np >= 128 ? 4 : 2;
+  return true;
+}
+
+template <int TP, bool STATS>
+static int sconv_launch_ns(SconvParams& sp, const SconvPlan& pl, hipStream_t st) {
+  const int lds = pl.np * sp.K * 2 + 8 * pl.ns * 4096;
+  const dim3 grid(256), block(512);
+#define PFR_SCONV_GO(NSV)                                                                                       \
+  do {                                                                                                          \
+    auto kern = sconv_kernel<TP, NSV, STATS>;                                                                   \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, sp);                                                         \
+  } while (0)
+  if (pl.ns >= 4) PFR_SCONV_GO(4);
+  else if (pl.ns == 3) PFR_SCONV_GO(3);
+  else PFR_SCONV_GO(2);
+#undef PFR_SCONV_GO
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// takes the launch when it is a plain 1x1 convolution of an eligible geometry; returns 1 when it is not
+int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
+  if (p.R != 1 || p.S != 1 || p.pad != 0 || p.idil_log2 != 0 || p.ldy != p.Cout) return 1;
+  if (p.bias || p.accumulate || p.out_relu || p.pro_scale || p.act || p.bnb_part[0]) return 1;
+  if (p.residual) return 1;   // (join variant: not built yet)
+  if (p.ostride != 1 && (p.H != p.OH * p.ostride || p.W != p.OW * p.ostride)) return 1;
+  if ((long)p.N * p.H * p.W * p.K * 2 >= ((long)1 << 31)) return 1;
+  SconvPlan pl;
+  if (!sconv_plan(p.M, p.Cout, p.K, dtype, out_dtype, &pl)) return 1;
+  SconvParams sp;
+  sp.x = p.x; sp.w = p.w; sp.y = p.y;
+  sp.M = p.M; sp.K = p.K; sp.N = p.Cout;
+  sp.H = p.H; sp.W = p.W; sp.OH = p.OH; sp.OW = p.OW; sp.ostride = p.ostride;
+  sp.stats_part = p.stats_part;
+  sp.res = nullptr; sp.res_mask = nullptr;
+  sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
+  sp.xbytes = (int)((long)p.N * p.H * p.W * p.K * 2);
+  sp.div_ohow = p.div_ohow; sp.div_ow = p.div_ow;
+  if (pl.tp == 2) return p.stats_part ? sconv_launch_ns<2, true>(sp, pl, st) : sconv_launch_ns<2, false>(sp, pl, st);
+  return p.stats_part ? sconv_launch_ns<4, true>(sp, pl, st) : sconv_launch_ns<4, false>(sp, pl, st);
+}
+
+// rows per statistics partial when this kernel takes a (post-op free) 1x1 launch of the geometry, 0 when it does not
+int sconv_mtile(int M, int N, int K, int dtype, int out_dtype) {
+  SconvPlan pl;
+  if (!sconv_plan(M, N, K, dtype, out_dtype, &pl)) return 0;
+  return pl.R;
+}

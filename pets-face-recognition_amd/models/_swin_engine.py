@@ -422,7 +422,7 @@ class SwinEngine:
                 if self.fuse_gelu:   # dh1 = (dz·W2) ∘ gelu'(h1) in the data-gradient GEMM's epilogue
                     # ... which also leaves the per-m-tile column means of dh1: fc1's bias gradient = sum_t rows_t * mean_t, merged
                     # with the other deferred column sums -- no second pass over the widest gradient tensor of the block
-                    mt = lib.pfr_conv2d_mtile(rows, 4 * C, C, C, did, did, 0)
+                    mt = lib.pfr_gemm_act_mtile(rows, C, 4 * C, did)
                     nt = (rows + mt - 1) // mt
                     stp = A((nt, 2, 4 * C), torch.float32)
                     bwd.append((lib.pfr_gemm_act_colstats, (dz.data_ptr(), b["fc2"].wt.data_ptr(), dh2.data_ptr(), did, rows, C, 4 * C, 0,

@@ -515,3 +515,40 @@ def test_nchw_to_nhwc_channel_padding(dtype, shape):
     ref = torch.zeros(N, H, W, Cp, device=DEV, dtype=dtype)
     ref[..., :C] = x.permute(0, 2, 3, 1).to(dtype)
     assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("case", [
+    # (N, H, C, Cout, stride): weight-stationary streaming kernel geometries (pfr_sconv.hip), incl. ragged row counts
+    (2, 56, 64, 64, 1), (2, 56, 64, 256, 1), (2, 56, 256, 64, 1), (3, 28, 128, 512, 1), (2, 28, 512, 128, 1),
+    (5, 14, 256, 1024, 1), (2, 56, 256, 128, 1), (2, 56, 256, 512, 2), (1, 7, 128, 256, 1), (3, 5, 64, 64, 1), (7, 9, 256, 64, 1),
+    (1, 3, 64, 256, 1),
+])
+def test_streaming_1x1_kernel_bit_identical(case):
+    """pfr_sconv.hip (persistent, weight panel resident in LDS, per-wave DMA rings) must reproduce the tile kernel BIT FOR BIT and
+    publish BatchNorm statistics that finalise to the same mean / invstd at the granularity pfr_conv2d_mtile reports."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, C, Co, sd = case
+    g = torch.Generator().manual_seed(H * C + Co)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(Co, 1, 1, C, generator=g) / C ** 0.5).to(DEV).bfloat16()
+    outs = []
+    try:
+        for mode in (0, 2):
+            lib.pfr_set_tuning(b"sconv", mode)
+            for stats in (True, False):
+                y, part = o.conv2d_fwd(x, w, stride=sd, pad=0, stats=stats)
+                st = None
+                if part is not None:
+                    M = y.numel() // Co
+                    mt = lib.pfr_conv2d_mtile(M, Co, C, C, 1, 1, 0)
+                    st = o.bn_finalize(part, mt, M, None, None, 1e-5, 0.1, None, None)[:2].clone()
+                torch.cuda.synchronize()
+                outs.append((y.clone(), st))
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=sd).permute(0, 2, 3, 1)
+    assert (outs[0][0].float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    for y, st in outs[1:]:
+        assert torch.equal(y, outs[0][0])
+    assert torch.allclose(outs[2][1], outs[0][1], rtol=2e-4, atol=1e-5)

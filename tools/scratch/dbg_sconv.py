@@ -1,0 +1,29 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import torch
+from pets_face_recognition_amd._hip import lib, ops as o
+dev="cuda:0"
+torch.manual_seed(0)
+for (N,H,C,Co) in [(256,56,64,64)]:
+    x = torch.randn(N, H, H, C, device=dev).bfloat16()
+    w = (torch.randn(Co, 1, 1, C, device=dev) / C ** 0.5).bfloat16()
+    ys=[]
+    for mode in (0,2):
+        lib.pfr_set_tuning(b"sconv", mode)
+        y,_ = o.conv2d_fwd(x, w, stats=False)
+        torch.cuda.synchronize()
+        ys.append(y.clone())
+    d = (ys[0].float()-ys[1].float()).reshape(-1, Co)
+    bad = ((d.abs() > 0) | d.isnan()).any(1).nonzero().flatten()
+    print((N,H,C,Co), "bad rows", bad.numel(), "of", d.shape[0])
+    X = x.reshape(-1, C).float(); W = w.reshape(Co, C).float()
+    for r in bad[:3].tolist() + bad[-2:].tolist():
+        for col in (32, 33, 34, 40):
+            full = (X[r] * W[col]).sum().item()
+            parts = [(X[r, 16*s:16*s+16] * W[col, 16*s:16*s+16]).sum().item() for s in range(4)]
+            print(f" row {r} (blk {r//32}, r%32 {r%32}) col {col}: tile {ys[0].reshape(-1,Co)[r,col].item():.4f} sconv {ys[1].reshape(-1,Co)[r,col].item():.4f} full {full:.4f} k16 parts {[round(p,4) for p in parts]}")
+        # does the sconv value match some other row's value of the same col?
+        v = ys[1].reshape(-1,Co)[r,32].item()
+        col32 = ys[0].reshape(-1,Co)[:,32]
+        near = (col32 == v).nonzero().flatten()[:5].tolist()
+        print("   rows whose correct col-32 value equals sconv's:", near)
