@@ -40,13 +40,16 @@ struct SconvParams {
 };
 
 // TP: 32-cout accumulator tiles per wave (the wave's column slice is TP*32 couts), NS: ring slots per wave, STATS: BatchNorm partials
-template <int TP, int NS, bool STATS>
+// JOIN: y = result + (mask bit ? res : 0) — the residual join of a block's first data gradient (pfr_conv2d_dgrad_join)
+template <int TP, int NS, bool STATS, bool JOIN = false>
 __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
+  static_assert(!(STATS && JOIN), "the join variant publishes no statistics");
   constexpr int NPV = TP * 32;           // couts per wave
   constexpr int GB = 4096;               // granule bytes: [32 rows][64 k] bf16
   constexpr int GI = 4;                  // DMA instructions per granule
   constexpr int NCG = NPV / 64;          // 64-cout column groups of the epilogue
   constexpr int SB = NPV / 16;           // store instructions per block (32 rows x NPV couts x 2 B / 1 KiB)
+  constexpr int RL = JOIN ? 2 * SB : 0;  // residual + mask load instructions per block (join)
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -73,6 +76,8 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.xbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.M * p.N * 2, 0x00020000);
   const uint32_t OOBB = 0xF0000000u;
+  __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0, p.M * p.N * 2, 0x00020000);
+  __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.res_mask ? p.res_mask : (const unsigned char*)p.y), 0, p.M * (p.N >> 3), 0x00020000);
 
   // ---- weight panel -> LDS (once): linear LDS image, XOR swizzle on the source side
   {
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   const int e_row = lane >> 3, e_ch = lane & 7;
   const uint32_t ew_r = (uint32_t)(e_row * 128 + ((e_ch ^ (e_row >> 1)) << 4)); // pass ps: + ps*1024, ^ ((ps & 1) << 6)
   const uint32_t y_lane = (uint32_t)((e_row * p.N + e_ch * 8) * 2);              // lane part of the output byte offset
+  const uint32_t k_lane = (uint32_t)(e_row * (p.N >> 3) + e_ch);                 // lane part of the mask byte offset
 
   // ---- loader state
   const int g_row = lane >> 3, g_pc = lane & 7;                       // DMA: row within an 8-row instruction, physical chunk
@@ -165,10 +171,14 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 #else
     const int ne = __builtin_popcount(hist & ((1u << (NS - 1)) - 1));
 #endif
+    // (join: the RL residual / mask loads of a block are issued at its start, which follows an epilogue: every epilogue in the
+    //  window stands for SB stores + RL loads younger than the granule.  The first block's loads follow no epilogue and go
+    //  uncounted: a smaller count than the true one only waits longer.)
+    constexpr int EV = SB + RL;
     if (ne == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI) : "memory");
-    else if (ne == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + SB > 63 ? 63 : (NS - 1) * GI + SB) : "memory");
-    else if (ne == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + 2 * SB > 63 ? 63 : (NS - 1) * GI + 2 * SB) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + 3 * SB > 63 ? 63 : (NS - 1) * GI + 3 * SB) : "memory");
+    else if (ne == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + EV > 63 ? 63 : (NS - 1) * GI + EV) : "memory");
+    else if (ne == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + 2 * EV > 63 ? 63 : (NS - 1) * GI + 2 * EV) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + 3 * EV > 63 ? 63 : (NS - 1) * GI + 3 * EV) : "memory");
     hist <<= 1;
   };
   typedef __attribute__((address_space(3))) const u32x4* lds_cptr;
@@ -178,6 +188,27 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   for (int bi = 0; bi < my_blocks; ++bi) {
     const int m0 = row_lo + (wrow + nrw * bi) * 32;
     f32x16 acc[TP];
+    // join: the block's residual rows and mask bytes, requested now and consumed by the epilogue.  Inline asm: hipcc would wait
+    // vmcnt(0) — draining the DMA ring — for any load it knows of; these are counted by hand (wait_granule, epilogue).
+    u32x4 rres[NCG][4];
+    uint32_t rmk[NCG][4];
+    if constexpr (JOIN) {
+      const uint32_t rbase = (uint32_t)((m0 * p.N + n0) * 2), kbase = (uint32_t)(m0 * (p.N >> 3) + (n0 >> 3));
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          // (s_nop: the scalar offsets come straight from the SALU; nothing inside an asm statement is padded by the compiler)
+          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+                       : "=v"(rres[g][ps])
+                       : "v"(y_lane + (uint32_t)(g * 128)), "s"(rrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
+                       : "memory");
+          asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen"
+                       : "=v"(rmk[g][ps])
+                       : "v"(k_lane + (uint32_t)(g * 8)), "s"(mrsrc), "s"(kbase + (uint32_t)(ps * p.N))
+                       : "memory");
+        }
+    }
     // ---- granules of the block: the first one starts the accumulators from a constant-zero C operand
 #pragma unroll 1
     for (int kc = 0; kc < KG; ++kc) {
@@ -215,6 +246,14 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
     hist |= 1u;
     const uint32_t wbase = ring0 + ((slot + NS - 1) % NS) * GB;
     const uint32_t ybase = (uint32_t)((m0 * p.N + n0) * 2);
+    if constexpr (JOIN) {
+      // the residual loads are older than the KG granules issued during this block
+      if (KG == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GI) : "memory");
+      else if (KG == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GI) : "memory");
+      else if (KG == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * GI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * GI) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int g = 0; g < NCG; ++g) {
       // accumulators (lane: row frow, couts 8*qd + 4*fhalf + 0..3 of tile i) -> window [row][128 B], chunk ^ ((row >> 1) & 7)
@@ -239,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const u32x4 v = *(lds_cptr)(uintptr_t)(wbase + ((ew_r ^ (uint32_t)((ps & 1) << 6)) + ps * 1024));
-        if (STATS) {
+        if constexpr (STATS) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const f32x2 f = {__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u)};
@@ -247,6 +286,17 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
             s1[g][e] += d;
             s2[g][e] = __builtin_elementwise_fma(d, d, s2[g][e]);
           }
+        }
+        if constexpr (JOIN) {
+          float f[8], rr8[8];
+          Chunk<bf16_t>::unpack(v, f);
+          Chunk<bf16_t>::unpack(rres[g][ps], rr8);
+          const uint32_t bits = rmk[g][ps];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += ((bits >> e) & 1u) ? rr8[e] : 0.f;
+          const u32x4 o = Chunk<bf16_t>::pack(f);
+          __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, (int)(y_lane + (uint32_t)(g * 128)), (int)(ybase + (uint32_t)(ps * 8 * p.N * 2)), 0);
+          continue;
         }
         // rows past M lie beyond num_records: the store is dropped
         __builtin_amdgcn_raw_buffer_store_b128(v, yrsrc, (int)(y_lane + (uint32_t)(g * 128)), (int)(ybase + (uint32_t)(ps * 8 * p.N * 2)), 0);
@@ -367,13 +417,13 @@ bool sconv_plan(int M, int N, int K, int dtype, int out_dtype, SconvPlan* sp) {
   return true;
 }
 
-template <int TP, bool STATS>
+template <int TP, bool STATS, bool JOIN = false>
 static int sconv_launch_ns(SconvParams& sp, const SconvPlan& pl, hipStream_t st) {
   const int lds = pl.np * sp.K * 2 + 8 * pl.ns * 4096;
   const dim3 grid(256), block(512);
 #define PFR_SCONV_GO(NSV)                                                                                       \
   do {                                                                                                          \
-    auto kern = sconv_kernel<TP, NSV, STATS>;                                                                   \
+    auto kern = sconv_kernel<TP, NSV, STATS, JOIN>;                                                                   \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
@@ -393,7 +443,8 @@ static int sconv_launch_ns(SconvParams& sp, const SconvPlan& pl, hipStream_t st)
 int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (p.R != 1 || p.S != 1 || p.pad != 0 || p.idil_log2 != 0 || p.ldy != p.Cout) return 1;
   if (p.bias || p.accumulate || p.out_relu || p.pro_scale || p.act || p.bnb_part[0]) return 1;
-  if (p.residual) return 1;   // (join variant: not built yet)
+  const bool join = p.residual != nullptr;
+  if (join && (!p.res_mask || p.stats_part)) return 1;   // residual only in its data-gradient join form (bit mask)
   if (p.ostride != 1 && (p.H != p.OH * p.ostride || p.W != p.OW * p.ostride)) return 1;
   if ((long)p.N * p.H * p.W * p.K * 2 >= ((long)1 << 31)) return 1;
   SconvPlan pl;
@@ -403,10 +454,11 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.M = p.M; sp.K = p.K; sp.N = p.Cout;
   sp.H = p.H; sp.W = p.W; sp.OH = p.OH; sp.OW = p.OW; sp.ostride = p.ostride;
   sp.stats_part = p.stats_part;
-  sp.res = nullptr; sp.res_mask = nullptr;
+  sp.res = p.residual; sp.res_mask = p.res_mask;
   sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
   sp.xbytes = (int)((long)p.N * p.H * p.W * p.K * 2);
   sp.div_ohow = p.div_ohow; sp.div_ow = p.div_ow;
+  if (join) return pl.tp == 2 ? sconv_launch_ns<2, false, true>(sp, pl, st) : sconv_launch_ns<4, false, true>(sp, pl, st);
   if (pl.tp == 2) return p.stats_part ? sconv_launch_ns<2, true>(sp, pl, st) : sconv_launch_ns<2, false>(sp, pl, st);
   return p.stats_part ? sconv_launch_ns<4, true>(sp, pl, st) : sconv_launch_ns<4, false>(sp, pl, st);
 }

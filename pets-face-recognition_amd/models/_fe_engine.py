@@ -125,6 +125,10 @@ class FEEngine:
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
+        # PFR_SIDE_CUS=n: the weight-gradient (side) launches of the backward plan run on a stream restricted to n of the 256 compute
+        # units (hipExtStreamCreateWithCUMask, every (256/n)-th CU so that all XCDs contribute), next to the HBM-bound BN passes
+        self.side_cus = int(os.environ.get("PFR_SIDE_CUS", "0"))
+        self._masked_side = None
         # Fusing BN-apply+ReLU into the CONSUMER conv's operand prologue saves one write+read of the normalised
         # activation, but the transform is then repeated for every tap and every Cout tile (18x for a 3x3 256->256
         # conv): measured on MI355X it costs ~2x the kernel time, far more than the single elementwise pass it saves.
@@ -987,7 +991,10 @@ class FEEngine:
         use_side = self._side_ok()
         if use_side and self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
-        if self._run_list(plan, "bwd%d" % acc, stream, self.side.cuda_stream if use_side else 0,
+        side_handle = self.side.cuda_stream if use_side else 0
+        if use_side and self.side_cus != 0 and self.c_plan:
+            side_handle = self._cu_masked_stream()
+        if self._run_list(plan, "bwd%d" % acc, stream, side_handle,
                           (lambda off: hook(off)) if hook is not None else None, 2 * plan.meta.get("n_side", 0)):
             return
         if use_side:
@@ -1015,6 +1022,27 @@ class FEEngine:
                     main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)
+
+    def _cu_masked_stream(self):
+        """raw hipStream_t limited to self.side_cus compute units (created once; used by the C plan executor only)"""
+        if self._masked_side is None:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            n = max(1, min(256, self.side_cus))
+            step = 256.0 / n
+            words = (ctypes.c_uint32 * 8)()
+            for i in range(n):
+                b = int(i * step)
+                words[b // 32] |= 1 << (b % 32)
+            h = ctypes.c_void_p()
+            if self.side_cus < 0:   # (experiment: a plain non-blocking stream created outside torch)
+                rc = hip.hipStreamCreateWithFlags(ctypes.byref(h), 1)
+            else:
+                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+            if rc != 0 or not h.value:
+                raise PfrError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+            self._masked_side = h.value
+        return self._masked_side
 
     def backward(self, demb, plan=None):
         plan = plan if plan is not None else self._last_plan

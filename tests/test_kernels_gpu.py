@@ -552,3 +552,33 @@ def test_streaming_1x1_kernel_bit_identical(case):
     for y, st in outs[1:]:
         assert torch.equal(y, outs[0][0])
     assert torch.allclose(outs[2][1], outs[0][1], rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 56, 64, 256), (3, 28, 128, 512), (5, 14, 256, 1024), (2, 56, 256, 64), (1, 9, 64, 64), (4, 28, 512, 128)])
+def test_streaming_1x1_residual_join_bit_identical(case):
+    """pfr_conv2d_dgrad_join (dx = dgrad(dy) + res where the block's ReLU bit is set) through the streaming kernel's join variant
+    (residual / mask rows prefetched by hand-counted loads) vs the tile kernel, bit for bit, and vs torch."""
+    from pets_face_recognition_amd._hip import lib
+    N, H, C, Co = case
+    g = torch.Generator().manual_seed(H * C + Co + 1)
+    dy = torch.randn(N, H, H, C, generator=g).to(DEV).bfloat16()
+    wt = (torch.randn(Co, 1, 1, C, generator=g) / C ** 0.5).to(DEV).bfloat16()
+    res = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16()
+    mask = torch.randint(0, 256, (N * H * H, Co // 8), generator=g, dtype=torch.uint8).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        for mode in (0, 2):
+            lib.pfr_set_tuning(b"sconv", mode)
+            dx = torch.full((N, H, H, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
+            lib.pfr_conv2d_dgrad_join(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H, res.data_ptr(),
+                                      mask.data_ptr(), st)
+            torch.cuda.synchronize()
+            outs.append(dx)
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+    bits = ((mask.unsqueeze(-1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(N, H, H, Co).float()
+    core = (dy.float().reshape(-1, C) @ wt.float().reshape(Co, C).t()).bfloat16().float().reshape(N, H, H, Co)
+    ref = (core + res.float() * bits).bfloat16()
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[1].float() - ref.float()).abs().max() <= 2e-2 * ref.float().abs().max()

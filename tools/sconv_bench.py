@@ -43,3 +43,35 @@ for H, C, Co, sd, cnt in GEOMS:
     tot[0] += res[0] * cnt; tot[1] += res[1] * cnt
     print(f"{H:3d}^2 {C:4d}->{Co:4d} s{sd}: tile {res[0]:7.1f} us  sconv {res[1]:7.1f} us  ({nbytes / res[1] / 1e6:5.2f} TB/s, HBM floor @6.3 {nbytes / 6.3e6:6.1f} us)  x{cnt}  identical={same}")
 print(f"per step: tile {tot[0] / 1e3:.3f} ms, sconv {tot[1] / 1e3:.3f} ms")
+
+# residual-join data gradients (pfr_conv2d_dgrad_join) of the identity blocks
+print("dgrad_join:")
+tot = [0.0, 0.0]
+st = torch.cuda.current_stream().cuda_stream
+for H, C, Co, cnt in [(56, 64, 256, 2), (28, 128, 512, 3), (14, 256, 1024, 5)]:
+    dy = torch.randn(N, H, H, C, device=dev).bfloat16()
+    wt = (torch.randn(Co, 1, 1, C, device=dev) / C ** 0.5).bfloat16()
+    rs = torch.randn(N, H, H, Co, device=dev).bfloat16()
+    mk = torch.randint(0, 256, (N * H * H, Co // 8), device=dev, dtype=torch.uint8)
+    dx = torch.empty(N, H, H, Co, device=dev, dtype=torch.bfloat16)
+    res, ys = [], []
+    for mode in (0, 2):
+        lib.pfr_set_tuning(b"sconv", mode)
+        call = lambda: lib.pfr_conv2d_dgrad_join(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H, rs.data_ptr(), mk.data_ptr(), st)
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 20 * 1e3)
+        ys.append(dx.clone())
+    lib.pfr_set_tuning(b"sconv", 1)
+    M = N * H * H
+    nbytes = M * C * 2 + 2 * M * Co * 2 + M * Co // 8
+    tot[0] += res[0] * cnt; tot[1] += res[1] * cnt
+    print(f"{H:3d}^2 {C:4d}->{Co:4d}: tile {res[0]:7.1f} us  sconv {res[1]:7.1f} us  ({nbytes / res[1] / 1e6:5.2f} TB/s, HBM floor @6.3 {nbytes / 6.3e6:6.1f} us)  x{cnt}  identical={torch.equal(ys[0], ys[1])}")
+print(f"per step: tile {tot[0] / 1e3:.3f} ms, sconv {tot[1] / 1e3:.3f} ms")
