@@ -14,10 +14,17 @@ from data_loading import SyntheticRecDataset, RecSubset, PairGenerator
 from losses import SoftmaxBasedMetricLearning
 
 
+
+def _rank():
+    """data-parallel rank of this process (torchrun), 0 otherwise: the reference's dataloader workers draw their augmentation
+    decisions from per-worker / per-rank seeds, so the ranks must not share one decision stream"""
+    import os
+    return int(os.environ.get("RANK", "0"))
+
 def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs, device, n_epochs=1, seed=0,
-         fused_optimizer=True, compute_dtype=None, limit_train_batches=None, workers=0, n_pairs=200, device_augment=False):
+         fused_optimizer=True, compute_dtype=None, limit_train_batches=None, workers=0, n_pairs=200, device_augment=False, noise=0.15):
     torch.manual_seed(seed)
-    dataset = SyntheticRecDataset(n_train_ids + n_val_ids, photos, image_size, seed=seed, raw_uint8=device_augment)
+    dataset = SyntheticRecDataset(n_train_ids + n_val_ids, photos, image_size, seed=seed, noise=noise, raw_uint8=device_augment)
     train_users = list(range(n_train_ids))
     val_users = list(range(n_train_ids, n_train_ids + n_val_ids))
     labels = dataset.get_labels()
@@ -42,6 +49,8 @@ def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs
 
     def model():
         kw = {} if compute_dtype is None else {'compute_dtype': compute_dtype}
+        if arch.startswith('swin'):   # the reference's own backbone (models/swin.py:228-241): `mlp_head` IS the 512-d embedding layer
+            return getattr(models, arch)(num_classes=512, **kw)
         model_ = getattr(models, arch)(**kw)
         model_.fc = torch.nn.Linear(model_.fc.in_features, 512)
         return model_
@@ -56,7 +65,8 @@ def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs
         params2 = [p for i, p in model_.module.named_parameters() if 'fc' in i]
         d = [{'lr': 10 ** -2 / 2, 'params': params1},
              {'lr': 10 ** -2, 'params': params2},
-             {'lr': 10 ** -2, 'params': model_.add_margin.parameters(), 'weight_decay': 1 * (10 ** -4)}]
+             {'lr': 10 ** -2, 'params': list(model_.add_margin.parameters()), 'weight_decay': 1 * (10 ** -4)}]
+        d = [g for g in d if len(g['params'])]   # (a backbone without an `fc` layer — Swin's embedding layer is `mlp_head` — has no second group)
         if fused_optimizer and device != 'cpu':
             from optim import FusedSGD
             optim = FusedSGD(d, 0.01, momentum=0.9)
@@ -75,7 +85,7 @@ def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs
         # the reference's train/val Compose pipelines (fe_dogs_config.py:17-32) applied on the device to uint8 batches
         from data_loading import DeviceAugmentation, val_augmentation
         ns['device_train_augmentation'] = DeviceAugmentation((image_size - 4, image_size - 4), (image_size, image_size), 0.1, 0.3,
-                                                             5.0, torch.Generator().manual_seed(seed))
+                                                             5.0, torch.Generator().manual_seed(seed + _rank()))
         ns['device_val_augmentation'] = val_augmentation()
     output = Path('results')
     output.mkdir(exist_ok=True)

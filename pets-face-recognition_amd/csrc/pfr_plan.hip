@@ -106,6 +106,12 @@ extern "C" int pfr_plan_run(void* plan, int begin, int end, pfr_stream_t main_st
           attached = i + 1;
         }
         const int rc = g_thunks[op.thunk].fn(op.a, (op.kind == 1 && use_side) ? (void*)ss : (void*)ms);
+        // the launch clears the thread-local when it attaches the event; if it returned before that point (argument error) the
+        // event is NOT attached: disarm it so that no later launch of this thread picks up a foreign plan's event
+        if (pfr_tls_stop_event != nullptr) {
+          pfr_tls_stop_event = nullptr;
+          attached = -1;
+        }
         if (rc != PFR_OK) return rc <= -2 ? rc : -2 + (rc < 0 ? rc : 0) - 1;
         break;
       }

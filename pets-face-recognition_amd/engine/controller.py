@@ -35,6 +35,19 @@ class Controller(nn.Module):
     def forward(self, *args, **kwargs):
         return self.model_loss(*args, **kwargs)
 
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, config=None, map_location='cpu', strict=True, **_):
+        """`Controller.load_from_checkpoint(path, config=get_dict_wrapper(cfg.py))` — how the reference's inference consumers get
+        their FE models (generate_tsv.py:158-176, eval_fe_*.py).  Reads this package's checkpoints (a plain state dict with the
+        reference's key names) and pytorch-lightning ones ({'state_dict': …}); the result is in eval()-ready train mode like PL's."""
+        if config is None:
+            raise ValueError("load_from_checkpoint needs config=… (the module is rebuilt from config.model() / config.loss())")
+        ckpt = torch.load(str(checkpoint_path), map_location=map_location)
+        sd = ckpt.get('state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
+        self = cls(config)
+        self.load_state_dict(sd, strict=strict)
+        return self
+
     # ------------------------------------------------------------------ steps
     def _images(self, x, train):
         """uint8 [N, H, W, 3] batches are raw frames: the config's device-side Compose pipeline (the reference's
@@ -144,14 +157,15 @@ class Controller(nn.Module):
         return d
 
     def _plot_confmat(self, name, cm):
-        try:
-            import matplotlib
-            matplotlib.use('Agg')
-            import matplotlib.pyplot as plt
+        try:   # an Agg canvas of its own: library code must not switch the process-wide matplotlib backend
+            from matplotlib.figure import Figure
+            from matplotlib.backends.backend_agg import FigureCanvasAgg
         except ImportError:
             return
         mat = [[cm['tn'], cm['fp']], [cm['fn'], cm['tp']]]
-        fig, ax = plt.subplots()
+        fig = Figure()
+        FigureCanvasAgg(fig)
+        ax = fig.subplots()
         ax.imshow(mat, cmap='viridis')
         for r in range(2):
             for c in range(2):
@@ -159,23 +173,22 @@ class Controller(nn.Module):
         ax.set_xticks([0, 1]); ax.set_yticks([0, 1])
         ax.set_xlabel('Predicted label'); ax.set_ylabel('True label')
         fig.savefig(self._img_dir() / f' {name}_confmat_{self.current_epoch}.png')
-        plt.close(fig)
 
     def _plot_rocs(self, rocs):
         try:
-            import matplotlib
-            matplotlib.use('Agg')
-            import matplotlib.pyplot as plt
+            from matplotlib.figure import Figure
+            from matplotlib.backends.backend_agg import FigureCanvasAgg
         except ImportError:
             return
-        fig = plt.figure(figsize=(10, 10))
+        fig = Figure(figsize=(10, 10))
+        FigureCanvasAgg(fig)
+        ax = fig.subplots()
         for fpr, tpr, auc, name in rocs:
-            plt.plot(fpr, tpr, label=f'{name} AUC = {auc}', linewidth=3)
-        plt.plot([0, 1], [0, 1], 'k--', linewidth=3)
-        plt.xlabel('False positive rate'); plt.ylabel('True positive rate')
-        plt.title('ROC curves'); plt.grid(); plt.legend()
+            ax.plot(fpr, tpr, label=f'{name} AUC = {auc}', linewidth=3)
+        ax.plot([0, 1], [0, 1], 'k--', linewidth=3)
+        ax.set_xlabel('False positive rate'); ax.set_ylabel('True positive rate')
+        ax.set_title('ROC curves'); ax.grid(); ax.legend()
         fig.savefig(self._img_dir() / f'roc_{self.current_epoch}.png')
-        plt.close(fig)
 
     def _log(self, name, metrics):
         if self.logger is not None and hasattr(self.logger, 'log_metrics'):

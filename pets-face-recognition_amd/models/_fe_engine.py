@@ -1058,6 +1058,11 @@ class FEEngine:
         plan.meta["owner"] = None
         # gradients are final (DDP bucket hook) only when no other forward pass still waits for its backward
         hook = self.grad_ready_hook if not any(self._plan_busy(q) for q in self.plans.values()) else None
+        if hook is None and self.grad_ready_hook is not None and not getattr(self, "_warned_hook", False):
+            import warnings
+            self._warned_hook = True
+            warnings.warn("FEEngine.backward: another forward pass of this model still holds its activations (a retained autograd "
+                          "graph?), so gradient buckets are reduced after the backward pass instead of overlapped with it")
         main = torch.cuda.current_stream()
         if self.wt_pending:
             main.wait_event(self.wt_ready)

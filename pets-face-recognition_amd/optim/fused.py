@@ -23,10 +23,19 @@ class _FusedBase(torch.optim.Optimizer):
 
     def _group_runs(self, gi, group):
         params = [p for p in group["params"] if p.grad is not None]
-        sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr()) for p in params)
+        # the state layout follows the PARAMETERS; a gradient that autograd re-allocated (the ArcFace head's, 20 MB) only moves
+        # the run's gradient view — it must not rebuild (re-allocate and copy) every state buffer of the group
+        sig = tuple((id(p), p.data_ptr()) for p in params)
+        gsig = tuple(p.grad.data_ptr() for p in params)
         cached = self._runs.get(gi)
         if cached is not None and cached[0] == sig:
-            return cached[1]
+            if cached[2] != gsig:
+                if not self._rebind_grads(cached[1]):
+                    cached = None
+                else:
+                    self._runs[gi] = (sig, cached[1], gsig)
+            if cached is not None:
+                return cached[1]
         if any(not p.is_cuda for p in params):
             raise PfrError("fused optimizers need CUDA parameters (use torch.optim on the CPU path)")
         runs = self._build_runs(params)
@@ -42,8 +51,26 @@ class _FusedBase(torch.optim.Optimizer):
                     if old is not None:
                         view.copy_(old.to(dev))     # carried over (loaded checkpoint, or a previous buffer layout)
                     st[k] = view
-        self._runs[gi] = (sig, runs)
+        self._runs[gi] = (sig, runs, gsig)
         return runs
+
+    def _rebind_grads(self, runs):
+        """gradient tensors moved: re-point the flat gradient view of every run (False: the members' gradients no longer form
+        the same dense run, rebuild everything)"""
+        for r in runs:
+            p0, _ = r["members"][0]
+            sp = self._storage_span(p0.grad)
+            if sp is None:
+                return False
+            gs = sp[0]
+            for p, off in r["members"]:
+                s2 = self._storage_span(p.grad)
+                if s2 is None or s2[0] != gs + 4 * off or p.grad.untyped_storage().data_ptr() != p0.grad.untyped_storage().data_ptr():
+                    return False
+            goff = (gs - p0.grad.untyped_storage().data_ptr()) // 4
+            r["gs"], r["ge"], r["gbase"] = gs, gs + 4 * r["n"], p0.grad.untyped_storage().data_ptr()
+            r["gf"] = torch.empty(0, dtype=torch.float32, device=p0.device).set_(p0.grad.untyped_storage(), goff, (r["n"],), (1,))
+        return True
 
     def _build_runs(self, params):
         """→ runs covering `params` with as few flat tensors as possible.  Neighbours are merged only across the engine's
@@ -62,14 +89,17 @@ class _FusedBase(torch.optim.Optimizer):
         runs = []
         for (pa, pn), (ga, gn), p in dense:
             r = runs[-1] if runs else None
-            if r is not None and 0 <= pa - r["pe"] < 256 and (ga - r["ge"]) == (pa - r["pe"]) \
+            # merge only across the engine's alignment padding of the PREVIOUS member ((-numel) % 64 floats): a small parameter
+            # of another group (or a frozen one) lying in a larger gap must not be swallowed into this group's update
+            if r is not None and pa - r["pe"] == 4 * ((-r["last_n"]) % 64) and (ga - r["ge"]) == (pa - r["pe"]) \
                     and r["pbase"] == p.data.untyped_storage().data_ptr() \
                     and r["gbase"] == p.grad.untyped_storage().data_ptr():
                 r["members"].append((p, (pa - r["ps"]) // 4))
                 r["pe"] = pa + 4 * pn
                 r["ge"] = ga + 4 * pn
+                r["last_n"] = pn
             else:
-                runs.append({"ps": pa, "pe": pa + 4 * pn, "gs": ga, "ge": ga + 4 * pn, "p": p, "members": [(p, 0)],
+                runs.append({"ps": pa, "pe": pa + 4 * pn, "gs": ga, "ge": ga + 4 * pn, "p": p, "members": [(p, 0)], "last_n": pn,
                              "pbase": p.data.untyped_storage().data_ptr(), "gbase": p.grad.untyped_storage().data_ptr()})
         for r in runs:
             n = (r["pe"] - r["ps"]) // 4

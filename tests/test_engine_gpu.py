@@ -342,3 +342,76 @@ def test_flat_ddp_world2_equals_mean_of_shard_gradients(tmp_path):
     the all-reduced gradients equal the mean of the per-shard single-GPU gradients to 1e-6 (ResNet-18 and Swin-T), the
     engine reports exactly grad_ready_marks(), every element is reduced once.  Reference: utils/__init__.py:114-119."""
     _run_ddp_n(tmp_path, 2, 29553)
+
+
+def test_integration_md_binding_blocks_run_against_the_library():
+    """The reference-side ctypes stub printed in INTEGRATION.md §2 is executed as written (only the library path is resolved)
+    and compared with the package's own wrappers: a documented binding that drifts from include/pfr_hip.h fails here."""
+    import os, re
+    import torch
+    from pets_face_recognition_amd._hip import ops, lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = md.split("## 2. Binding the C-ABI directly")[1].split("\n## ")[0]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert blocks, "no python block in INTEGRATION.md §2"
+    so = os.path.join(root, "pets-face-recognition_amd", "csrc", "libpfr_hip.so")
+    ns = {}
+    exec(blocks[0].replace('"libpfr_hip.so"', repr(so)), ns)
+    # argument counts of the documented stubs equal the header's
+    for name in ("pfr_conv2d_fwd", "pfr_margin_ce"):
+        proto = re.search(r"int %s\((.*?)\);" % name, open(os.path.join(root, "include", "pfr_hip.h")).read(), flags=re.S).group(1)
+        assert len(getattr(ns["_lib"], name).argtypes) == len(proto.split(",")), name
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 12, 12, 32, generator=g).cuda().bfloat16()
+    w = (torch.randn(64, 3, 3, 32, generator=g) * 0.1).cuda().bfloat16()
+    y = ns["conv2d_nhwc"](x, w, 1, 1)
+    y2, _ = ops.conv2d_fwd(x, w, stride=1, pad=1)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    from oracle import arcface_ref
+    xe, we = torch.randn(8, 16, generator=g), torch.randn(50, 16, generator=g)
+    lab = torch.randint(0, 50, (8,), generator=g)
+    cos = arcface_ref.cosine(xe, we)
+    logits, loss = ns["arcface_ce"](cos.cuda().contiguous(), lab.cuda())
+    torch.cuda.synchronize()
+    ref = arcface_ref.arc_margin_logits(xe, we, lab, 64.0, 0.5, False)
+    assert torch.allclose(logits.cpu(), ref, atol=2e-4)
+    assert abs(loss.item() - arcface_ref.focal_loss(ref, lab).item()) < 1e-4
+
+
+def test_main_swin_t_config_and_load_from_checkpoint(tmp_path):
+    """BASELINE config 4 through the drop-in CLI (`main.py --config`, Swin-T backbone of models/swin.py) at a small size, then
+    `Controller.load_from_checkpoint(path, config=…)` as the reference's inference scripts use it (generate_tsv.py:158-176)."""
+    cfg = tmp_path / "fe_small_swin.py"
+    common = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic")
+    cfg.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {common!r})
+        from _common import make as _make
+        _make(globals(), arch='swin_t', n_train_ids=16, n_val_ids=8, photos=4, image_size=224, train_bs=8, test_bs=8,
+              device='cuda:0', n_epochs=1, n_pairs=20)
+    """))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", str(cfg)], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "Completed!" in r.stdout and "Val Recall@K=10" in r.stdout
+    import torch
+    sys.path.insert(0, ROOT)
+    import pets_face_recognition_amd as pfr
+    pfr.install_reference_aliases()
+    from pets_face_recognition_amd.utils import get_dict_wrapper
+    from pets_face_recognition_amd.engine import Controller
+    run = list((tmp_path / "results").iterdir())[0]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        ctl = Controller.load_from_checkpoint(run / "checkpoints" / "epoch=0.ckpt", config=get_dict_wrapper(str(cfg)))
+    finally:
+        os.chdir(cwd)
+    sd = torch.load(run / "checkpoints" / "epoch=0.ckpt", map_location="cpu")
+    ml = ctl.eval().model_loss.to("cuda:0")
+    assert torch.equal(ml.state_dict()["module.mlp_head.1.weight"].cpu(), sd["model_loss.module.mlp_head.1.weight"])
+    with torch.no_grad():
+        emb = ml(torch.rand(2, 3, 224, 224, device="cuda:0"))
+    assert emb.shape == (2, 512) and torch.isfinite(emb).all()

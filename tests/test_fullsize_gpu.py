@@ -101,3 +101,45 @@ def test_swin_t_bs128_separable_and_linear():
     for n in a:
         assert torch.isfinite(a[n]).all(), n
         assert torch.equal(b[n], 2.0 * a[n]), n
+
+
+def _config5_data(Q, G, D=512, seed=123, sigma=3.2):
+    """the synthetic config-5 set of tools/bench_match.py: 10 photos per class, centre + sigma * N(0, 1)"""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    ncls = G // 10
+    centers = torch.randn(ncls, D, device=DEV, generator=g)
+    gcls = torch.arange(ncls, device=DEV).repeat_interleave(10)[:G]
+    gcls = gcls[torch.randperm(G, device=DEV, generator=g)]
+    gal = centers[gcls] + sigma * torch.randn(G, D, device=DEV, generator=g)
+    qcls = torch.randint(0, ncls, (Q,), device=DEV, generator=g)
+    qry = centers[qcls] + sigma * torch.randn(Q, D, device=DEV, generator=g)
+    return qry, gal
+
+
+def test_config5_top100_vs_fp64_oracle_on_the_1m_gallery():
+    """64 queries against the 1 000 000-row config-5 gallery: the top-100 SET of the bf16 + fp32-re-score path and of the f32
+    path must equal the fp64 CPU ranking (oracle/match_ref.topk_query_gallery restated in float64, chunked), except for
+    entries whose fp64 score lies within 1e-6 of the fp64 score at rank 100 (a genuine near-tie at the cut)."""
+    from pets_face_recognition_amd.match import cosine_topk
+    Q, G, K = 64, 1000000, 100
+    qry, gal = _config5_data(Q, G)
+    q64 = torch.nn.functional.normalize(qry.double().cpu(), dim=1)
+    scores = torch.empty(Q, G, dtype=torch.float64)
+    for lo in range(0, G, 125000):
+        gc = torch.nn.functional.normalize(gal[lo:lo + 125000].double().cpu(), dim=1)
+        scores[:, lo:lo + 125000] = q64 @ gc.t()
+    ref_sc, ref_ix = torch.topk(scores, K + 1, dim=1)
+    cut = ref_sc[:, K - 1]
+    for dt in (torch.bfloat16, torch.float32):
+        sc, idx = cosine_topk(qry, gal, K, compute_dtype=dt)
+        idx = idx.long().cpu()
+        assert (idx >= 0).all()
+        nd = 0
+        for q in range(Q):
+            got, want = set(idx[q].tolist()), set(ref_ix[q, :K].tolist())
+            for j in got ^ want:          # every disagreement must be a near-tie at the cut
+                nd += 1
+                assert abs(scores[q, j].item() - cut[q].item()) < 1e-6, (dt, q, j, scores[q, j].item(), cut[q].item())
+        # scores are the fp32 cosines of the returned rows
+        assert (sc.cpu().double() - torch.gather(scores, 1, idx)).abs().max() < 5e-6
+        assert nd <= 4

@@ -1,0 +1,22 @@
+#!/bin/bash
+# wait / busy counters of the forward GEMM kernels on selected geometries (fw_one.py cases)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for c in "$@"; do
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
+  rm -rf /tmp/pm
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pm -o pm -- python $R/tools/scratch/fw_one.py $c > /tmp/pm.log 2>&1
+  f=$(find /tmp/pm -name "*counter_collection.csv" | head -1)
+  python - "$f" case_$c <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in rows:
+    k = r['Kernel_Name'][:70]
+    if 'igemm' not in k and 'sconv' not in k: continue
+    acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+for k, d in acc.items():
+    n = sum(1 for r in rows if r['Kernel_Name'][:70] == k and r['Counter_Name'] == list(d)[0])
+    print(sys.argv[2], k, 'disp', n, {c: round(v / n) for c, v in d.items()})
+PY
+done; done
