@@ -66,10 +66,13 @@ int pfr_plan_run(void* plan, int begin, int end, pfr_stream_t main_stream, pfr_s
  *   bias [Cout] fp32 or NULL; residual [M][ldy] (y's dtype) or NULL: y = result + bias + residual;
  *   accumulate: y += result; out_relu: y = max(y,0)
  *   pro_scale/pro_shift [C] fp32 or NULL: operand is relu?(scale[c]*x + shift[c]) (fused BN-apply of the producer)
- *   stats_part or NULL: fp32 [ceil(M/mtile)][2][Cout] per-channel (mean, M2 = Σ(y-mean)²) of each m-tile of the stored y,
- *   mtile = pfr_conv2d_mtile(M, Cout, R*S*C, C, dtype, out_dtype, pro_scale != 0)  (input of pfr_bn_finalize; deterministic, no atomics):
- *   the m-tile height of the kernel that takes this geometry, or half of it for the persistent kernel (one partial per wave row). */
-int pfr_conv2d_mtile(int M, int Cout, int K, int C, int dtype, int out_dtype, int fused_prologue); /* K = R*S*C */
+ *   stats_part or NULL: fp32 [ceil(M/mtile)][2][Cout] per-channel (mean, M2 = Σ(y-mean)²) of row groups of the stored y,
+ *   mtile = pfr_conv2d_mtile(<the launch's geometry>, pro_scale != 0)  (input of pfr_bn_finalize; deterministic, no atomics):
+ *   the m-tile height of the tile kernel that takes this geometry, half of it for the persistent kernel (one partial per wave row),
+ *   or the rows of one workgroup's share for the streaming kernels (pfr_sconv.hip: a row range; pfr_sconv3.hip: 4x8-pixel patches
+ *   in patch order) — pfr_bn_finalize only needs every group's row count, which is min(mtile, M - t*mtile) in all cases. */
+int pfr_conv2d_mtile(int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad, int OH, int OW, int dtype,
+                     int out_dtype, int fused_prologue);
 /* the same query for pfr_gemm_act_colstats (a launch with an activation epilogue always takes the tile kernel) */
 int pfr_gemm_act_mtile(long M, int K, int N, int dtype);
 int pfr_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W, int C,

@@ -49,8 +49,9 @@ def conv2d_fwd(x, w, stride=1, pad=0, idil_log2=0, out_hw=None, out=None, out_dt
     M = N * OH * OW
     part = None
     if stats:
-        mt = lib.pfr_conv2d_mtile(M, Cout, R * S * C, C, dtype_id(x.dtype), dtype_id(out.dtype), int(pro is not None))
+        mt = lib.pfr_conv2d_mtile(N, H, W, C, Cout, R, S, stride, pad, OH, OW, dtype_id(x.dtype), dtype_id(out.dtype), int(pro is not None))
         nt = (M + mt - 1) // mt
+        conv2d_fwd.last_mt = mt     # (rows per statistics partial of this launch: what pfr_bn_finalize needs as rows_per_part)
         part = stats_buf if stats_buf is not None else torch.empty((nt, 2, Cout), dtype=torch.float32, device=x.device)
         assert part.numel() >= nt * 2 * Cout
     ps = psh = None

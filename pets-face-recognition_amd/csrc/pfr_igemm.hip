@@ -759,7 +759,9 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
   const bool stats_postop = p.stats_part && (p.bias || p.act || p.accumulate || p.residual || p.out_relu);
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
     if (!stats_postop) {
-      const int rc = sconv_try_launch(p, dtype, out_dtype, st);
+      int rc = sconv3_try_launch(p, dtype, out_dtype, st);
+      if (rc != 1) return rc;
+      rc = sconv_try_launch(p, dtype, out_dtype, st);
       if (rc != 1) return rc;
     }
   }
@@ -786,11 +788,18 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
 
 // rows per BatchNorm-statistics partial of a convolution launch with this geometry (the caller sizes stats_part with it):
 // the m-tile height, or half of it when the persistent kernel (one partial per wave row) takes the launch
-extern "C" int pfr_conv2d_mtile(int M, int Cout, int K, int C, int dtype, int out_dtype, int fused_prologue) {
+extern "C" int pfr_conv2d_mtile(int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad, int OH, int OW, int dtype,
+                                int out_dtype, int fused_prologue) {
+  const int M = N * OH * OW, K = R * S * C;
   int bq, bp;
-  if (K == C && !fused_prologue) {   // 1x1: the streaming kernel publishes one partial per workgroup row range
-    const int mt = sconv_mtile(M, Cout, K, dtype, out_dtype);
-    if (mt) return mt;
+  if (!fused_prologue) {
+    int bpw;
+    if (sconv3_geom(N, H, W, C, Cout, R, S, stride, pad, 0, OH, OW, dtype, out_dtype, &bpw)) return bpw * 32;
+    if (R == 1 && S == 1 && pad == 0 && (stride == 1 || (H == OH * stride && W == OW * stride))) {
+      // 1x1: the streaming kernel publishes one partial per workgroup row range
+      const int mt = sconv_mtile(M, Cout, K, dtype, out_dtype);
+      if (mt) return mt;
+    }
   }
   if (pick_ws(M, Cout, K, C, dtype, out_dtype, fused_prologue)) return 64;   // one partial per memory wave (64 rows)
   // (statistics and the parity-class mode exclude each other, so the heuristic never picks the persistent kernel for a

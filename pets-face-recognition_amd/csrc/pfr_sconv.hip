@@ -399,9 +399,10 @@ bool sconv_plan(int M, int N, int K, int dtype, int out_dtype, SconvPlan* sp) {
   if (!np) return false;
   const int npanels = N / np;
   if (npanels > 32 || (256 % npanels) != 0) return false;
-  // re-reading x once per panel must stay cheaper than what the tile kernels do: at most 8 panels, and K <= 256 unless 2 panels
+  // re-reading x once per panel (from L2: the panels of a row range run on one XCD) must stay cheaper than what the tile kernels do
   if (mode == 1) {
-    if (npanels > 8 || (K == 512 && npanels > 2)) return false;
+    // (measured, tools/sconv_bench.py: K = 512 with 4 panels 81 vs 94 us for the tile kernel, with 16 panels 68-72 vs 76-78)
+    if (npanels > 16 || (K < 512 && npanels > 8)) return false;
     if (M < 256 * 64) return false;    // too few rows per workgroup for a pipeline
   }
   int nranges = 256 / npanels;

@@ -480,10 +480,12 @@ class FEEngine:
                                          0 if bias is None else bias.data_ptr(), 0, accumulate, 0, ps, psh, prelu,
                                          0 if part is None else part.data_ptr())))
 
-    def _stats_buf(self, plan, M, Cout, K, C, pro=False):
-        mt = lib.pfr_conv2d_mtile(M, Cout, K, C, self.did, self.did, int(pro))
+    def _stats_buf(self, plan, xshape, c, OH, OW, pro=False):
+        N, H, W, C = xshape
+        M = N * OH * OW
+        mt = lib.pfr_conv2d_mtile(N, H, W, C, c.Cout, c.R, c.S, c.stride, c.pad, OH, OW, self.did, self.did, int(pro))
         nt = (M + mt - 1) // mt
-        return self._A(plan, (nt, 2, Cout), torch.float32), nt, mt
+        return self._A(plan, (nt, 2, c.Cout), torch.float32), nt, mt
 
     def _bn_fwd(self, ops, bn, part, nparts, count, train, mt=0):
         if train:
@@ -505,7 +507,7 @@ class FEEngine:
         y = self._A(plan, (N, OH, OW, c.Cout))
         part, nt, mt = (None, 0, 0)
         if train:
-            part, nt, mt = self._stats_buf(plan, N * OH * OW, c.Cout, c.R * c.S * C, C, pro is not None)
+            part, nt, mt = self._stats_buf(plan, xshape, c, OH, OW, pro is not None)
         self._conv_fwd(ops, x, xshape, w if w is not None else c.w, y, c, c.stride, c.pad, OH, OW, pro=pro, part=part)
         self._bn_fwd(ops, bn, part, nt, N * OH * OW, train, mt)
         return y, (N, OH, OW, c.Cout)

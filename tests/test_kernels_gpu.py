@@ -74,7 +74,9 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     # fused per-channel statistics (per-m-tile mean / M2, merged by pfr_bn_finalize) of the stored output
     from pets_face_recognition_amd._hip import lib
     M = yd.numel() // Cout
-    coef = o.bn_finalize(part, lib.pfr_conv2d_mtile(M, Cout, R * R * C, C, 0 if dtype == torch.float32 else 1, 0 if dtype == torch.float32 else 1, 0), M, None, None, 1e-5, 0.1, None, None)
+    did = 0 if dtype == torch.float32 else 1
+    part_mt = lib.pfr_conv2d_mtile(N, H, W, C, Cout, R, R, stride, pad, yd.shape[1], yd.shape[2], did, did, 0)
+    coef = o.bn_finalize(part, part_mt, M, None, None, 1e-5, 0.1, None, None)
     torch.cuda.synchronize()
     ydf = yd.double().cpu().reshape(-1, Cout)
     assert torch.allclose(coef[0].cpu().double(), ydf.mean(0), rtol=1e-4, atol=1e-5)
@@ -426,7 +428,8 @@ def test_alternative_gemm_kernels_bit_identical(case):
             st = None
             if part is not None:
                 M = y.numel() // Co
-                mt = lib.pfr_conv2d_mtile(M, Co, R * R * C, C, 1, 1, 0)
+                OHH = y.shape[1]
+                mt = lib.pfr_conv2d_mtile(N, H, H, C, Co, R, R, sd, pad, OHH, OHH, 1, 1, 0)
                 st = o.bn_finalize(part, mt, M, None, None, 1e-5, 0.1, None, None)[:2].clone()
             torch.cuda.synchronize()
             outs.append((y.clone(), st))
@@ -541,7 +544,7 @@ def test_streaming_1x1_kernel_bit_identical(case):
                 st = None
                 if part is not None:
                     M = y.numel() // Co
-                    mt = lib.pfr_conv2d_mtile(M, Co, C, C, 1, 1, 0)
+                    mt = lib.pfr_conv2d_mtile(N, H, H, C, Co, 1, 1, sd, 0, y.shape[1], y.shape[2], 1, 1, 0)
                     st = o.bn_finalize(part, mt, M, None, None, 1e-5, 0.1, None, None)[:2].clone()
                 torch.cuda.synchronize()
                 outs.append((y.clone(), st))
@@ -582,3 +585,38 @@ def test_streaming_1x1_residual_join_bit_identical(case):
     ref = (core + res.float() * bits).bfloat16()
     assert torch.equal(outs[0], outs[1])
     assert (outs[1].float() - ref.float()).abs().max() <= 2e-2 * ref.float().abs().max()
+
+
+@pytest.mark.parametrize("case", [(2, 56, 56), (3, 16, 16), (1, 8, 8), (2, 12, 16), (5, 24, 40), (1, 4, 8), (9, 28, 32)])
+def test_halo_staged_3x3_kernel_bit_identical(case):
+    """pfr_sconv3.hip (64 -> 64 channels, 3x3 / stride 1 / pad 1: weights resident in LDS, one 6x10-pixel halo tile per 4x8 patch,
+    nine taps read from it) must reproduce the implicit-GEMM tile kernel BIT FOR BIT — forward with BatchNorm statistics, forward
+    without, and as data gradient (tap-flipped weights) — and match torch."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, W = case
+    g = torch.Generator().manual_seed(H * W + N)
+    x = torch.randn(N, H, W, 64, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(64, 3, 3, 64, generator=g) / 24.0).to(DEV).bfloat16()
+    wt = o.weight_dgrad_layout(w)
+    outs = []
+    try:
+        for mode in (0, 2):
+            lib.pfr_set_tuning(b"sconv", mode)
+            y, part = o.conv2d_fwd(x, w, stride=1, pad=1, stats=True)
+            mt = lib.pfr_conv2d_mtile(N, H, W, 64, 64, 3, 3, 1, 1, H, W, 1, 1, 0)
+            st = o.bn_finalize(part, mt, N * H * W, None, None, 1e-5, 0.1, None, None)[:2].clone()
+            y2, _ = o.conv2d_fwd(x, w, stride=1, pad=1, stats=False)
+            dx = o.conv2d_dgrad(x, wt, (H, W), 1, 1, 3, 3)
+            torch.cuda.synchronize()
+            outs.append((y.clone(), st, y2.clone(), dx.clone()))
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+    xf, wf = x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xf, wf, padding=1).permute(0, 2, 3, 1)
+    assert (outs[0][0].float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    refd = torch.nn.functional.conv_transpose2d(xf, wf, padding=1).permute(0, 2, 3, 1)
+    assert (outs[0][3].float() - refd).abs().max() <= 2e-2 * refd.abs().max()
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][2], outs[0][2]) and torch.equal(outs[1][3], outs[0][3])
+    assert torch.equal(outs[1][0], outs[1][2])
+    assert torch.allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=1e-5)

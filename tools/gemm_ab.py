@@ -57,13 +57,13 @@ for kind, H, C, Co, R, s, dil, n in cases:
             refstat = None
             if part is not None:
                 M = y.numel() // Co
-                mt = lib.pfr_conv2d_mtile(M, Co, R * R * C, C, 1, 1, 0)
+                mt = ops.conv2d_fwd.last_mt
                 refstat = [t.clone() for t in ops.bn_finalize(part, mt, M, None, None, 1e-5, 0.1, None, None)[:2]]
         else:
             same = torch.equal(y, ref)
             if part is not None:
                 M = y.numel() // Co
-                mt = lib.pfr_conv2d_mtile(M, Co, R * R * C, C, 1, 1, 0)
+                mt = ops.conv2d_fwd.last_mt
                 st = ops.bn_finalize(part, mt, M, None, None, 1e-5, 0.1, None, None)[:2]
                 same = same and all(torch.allclose(a, b_, rtol=2e-4, atol=1e-5) for a, b_ in zip(st, refstat))
             if not same:

@@ -24,7 +24,7 @@ for H, C, Co, sd, cnt in GEOMS:
     ys = []
     for mode in (0, 2):
         lib.pfr_set_tuning(b"sconv", mode)
-        mt = lib.pfr_conv2d_mtile(M, Co, C, C, 1, 1, 0)
+        mt = lib.pfr_conv2d_mtile(N, H, H, C, Co, 1, 1, sd, 0, OH, OH, 1, 1, 0)
         part = torch.empty(((M + mt - 1) // mt, 2, Co), device=dev, dtype=torch.float32)
         for _ in range(3):
             o.conv2d_fwd(x, w, stride=sd, out=y, stats=STATS, stats_buf=part if STATS else None)
@@ -75,3 +75,30 @@ for H, C, Co, cnt in [(56, 64, 256, 2), (28, 128, 512, 3), (14, 256, 1024, 5)]:
     tot[0] += res[0] * cnt; tot[1] += res[1] * cnt
     print(f"{H:3d}^2 {C:4d}->{Co:4d}: tile {res[0]:7.1f} us  sconv {res[1]:7.1f} us  ({nbytes / res[1] / 1e6:5.2f} TB/s, HBM floor @6.3 {nbytes / 6.3e6:6.1f} us)  x{cnt}  identical={torch.equal(ys[0], ys[1])}")
 print(f"per step: tile {tot[0] / 1e3:.3f} ms, sconv {tot[1] / 1e3:.3f} ms")
+
+# 3x3 / 64 -> 64 channels at 56x56 (layer1 conv2 forward and data gradient): halo-staged kernel vs the tile kernel
+print("3x3 64->64 @56:")
+x = torch.randn(N, 56, 56, 64, device=dev).bfloat16()
+w = (torch.randn(64, 3, 3, 64, device=dev) / 24).bfloat16()
+y = torch.empty(N, 56, 56, 64, device=dev, dtype=torch.bfloat16)
+for stats in (True, False):
+    res, ys = [], []
+    for mode in (0, 2):
+        lib.pfr_set_tuning(b"sconv", mode)
+        mt = lib.pfr_conv2d_mtile(N, 56, 56, 64, 64, 3, 3, 1, 1, 56, 56, 1, 1, 0)
+        M = N * 56 * 56
+        part = torch.empty(((M + mt - 1) // mt, 2, 64), device=dev, dtype=torch.float32)
+        for _ in range(3):
+            o.conv2d_fwd(x, w, stride=1, pad=1, out=y, stats=stats, stats_buf=part if stats else None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            o.conv2d_fwd(x, w, stride=1, pad=1, out=y, stats=stats, stats_buf=part if stats else None)
+        e1.record()
+        torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 20 * 1e3)
+        ys.append(y.clone())
+    lib.pfr_set_tuning(b"sconv", 1)
+    nbytes = 2 * M * 128
+    print(f" stats={stats}: tile {res[0]:7.1f} us  sconv3 {res[1]:7.1f} us  ({nbytes / res[1] / 1e6:5.2f} TB/s, {2 * M * 64 * 576 / res[1] / 1e6:6.0f} TFLOP/s, HBM floor @6.3 {nbytes / 6.3e6:5.1f} us)  identical={torch.equal(ys[0], ys[1])}")

@@ -22,7 +22,7 @@ for kind, H, C, Co, R, s, dil in cases:
         st = None
         if part is not None:
             M = y.numel() // Co
-            mt = lib.pfr_conv2d_mtile(M, Co, R * R * C, C, 1, 1, 0)
+            mt = ops.conv2d_fwd.last_mt
             st = ops.bn_finalize(part, mt, M, None, None, 1e-5, 0.1, None, None)[:2].clone()
         res.append((y.clone(), st, part.shape if part is not None else None))
     same = torch.equal(res[0][0], res[1][0])
