@@ -142,16 +142,18 @@ def cpu_thread_sweep(args):
         sweep[nt] = B / (time.perf_counter() - t0)
     best = max(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    t0 = time.perf_counter()
-    n = 0
-    while n < 2:
+    # BASELINE.md §3 protocol at the winning thread count: 2 warm-up + 5 timed steps
+    for _ in range(2):
         step()
-        n += 1
-    v = B * n / (time.perf_counter() - t0)
-    return {"value": round(max(v, sweep[best]), 2), "unit": "images/sec", "cores": best, "kind": "port",
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    v = B * 5 / (time.perf_counter() - t0)
+    return {"value": round(v, 2), "unit": "images/sec", "cores": best, "kind": "port",
             "thread_sweep_img_s": {str(k): round(val, 2) for k, val in sweep.items()},
             "sample": f"{args.arch}+ArcFace(C={args.classes}) train steps at bs={B}, PyTorch-CPU fp32 oracle restatement (torchvision "
-                      f"absent): 1 warm-up + 1 timed step per thread count, 2 more timed steps at the best ({best} threads of {ncpu})"}
+                      f"absent): thread sweep with 1 warm-up + 1 timed step per count, then 2 warm-up + 5 timed steps at the best "
+                      f"({best} threads of {ncpu})"}
 
 
 def extras(args, device):
@@ -191,6 +193,17 @@ def extras(args, device):
         torch.cuda.empty_cache()
         return res
 
+    # the same headline step through the data-parallel code path (FlatDDP bucket reducer + RCCL communicator of ONE rank): the
+    # number the N = 1 point of a scaling run should be compared with, and what the comm / side / main stream joins cost
+    try:
+        import subprocess
+        env = dict(os.environ, PFR_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-extras",
+                            "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=600)
+        j = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out["ddp_path_w1"] = {"value": j["value"], "unit": "images/sec", "ms_per_step": j["ms_per_step"], "rccl_ranks": j["config"]["rccl_ranks"]}
+    except Exception as e:   # noqa: BLE001
+        out["ddp_path_w1"] = {"error": repr(e)[:200]}
     out["swin_t_bs128"] = train_rate("swin_t", 128, "bf16", 10, 3)
     out["f32_resnet50_bs256"] = train_rate("resnet50", 256, "f32", 4, 2)
     # eval-mode embedder (Controller.validation_step path)
@@ -483,7 +496,7 @@ def main():
                 with open(fn, "rb") as f:
                     h.update(f.read())
             traffic_stale = tj.get("csrc_sha256") != h.hexdigest()   # counters collected with other kernel sources
-        roof = {"bound": "mfma", "kernel": "igemm_kernel + wgrad_kernel (all conv/linear launches of a step)",
+        roof = {"bound": "mfma", "kernel": "all conv/linear launches of a step: igemm_kernel (tiles), sconv_kernel / sconv3_kernel (weight-stationary streaming 1x1 / halo-staged 3x3), wgrad3_kernel",
                 "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes per step of the same launches (PMC), algorithmic minimum = activations+weights once",
                 "traffic_stale": traffic_stale,

@@ -35,6 +35,7 @@ struct SconvParams {
   const unsigned char* res_mask;   // join: its ReLU bit mask [M][N/8]
   int npanels, nranges, R;    // R: rows per range (multiple of the 32-row block height)
   int npw;                    // couts of a workgroup's weight panel (64, 128 or 256)
+  int interleave;             // 1: block-interleaved row assignment (needs M % 32 == 0 and M / 32 divisible by nranges)
   int xbytes;                 // bytes of x (buffer bound: rows past the end read zeros)
   FastDiv div_ohow, div_ow;
 };
@@ -67,10 +68,15 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   const int pn = q8 % p.npanels, rq = q8 / p.npanels;
   const int r = rq * 8 + xcd;
   const int n0 = pn * NPW + sub * NPV;           // first cout of this wave
-  const int row_lo = r * p.R;
-  const int row_hi = row_lo + p.R < p.M ? row_lo + p.R : p.M;
+  // rows of this workgroup: the contiguous range [r*R, (r+1)*R), or — interleaved mode, every block whole — the 32-row blocks
+  // r, r + nranges, r + 2*nranges, ... (chip-wide the workgroups then read ONE moving window of the tensor instead of 256 streams:
+  // +5-8 % HBM throughput, tools/probe/stream_probe.hip); block b of the workgroup starts at row blk_row(b)
+  const int il = p.interleave;
+  const int row_lo = il ? r * 32 : r * p.R;
   if (r >= p.nranges || row_lo >= p.M) return;
-  const int nblk = (row_hi - row_lo + 31) >> 5;
+  const int row_hi = il ? p.M : (row_lo + p.R < p.M ? row_lo + p.R : p.M);
+  const int bstep = il ? p.nranges * 32 : 32;     // row distance of consecutive blocks of this workgroup
+  const int nblk = il ? (p.M / 32 - r + p.nranges - 1) / p.nranges : (row_hi - row_lo + 31) >> 5;
 
   __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.N * RB, 0x00020000);
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.xbytes, 0x00020000);
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   auto set_rows = [&](int blk) {
 #pragma unroll
     for (int t = 0; t < GI; ++t) {
-      const int m = row_lo + blk * 32 + t * 8 + g_row;
+      const int m = row_lo + blk * bstep + t * 8 + g_row;
       uint32_t off = OOBB;
       if (blk < nblk) {
         uint32_t xr = (uint32_t)m;
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 
 #pragma unroll 1
   for (int bi = 0; bi < my_blocks; ++bi) {
-    const int m0 = row_lo + (wrow + nrw * bi) * 32;
+    const int m0 = row_lo + (wrow + nrw * bi) * bstep;
     f32x16 acc[TP];
     // join: the block's residual rows and mask bytes, requested now and consumed by the epilogue.  Inline asm: hipcc would wait
     // vmcnt(0) — draining the DMA ring — for any load it knows of; these are counted by hand (wait_granule, epilogue).
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
     // rows this wave processed; those past M contributed y = 0, i.e. d = -ksh: taken out again below
     int nproc = my_blocks * 32, ninv = 0;
     if (my_blocks > 0) {
-      const int last_end = row_lo + (wrow + nrw * (my_blocks - 1)) * 32 + 32;
+      const int last_end = row_lo + (wrow + nrw * (my_blocks - 1)) * bstep + 32;
       ninv = last_end > p.M ? last_end - p.M : 0;
     }
     const float nval = (float)(nproc - ninv), finv = (float)ninv;
@@ -457,6 +463,8 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.stats_part = p.stats_part;
   sp.res = p.residual; sp.res_mask = p.res_mask;
   sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
+  static const bool il_on = !(getenv("PFR_SCONV_INTERLEAVE") && getenv("PFR_SCONV_INTERLEAVE")[0] == '0');
+  sp.interleave = (il_on && p.M % 32 == 0 && (p.M / 32) % pl.nranges == 0 && (long)pl.R * pl.nranges == p.M) ? 1 : 0;
   sp.xbytes = (int)((long)p.N * p.H * p.W * p.K * 2);
   sp.div_ohow = p.div_ohow; sp.div_ow = p.div_ow;
   if (join) return pl.tp == 2 ? sconv_launch_ns<2, false, true>(sp, pl, st) : sconv_launch_ns<4, false, true>(sp, pl, st);
