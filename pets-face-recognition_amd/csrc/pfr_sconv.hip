@@ -10,15 +10,17 @@
 // prologue/epilogue per tile.  tools/probe/stream_probe.hip shows what the memory system gives a PERSISTENT workgroup whose waves
 // each own a private LDS-DMA ring: 6.3-6.5 TB/s read-only, 5.6-5.9 TB/s with an output stream — this kernel is that skeleton
 // with the MFMAs and the epilogue hung into it:
-//   * grid = npanels x nranges = 256 persistent workgroups of 4 waves (one per SIMD, up to 512 registers each);
-//   * the weight panel [NP couts][K] is loaded into LDS ONCE per workgroup (<= 64 KiB, XOR-swizzled 16-byte chunks);
-//   * a workgroup owns the contiguous row range [r*R, (r+1)*R); its wave w walks the 32*TQ-row blocks w, w+4, ... of it.  The rows
-//     of a block arrive as K/64 "granules" ([32*TQ rows][64 k] = 4*TQ KiB, full 128-byte lines) through the wave's PRIVATE ring
-//     of NS slots with counted `s_waitcnt vmcnt(n)` — no workgroup barrier anywhere in the loop, waves drift freely, so one
-//     wave's MFMAs overlap another's epilogue and a third's DMA issue;
-//   * epilogue per wave: accumulators -> bf16 -> private 4 KiB LDS window -> whole 128-byte row segments -> buffer stores;
-//     BatchNorm statistics (shifted sums of the values AS STORED) stay in registers over all blocks of the wave and leave as ONE
-//     (mean, M2) partial per workgroup: pfr_bn_finalize sees <= 256 partials of R rows (one launch, no group merge).
+//   * grid = npanels x nranges = 256 persistent workgroups of 8 waves (two per SIMD, <= 256 registers each; a first version with
+//     4 waves of 512 registers was instruction-issue bound: one wave per SIMD issues one instruction per ~4 cycles);
+//   * the weight panel [<= 256 couts][K] is loaded into LDS ONCE per workgroup (<= 64 KiB, XOR-swizzled 16-byte chunks);
+//   * a workgroup owns a set of 32-row blocks (block-interleaved over the workgroups, or a contiguous range when the block count
+//     does not divide); a wave takes a 64- or 128-cout slice of the panel and walks its blocks.  The rows of a block arrive as K/64
+//     "granules" ([32 rows][64 k] = 4 KiB, full 128-byte lines) through the wave's PRIVATE ring of NS slots with counted
+//     `s_waitcnt vmcnt(n)` — no workgroup barrier anywhere in the loop, waves drift freely, so one wave's MFMAs overlap another's
+//     epilogue and a third's DMA issue;
+//   * epilogue per wave: accumulators -> bf16 -> the just-consumed ring slot as 4 KiB staging window -> whole 128-byte row
+//     segments -> buffer stores; BatchNorm statistics (shifted sums of the values AS STORED) stay in registers over all blocks
+//     of the wave and leave as ONE (mean, M2) partial per workgroup: pfr_bn_finalize sees <= 256 partials (one launch).
 // Results are bit-identical to igemm_kernel's (same k order inside and across MFMAs); statistics partials differ only in how the
 // rows are grouped.
 #include "pfr_igemm.h"

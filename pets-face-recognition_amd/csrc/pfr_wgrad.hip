@@ -706,7 +706,7 @@ static void wgrad_tiles(int Cout, int KK, int* bp, int* bq) {
 // launch of W = tiles*s workgroups takes ceil(W / 512) rounds of M/s rows: s is chosen to minimise
 //     t_pass * (ceil(W/512)*512 / W)  +  s * slab * 2 / 4 TB/s          (fp32 partial slabs written once, read once)
 // with t_pass = the pass at full occupancy (600 TFLOP/s or 4 TB/s of operand bytes, whichever is slower).  Measured on MI355X
-// (tools/scratch/split_sweep.sh): 3x3 256ch 14x14: 10 -> 14 splits = 98 -> 82 us; 3x3 512ch 7x7: 4 -> 3 splits = 115 -> 91 us.
+// (profiles/repro/split_sweep.sh): 3x3 256ch 14x14: 10 -> 14 splits = 98 -> 82 us; 3x3 512ch 7x7: 4 -> 3 splits = 115 -> 91 us.
 extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   int bp, bq;
   wgrad_tiles(Cout, KK, &bp, &bq);

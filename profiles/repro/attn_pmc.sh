@@ -1,10 +1,10 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python $R/tools/scratch/attn_one.py 2>&1 | tail -1
+python $R/profiles/repro/attn_one.py 2>&1 | tail -1
 for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
   rm -rf /tmp/pm
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pm -o pm -- python $R/tools/scratch/attn_one.py > /tmp/pm.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pm -o pm -- python $R/profiles/repro/attn_one.py > /tmp/pm.log 2>&1
   f=$(find /tmp/pm -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 for c in a b c d; do
 for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES"; do
   rm -rf /tmp/pm
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pm -o pm -- python $R/tools/scratch/fw_one.py $c > /tmp/pm.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pm -o pm -- python $R/profiles/repro/fw_one.py $c > /tmp/pm.log 2>&1
   f=$(find /tmp/pm -name "*counter_collection.csv" | head -1)
   python - "$f" case_$c <<'PY'
 import csv, sys, collections

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 for c in "$@"; do
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
   rm -rf /tmp/pm
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pm -o pm -- python $R/tools/scratch/fw_one.py $c > /tmp/pm.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pm -o pm -- python $R/profiles/repro/fw_one.py $c > /tmp/pm.log 2>&1
   f=$(find /tmp/pm -name "*counter_collection.csv" | head -1)
   python - "$f" case_$c <<'PY'
 import csv, sys, collections

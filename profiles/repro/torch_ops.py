@@ -1,6 +1,6 @@
 """Which torch (aten) operators run inside one train step besides the C-ABI launches — they show up as __amd_rocclr_copyBuffer /
 FillFunctor kernels in the rocprof tables.  Prints operator counts with the python frames that issued them.
-usage: python tools/scratch/torch_ops.py [resnet50|swin_t] [batch]"""
+usage: python profiles/repro/torch_ops.py [resnet50|swin_t] [batch]"""
 import sys, os, types, collections, importlib.util, torch
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
