@@ -304,17 +304,19 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
           for (int e = 0; e < 8; ++e) f[e] += ((bits >> e) & 1u) ? rr8[e] : 0.f;
           const u32x4 o = Chunk<bf16_t>::pack(f);
           __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, (int)(y_lane + (uint32_t)(g * 128)), (int)(ybase + (uint32_t)(ps * 8 * p.N * 2)), 0);
+          asm volatile("s_waitcnt expcnt(0)" ::: "memory");   // (store data read-out: see below)
           continue;
         }
         // rows past M lie beyond num_records: the store is dropped
         __builtin_amdgcn_raw_buffer_store_b128(v, yrsrc, (int)(y_lane + (uint32_t)(g * 128)), (int)(ybase + (uint32_t)(ps * 8 * p.N * 2)), 0);
+        // MEASURED on gfx950: a buffer_store_dwordx4 reads its data VGPRs from the register file LATE when the wave's vector-memory
+        // queue is deep (here up to ~28 DMA / store instructions in flight).  hipcc assumes store data is read at issue and
+        // re-uses the registers at once — for the next pass's LDS read, or the next iteration's DMA address — so the last quad
+        // lanes of the first data dword went out overwritten (tens to ~1000 rows of 800 k per launch, NaN / byte offsets).  The
+        // read-out IS tracked by EXP_CNT: wait for it after EVERY store, before anything can touch its registers.
+        asm volatile("s_waitcnt expcnt(0)" ::: "memory");
       }
     }
-    // MEASURED on gfx950: a buffer_store_dwordx4 reads its data VGPRs from the register file LATE when the vector-memory queue is
-    // deep (here up to ~28 DMA / store instructions in flight per wave) — the DMA address arithmetic of the next iteration, which
-    // hipcc places in the same registers, overwrote the last quad lanes of the first data dword of this block's last stores
-    // (~1000 rows of 800 k wrong, each holding an x byte offset instead of two outputs).  hipcc assumes store data is read at
-    // issue and emits no wait; the read-out IS tracked by EXP_CNT: waiting for it costs nothing measurable.
     asm volatile("s_waitcnt expcnt(0)" ::: "memory");
   }
   // drain: the dummy granules issued past the end must have landed before the LDS is reused or released
@@ -410,7 +412,9 @@ bool sconv_plan(int M, int N, int K, int dtype, int out_dtype, SconvPlan* sp) {
   // re-reading x once per panel (from L2: the panels of a row range run on one XCD) must stay cheaper than what the tile kernels do
   if (mode == 1) {
     // (measured, tools/sconv_bench.py: K = 512 with 4 panels 81 vs 94 us for the tile kernel, with 16 panels 68-72 vs 76-78)
-    if (npanels > 16 || (K < 512 && npanels > 8)) return false;
+    static const int maxp = getenv("PFR_SCONV_MAXPANELS") ? atoi(getenv("PFR_SCONV_MAXPANELS")) : 16;
+    static const int maxk = getenv("PFR_SCONV_MAXK") ? atoi(getenv("PFR_SCONV_MAXK")) : 512;
+    if (npanels > maxp || K > maxk || (K < 512 && npanels > 8)) return false;
     if (M < 256 * 64) return false;    // too few rows per workgroup for a pipeline
   }
   int nranges = 256 / npanels;
