@@ -65,35 +65,20 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
         qn, gn = (q32, g32) if T == torch.float32 else (ops.cast(q32, T), ops.cast(g32, T))
         qn32, gn32 = q32, g32
     chunk = min(chunk, G)
+    ld = (chunk + 3) // 4 * 4
+    sbuf = torch.empty((Q, 1, 1, ld), dtype=torch.float32, device=q.device)
+    state = torch.empty(lib.pfr_topk_state_bytes(Q, kc), dtype=torch.uint8, device=q.device)
     self_idx = torch.arange(Q, dtype=torch.int32, device=q.device) if exclude_self else None
-    # Every chunk but the first uses the GEMM with the top-K filter in its epilogue (the fp32 score chunk is never written): a
-    # score enters a query's candidate list iff it beats the query's current kc-th best.  The FIRST chunk has no thresholds yet and
-    # goes through the unfused pair (fp32 score GEMM + running-list build) — so it is kept SMALL (4096 rows) and the fused chunks
-    # grow geometrically behind it: after n rows a threshold passes ~kc/n of a chunk, so a chunk of n·(cap/3)/kc rows yields ~cap/3
-    # candidates per query (the list capacity is cap).  (Round 2 ran the first 65 536 rows unfused: 4.1 of 20.7 ms for 10 k x 1 M.)
-    # A candidate-list overflow (adversarially ordered gallery) is flagged on the device and the match is redone unfused.
+    # Chunks after the first (every running list is full by then) use the GEMM with the top-K filter in its epilogue: the
+    # fp32 score chunk is never written.  A candidate-list overflow (adversarially ordered gallery) is flagged on the
+    # device and the whole match is redone on the unfused path.
     fused = fused_filter and G > chunk and chunk >= kc + 1 and D % (64 if T == torch.bfloat16 else 32) == 0
     cap = 1536
     cand = torch.empty((Q, cap), dtype=torch.int64, device=q.device) if fused else None
-    state = torch.empty(lib.pfr_topk_state_bytes(Q, kc), dtype=torch.uint8, device=q.device)
-
-    def schedule(fused_):
-        if not fused_:
-            return [(c0, min(chunk, G - c0)) for c0 in range(0, G, chunk)]
-        first = min(chunk, max(4096, 8 * kc))
-        out, c0, n = [(0, first)], first, first
-        while c0 < G:
-            n = min(chunk, G - c0, max(4096, int(c0 * (cap // 3) / kc) // 256 * 256))
-            out.append((c0, n))
-            c0 += n
-        return out
-
     while True:
-        sched = schedule(fused)
-        ld = (max(n for c0, n in sched if c0 == 0 or not fused) + 3) // 4 * 4
-        sbuf = torch.empty((Q, 1, 1, ld), dtype=torch.float32, device=q.device)
         lib.pfr_topk_reset(state.data_ptr(), Q, kc, _stream())
-        for c0, n in sched:
+        for c0 in range(0, G, chunk):
+            n = min(chunk, G - c0)
             if fused and c0 > 0:
                 lib.pfr_match_scores_filter(qn.data_ptr(), gn[c0:c0 + n].data_ptr(), dtype_id(T), Q, n, D, c0, kc, state.data_ptr(),
                                             cand.data_ptr(), cap, int(exclude_self), _stream())
