@@ -328,6 +328,16 @@ int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, long M, int K
 int pfr_gemm_act_colstats(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
                           void* y2, float* stats_part, pfr_stream_t stream);
 
+/* ---- gradient all-reduce over RCCL / xGMI (csrc/pfr_comm.hip) ---------------------------------------------
+ * For hosts that bind this library directly; replaces DistributedDataParallel's bucket all-reduce (utils/__init__.py:114-119).
+ * RCCL is resolved with dlopen at first use (no load-time dependency).  pfr_comm_unique_id: rank 0 fills a 128-byte id, the
+ * host distributes it; pfr_comm_init: one communicator per process / GPU (current HIP device), NULL on error;
+ * pfr_comm_allreduce: in place, `count` elements of dtype, mean over the ranks when average != 0, asynchronous on `stream`. */
+int pfr_comm_unique_id(void* id128);
+void* pfr_comm_init(int rank, int world, const void* id128);
+int pfr_comm_allreduce(void* comm, void* buf, size_t count, int dtype, int average, pfr_stream_t stream);
+int pfr_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -415,3 +415,73 @@ def test_main_swin_t_config_and_load_from_checkpoint(tmp_path):
     with torch.no_grad():
         emb = ml(torch.rand(2, 3, 224, 224, device="cuda:0"))
     assert emb.shape == (2, 512) and torch.isfinite(emb).all()
+
+
+def test_c_abi_rccl_allreduce_world1():
+    """pfr_comm_{unique_id,init,allreduce,destroy} (csrc/pfr_comm.hip): RCCL resolved by dlopen, one rank: mean and sum all-reduce
+    leave f32 / bf16 buffers bit-unchanged, on a side stream too; bad arguments are reported, not crashed on."""
+    from pets_face_recognition_amd._hip import comm as C
+    from pets_face_recognition_amd._hip.lib import PfrError, lib
+    uid = C.unique_id()
+    assert len(uid) == 128 and any(uid)
+    c = C.Communicator(0, 1, uid)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for dt in (torch.float32, torch.bfloat16):
+        t = torch.randn(1 << 20, device="cuda", generator=g).to(dt)
+        ref = t.clone()
+        c.allreduce_(t, average=True)
+        c.allreduce_(t, average=False)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        c.allreduce_(t, average=True, stream=side)
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref)
+    with pytest.raises(PfrError):
+        lib.pfr_comm_allreduce(c._h, t.data_ptr(), 16, 7, 1, None)   # unknown dtype code
+    assert not lib.pfr_comm_init(3, 2, uid)                          # rank outside the world
+    c.close()
+
+
+_COMM2_SCRIPT = r'''
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch
+rank, world, path = int(sys.argv[1]), 2, sys.argv[2]
+torch.cuda.set_device(rank)
+from pets_face_recognition_amd._hip import comm as C
+if rank == 0:
+    uid = C.unique_id()
+    open(path + ".tmp", "wb").write(uid); os.replace(path + ".tmp", path)
+else:
+    while not os.path.exists(path): time.sleep(0.05)
+    uid = open(path, "rb").read()
+c = C.Communicator(rank, world, uid)
+g = torch.Generator().manual_seed(11)
+shards = [torch.randn(3_000_001, generator=g) for _ in range(world)]
+t = shards[rank].cuda()
+c.allreduce_(t, average=True)
+torch.cuda.synchronize()
+want = (shards[0].double() + shards[1].double()) / 2
+assert (t.cpu().double() - want).abs().max().item() < 1e-6
+b = shards[rank].cuda().bfloat16()
+c.allreduce_(b, average=False)
+torch.cuda.synchronize()
+want = shards[0].bfloat16().float() + shards[1].bfloat16().float()
+assert (b.float().cpu() - want).abs().max().item() <= 0.04 * want.abs().max().item()
+c.close()
+print("OK comm", rank)
+'''
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 MI355X on the node")
+def test_c_abi_rccl_allreduce_world2(tmp_path):
+    """two processes, one GPU each, rendezvous id through a file (no torch.distributed anywhere): mean / sum over xGMI"""
+    script = tmp_path / "comm2.py"
+    script.write_text(_COMM2_SCRIPT.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ps = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / "uid")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+          for r in range(2)]
+    for r, p in enumerate(ps):
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and f"OK comm {r}" in out, (out[-1000:], err[-3000:])
