@@ -166,6 +166,14 @@ int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* x, const fl
                       pfr_stream_t stream);
 int pfr_bn_bwd_finalize(const float* part, int nparts, int C, float count, const float* gamma, const float* mean,
                         const float* invstd, float* dgamma, float* dbeta, float* coef, int accumulate, pfr_stream_t stream);
+/* reduce and finalize in ONE launch (the last workgroups to arrive sum the partial rows in index order: deterministic, nothing
+ * spins).  part: [pfr_bn_bwd_fused_part_rows(C, dtype, rows)][2][C] floats; counters: >= 64 zero-initialised 32-bit words owned by
+ * the call site (left at zero); count = rows. */
+int pfr_bn_bwd_fused_part_rows(int C, int dtype, long rows);
+int pfr_bn_bwd_reduce_finalize(const void* dout, const void* out, const void* x, const float* mean, const float* invstd,
+                               const float* scale, const float* shift, int mask_mode, int dtype, long rows, int C, float* part,
+                               unsigned int* counters, const float* gamma, float* dgamma, float* dbeta, float* coef,
+                               int accumulate, pfr_stream_t stream);
 int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x, const float* coef, const float* scale,
                      const float* shift, int mask_mode, void* dx, void* gres, int dtype, long rows, int C,
                      pfr_stream_t stream);

@@ -208,7 +208,9 @@ extern "C" int pfr_colreduce_blocks(int C, int dtype, long rows) {
   return col_geom(C, dtype == PFR_BF16 ? 8 : 4, (size_t)rows).gx;
 }
 
-template <int NQ, int KP>
+// COHERENT: the row is written with device-scope (write-through) stores — for launches whose last workgroups read the rows of
+// the others (bn_bwd_reduce_kernel<.., FIN>); a release fence instead costs an L2 write-back scan per workgroup.
+template <int NQ, int KP, bool COHERENT = false>
 __device__ __forceinline__ void col_block_reduce(float (&v)[NQ][KP], float* lds, int cw, int rl, int col, int rlane,
                                                  int cglob, int cpr, float* out_row, int C) {
   // lds: [rl][cw][NQ*KP]
@@ -225,7 +227,8 @@ __device__ __forceinline__ void col_block_reduce(float (&v)[NQ][KP], float* lds,
       for (int e = 0; e < KP; ++e) {
         float a = 0.f;
         for (int r = 0; r < rl; ++r) a += lds[((size_t)r * cw + col) * (NQ * KP) + q * KP + e];
-        out_row[(size_t)q * C + cglob * KP + e] = a;
+        if (COHERENT) __hip_atomic_store(out_row + (size_t)q * C + cglob * KP + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out_row[(size_t)q * C + cglob * KP + e] = a;
       }
   }
 }
@@ -601,13 +604,31 @@ extern "C" int pfr_bn_act_mask(const void* x1, const float* a1, const float* b1,
 // mask_mode 0: none; 1: out > 0 (materialised post-activation tensor); 2: scale·x + shift > 0 (recomputed)
 // MASK is a template parameter: with a run-time mode the optional loads (`if (mode == 3) bits = …`) sit in branches and hipcc drains
 // the memory queue (vmcnt(0)) behind the first row of every four-row batch — two round trips per batch instead of one
-template <typename T, int MASK>
+// FIN: the launch also does pfr_bn_bwd_finalize's work (no second launch on the dependency chain).  Workgroups are grouped by
+// BNF_GROUP consecutive row blocks; the LAST workgroup of a group to arrive (device-scope counter) sums the group's partial rows in
+// index order into a group row, and the last GROUP to arrive sums the group rows in index order and writes dgamma / dbeta / coef:
+// the order of every sum is fixed by indices, not by arrival, so the result is deterministic.  Nothing spins; the counters are left
+// at zero for the next launch.
+#define BNF_GROUP 16
+struct BnBwdFin {
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  float* coef;
+  float* gpart;          // [ngroups][2][C]
+  unsigned int* counters;  // [gridDim.y][1 + ngroups], zero before the first launch
+  float count;
+  int accumulate;
+};
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <typename T, int MASK, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ part, size_t rows, int C,
-                                                            int cw, int rl, int cpr) {
+                                                            int cw, int rl, int cpr, BnBwdFin fin = BnBwdFin()) {
   constexpr int mask_mode = MASK;
   constexpr int KP = DT<T>::KPACK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -670,7 +691,66 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       body(ld16(dout + off), ld16(x + off), vo, mask_mode == 3 ? mk[r * cpr + cglob] : 0u);
     }
   }
-  col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
+  col_block_reduce<2, KP, FIN>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
+  if (!FIN) return;
+  __shared__ int last;
+  const int ngroups = (gridDim.x + BNF_GROUP - 1) / BNF_GROUP, grp = blockIdx.x / BNF_GROUP;
+  const int gbeg = grp * BNF_GROUP, gend = min((int)gridDim.x, gbeg + BNF_GROUP);
+  unsigned int* cnt = fin.counters + (size_t)blockIdx.y * (1 + ngroups);
+  const int c_lo = blockIdx.y * cw * KP, c_hi = min(C, c_lo + cw * KP);   // the channels this column of workgroups owns
+  // hand-over without fences: the partial row went out as device-scope stores (not left dirty in this XCD's L2), every wave waits
+  // for its stores to complete before the barrier, then ONE device-scope atomic counts the arrival; readers use device-scope loads
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&cnt[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(gend - gbeg - 1);
+  __syncthreads();
+  if (!last) return;
+  for (int c = c_lo + (int)threadIdx.x; c < c_hi; c += 256) {
+    float va[BNF_GROUP], vb[BNF_GROUP];
+#pragma unroll
+    for (int i = 0; i < BNF_GROUP; ++i) {
+      const int b = gbeg + i < gend ? gbeg + i : gbeg;
+      va[i] = ld_agent(part + ((size_t)b * 2 + 0) * C + c);
+      vb[i] = ld_agent(part + ((size_t)b * 2 + 1) * C + c);
+    }
+    float a = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < BNF_GROUP; ++i)
+      if (gbeg + i < gend) { a += va[i]; b2 += vb[i]; }
+    __hip_atomic_store(fin.gpart + ((size_t)grp * 2 + 0) * C + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fin.gpart + ((size_t)grp * 2 + 1) * C + c, b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ngroups - 1);
+  __syncthreads();
+  if (!last) return;
+  for (int c = c_lo + (int)threadIdx.x; c < c_hi; c += 256) {
+    const float g = fin.gamma ? fin.gamma[c] : 1.f, is = invstd[c], mu = mean[c];
+    const float dg0 = (fin.dgamma && fin.accumulate) ? fin.dgamma[c] : 0.f, db0 = (fin.dbeta && fin.accumulate) ? fin.dbeta[c] : 0.f;
+    float sg = 0.f, sgx = 0.f;
+    for (int g0 = 0; g0 < ngroups; g0 += 8) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int gg = g0 + i < ngroups ? g0 + i : 0;
+        va[i] = ld_agent(fin.gpart + ((size_t)gg * 2 + 0) * C + c);
+        vb[i] = ld_agent(fin.gpart + ((size_t)gg * 2 + 1) * C + c);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (g0 + i < ngroups) { sg += va[i]; sgx += vb[i]; }
+    }
+    if (fin.dgamma) fin.dgamma[c] = fin.accumulate ? dg0 + sgx : sgx;
+    if (fin.dbeta) fin.dbeta[c] = fin.accumulate ? db0 + sg : sg;
+    const float cg = g * is;
+    const float cx = -g * is * is * sgx / fin.count;
+    const float c0 = -g * is * sg / fin.count - cx * mu;
+    fin.coef[c] = cg;
+    fin.coef[C + c] = cx;
+    fin.coef[2 * C + c] = c0;
+  }
+  if ((int)threadIdx.x <= ngroups) __hip_atomic_store(&cnt[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream order separates the launches)
 }
 
 extern "C" int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* x, const float* mean,
@@ -686,6 +766,39 @@ extern "C" int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* 
 #define PFR_BNR(TT, M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, M>), dim3(g.gx, g.gy), dim3(256), shb, st, (const TT*)dout, (const TT*)out, (const TT*)x, mean, invstd, scale, shift, part, (size_t)rows, C, g.cw, g.rl, g.cpr)
 #define PFR_BNR4(TT) do { switch (mask_mode) { case 0: PFR_BNR(TT, 0); break; case 1: PFR_BNR(TT, 1); break; case 2: PFR_BNR(TT, 2); break; default: PFR_BNR(TT, 3); } } while (0)
   PFR_CHECK_ARG(mask_mode >= 0 && mask_mode <= 3, "pfr_bn_bwd_reduce: bad mask_mode");
+  if (dtype == PFR_BF16) PFR_BNR4(bf16_t); else PFR_BNR4(float);
+#undef PFR_BNR4
+#undef PFR_BNR
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
+// reduce + finalize in ONE launch (see bn_bwd_reduce_kernel<.., FIN>).  part: [pfr_bn_bwd_fused_part_rows][2][C] floats (the
+// row-block partials followed by the group rows); counters: >= 64 zero-initialised 32-bit words owned by this call site.
+extern "C" int pfr_bn_bwd_fused_part_rows(int C, int dtype, long rows) {
+  const ColGeom g = col_geom(C, dtype == PFR_BF16 ? 8 : 4, (size_t)rows);
+  return g.gx + (g.gx + BNF_GROUP - 1) / BNF_GROUP;
+}
+extern "C" int pfr_bn_bwd_reduce_finalize(const void* dout, const void* out, const void* x, const float* mean, const float* invstd,
+                                          const float* scale, const float* shift, int mask_mode, int dtype, long rows, int C,
+                                          float* part, unsigned int* counters, const float* gamma, float* dgamma, float* dbeta,
+                                          float* coef, int accumulate, hipStream_t st) {
+  PFR_CHECK_ARG(dout && x && mean && invstd && part && counters && coef, "pfr_bn_bwd_reduce_finalize: null pointer");
+  PFR_CHECK_ARG((mask_mode != 1 && mask_mode != 3) || out, "pfr_bn_bwd_reduce_finalize: mask_mode 1 / 3 needs out / the bit mask");
+  PFR_CHECK_ARG(mask_mode != 2 || (scale && shift), "pfr_bn_bwd_reduce_finalize: mask_mode 2 needs scale/shift");
+  PFR_CHECK_ARG(mask_mode >= 0 && mask_mode <= 3, "pfr_bn_bwd_reduce_finalize: bad mask_mode");
+  const int kp = dtype == PFR_BF16 ? 8 : 4;
+  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_reduce_finalize: C %% %d != 0", kp);
+  ColGeom g = col_geom(C, kp, (size_t)rows);
+  const int ngroups = (g.gx + BNF_GROUP - 1) / BNF_GROUP;
+  PFR_CHECK_ARG(g.gy * (1 + ngroups) <= 64, "pfr_bn_bwd_reduce_finalize: geometry needs %d counters", g.gy * (1 + ngroups));
+  BnBwdFin fin;
+  fin.gamma = gamma; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.coef = coef;
+  fin.gpart = part + (size_t)g.gx * 2 * C;
+  fin.counters = counters; fin.count = (float)rows; fin.accumulate = accumulate;
+  const size_t shb = (size_t)256 * 2 * kp * sizeof(float);
+#define PFR_BNR(TT, M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, M, true>), dim3(g.gx, g.gy), dim3(256), shb, st, (const TT*)dout, (const TT*)out, (const TT*)x, mean, invstd, scale, shift, part, (size_t)rows, C, g.cw, g.rl, g.cpr, fin)
+#define PFR_BNR4(TT) do { switch (mask_mode) { case 0: PFR_BNR(TT, 0); break; case 1: PFR_BNR(TT, 1); break; case 2: PFR_BNR(TT, 2); break; default: PFR_BNR(TT, 3); } } while (0)
   if (dtype == PFR_BF16) PFR_BNR4(bf16_t); else PFR_BNR4(float);
 #undef PFR_BNR4
 #undef PFR_BNR

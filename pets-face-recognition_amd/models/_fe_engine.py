@@ -143,6 +143,13 @@ class FEEngine:
         # kernels are bound by their vector-memory path into LDS, not by HBM, so the extra x reads and the registers of the sums
         # lengthen them (3.5 -> 7.4 ms) by more than the HBM-speed reduce kernels (2.1 ms at 4.5 TB/s) cost.  DESIGN.md §6.
         self.fuse_bnb = os.environ.get("PFR_FUSE_BNB", "0") == "1"
+        # Opt-in (PFR_FUSE_FIN=1): BatchNorm backward reduce + finalize in one launch (the last workgroups to arrive merge the
+        # partial rows, pfr_bn_bwd_reduce_finalize) — 53 dependent 7 us launches fewer per ResNet-50 step, but MEASURED SLOWER
+        # (profiles/r03_finalize_fusion.txt): with release fences 26.1 vs 19.5 ms/step (every fence is an L2 write-back scan), with
+        # write-through stores + device-scope loads instead of fences 20.14 vs 19.56: the hand-over is six dependent device-scope
+        # round trips of ~2 us, more than the 6.7 us finalize launch (256 workgroups in parallel) and its gap cost.
+        self.fuse_fin = os.environ.get("PFR_FUSE_FIN", "0") == "1"
+        self._fin_counters = {}
         # stem tail backward without the max-pool gradient tensor (-1.1 GB of HBM traffic per step at bs 256): measured neutral
         # (0.57 vs 0.62 ms; the gather is vector-ALU bound), bit-identical, opt-in like PFR_FUSE_BNB
         self.fuse_pool = os.environ.get("PFR_FUSE_POOL", "0") == "1"
@@ -662,15 +669,26 @@ class FEEngine:
             oa = 0 if out_act is None else out_act.data_ptr()
             if pre is not None:
                 part, nb = pre          # the launch that produced `dout` already left the partial sums (pfr_conv2d_dgrad_bn)
+            elif self.fuse_fin:
+                part = G((lib.pfr_bn_bwd_fused_part_rows(C, self.did, rows), 2, C), torch.float32)
+                cnt = self._fin_counters.get(id(bn))
+                if cnt is None:
+                    cnt = self._fin_counters[id(bn)] = torch.zeros(64, dtype=torch.int32, device=self.device)
+                ops.append((lib.pfr_bn_bwd_reduce_finalize, (dout.data_ptr(), oa, x.data_ptr(), bn.coef[0].data_ptr(),
+                                                             bn.coef[1].data_ptr(), bn.coef[2].data_ptr(), bn.coef[3].data_ptr(),
+                                                             mask_mode, self.did, rows, C, part.data_ptr(), cnt.data_ptr(),
+                                                             bn.gamma.data_ptr(), bn.dgamma.data_ptr(), bn.dbeta.data_ptr(),
+                                                             bn.bcoef.data_ptr(), acc)))
             else:
                 nb = lib.pfr_colreduce_blocks(C, self.did, rows)
                 part = G((nb, 2, C), torch.float32)
                 ops.append((lib.pfr_bn_bwd_reduce, (dout.data_ptr(), oa, x.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
                                                     bn.coef[2].data_ptr(), bn.coef[3].data_ptr(), mask_mode, self.did, rows, C,
                                                     part.data_ptr())))
-            ops.append((lib.pfr_bn_bwd_finalize, (part.data_ptr(), nb, C, float(rows), bn.gamma.data_ptr(), bn.coef[0].data_ptr(),
-                                                  bn.coef[1].data_ptr(), bn.dgamma.data_ptr(), bn.dbeta.data_ptr(),
-                                                  bn.bcoef.data_ptr(), acc)))
+            if pre is not None or not self.fuse_fin:
+                ops.append((lib.pfr_bn_bwd_finalize, (part.data_ptr(), nb, C, float(rows), bn.gamma.data_ptr(), bn.coef[0].data_ptr(),
+                                                      bn.coef[1].data_ptr(), bn.dgamma.data_ptr(), bn.dbeta.data_ptr(),
+                                                      bn.bcoef.data_ptr(), acc)))
             ops.append((lib.pfr_bn_bwd_apply, (dout.data_ptr(), oa, x.data_ptr(), bn.bcoef.data_ptr(), bn.coef[2].data_ptr(),
                                                bn.coef[3].data_ptr(), mask_mode, dx.data_ptr(),
                                                0 if gres is None else gres.data_ptr(), self.did, rows, C)))
@@ -904,7 +922,7 @@ class FEEngine:
                     res.append((lib.pfr_copy2d_f32, tuple(args[:-1]) + (acc,)))
                 elif fn == "s2dunpack":
                     res.append((lib.pfr_s2d_wgrad, tuple(args[:-1]) + (acc,)))
-                elif fn is lib.pfr_bn_bwd_finalize:
+                elif fn is lib.pfr_bn_bwd_finalize or fn is lib.pfr_bn_bwd_reduce_finalize:
                     res.append((fn, tuple(args[:-1]) + (acc,)))
                 else:
                     res.append((fn, args))

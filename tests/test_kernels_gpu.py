@@ -620,3 +620,60 @@ def test_halo_staged_3x3_kernel_bit_identical(case):
     assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][2], outs[0][2]) and torch.equal(outs[1][3], outs[0][3])
     assert torch.equal(outs[1][0], outs[1][2])
     assert torch.allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,mask_mode", [(256 * 56 * 56, 64, 2), (64 * 28 * 28, 512, 3), (256 * 49, 2048, 0), (1000, 128, 1),
+                                             (37, 16, 2), (32 * 14 * 14, 1024, 3)])
+def test_bn_backward_reduce_finalize_one_launch(dtype, rows, C, mask_mode):
+    """pfr_bn_bwd_reduce_finalize (last workgroups to arrive merge the partial rows) against pfr_bn_bwd_reduce + pfr_bn_bwd_finalize:
+    same sums in a different (index-fixed) order -> equal to fp32 summation tolerance, BIT-identical from launch to launch
+    (determinism; also shows the counters are left at zero), accumulate adds to dgamma / dbeta."""
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    did = dtype_id(dtype)
+    kp = 8 if dtype == torch.bfloat16 else 4
+    g = torch.Generator().manual_seed(rows % 1000 + C)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(rows, C, generator=g).to(DEV, dtype)
+    dout = torch.randn(rows, C, generator=g).to(DEV, dtype)
+    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    mean = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    invstd = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    out = 0
+    if mask_mode == 1:
+        keep = torch.relu(x.float() * scale + shift).to(dtype)
+        out = keep.data_ptr()
+    elif mask_mode == 3:
+        keep = torch.randint(0, 256, (rows, C // kp), generator=g, dtype=torch.uint8).to(DEV)
+        out = keep.data_ptr()
+    nb = lib.pfr_colreduce_blocks(C, did, rows)
+    part = torch.zeros(nb, 2, C, device=DEV)
+    coef_a, dg_a, db_a = torch.empty(3, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    lib.pfr_bn_bwd_reduce(dout.data_ptr(), out, x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                          mask_mode, did, rows, C, part.data_ptr(), st)
+    lib.pfr_bn_bwd_finalize(part.data_ptr(), nb, C, float(rows), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dg_a.data_ptr(),
+                            db_a.data_ptr(), coef_a.data_ptr(), 0, st)
+    nrows = lib.pfr_bn_bwd_fused_part_rows(C, did, rows)
+    assert nb < nrows <= nb + 32
+    counters = torch.zeros(64, dtype=torch.int32, device=DEV)
+    results = []
+    for rep in range(4):
+        part_b = torch.full((nrows, 2, C), float("nan"), device=DEV)
+        coef_b, dg_b, db_b = torch.empty(3, C, device=DEV), torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+        lib.pfr_bn_bwd_reduce_finalize(dout.data_ptr(), out, x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                       shift.data_ptr(), mask_mode, did, rows, C, part_b.data_ptr(), counters.data_ptr(),
+                                       gamma.data_ptr(), dg_b.data_ptr(), db_b.data_ptr(), coef_b.data_ptr(), rep & 1, st)
+        torch.cuda.synchronize()
+        assert int(counters.abs().sum()) == 0
+        assert torch.equal(part_b[:nb], part)
+        acc = float(rep & 1)
+        results.append((coef_b.clone(), dg_b - acc, db_b - acc))
+    scale_g = part[:, 0].abs().sum(0) + 1e-3
+    scale_gx = part[:, 1].abs().sum(0) + 1e-3
+    for coef_b, dg_b, db_b in results:
+        assert ((db_b - db_a).abs() / scale_g).max().item() < 2e-6
+        assert ((dg_b - dg_a).abs() / scale_gx).max().item() < 2e-6
+        assert torch.allclose(coef_b, coef_a, rtol=2e-4, atol=1e-5 * float(coef_a.abs().max()))
+    assert torch.equal(results[0][0], results[2][0]) and torch.equal(results[0][1], results[2][1]) and torch.equal(results[0][2], results[2][2])
