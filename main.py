@@ -18,7 +18,7 @@ import pets_face_recognition_amd as pfr  # noqa: E402
 pfr.install_reference_aliases()
 
 from engine import Controller  # noqa: E402
-from utils import is_main_process, configure_trainer, get_config  # noqa: E402
+from utils import is_main_process, configure_trainer, get_config, find_max_batch_size, find_optimal_init_lr  # noqa: E402
 
 
 def parse_args(argv=None):
@@ -51,7 +51,24 @@ def main(argv=None):
                 print('mlflow is not installed: metrics are written to', run_root / 'metrics.jsonl')
     controller = Controller(config=config)
     trainer = configure_trainer(config, logger, checkpoint_path)
+    if config.get('find_max_batch_size'):        # reference main.py:79-84
+        new_batch_size = find_max_batch_size(trainer, controller)
+        if new_batch_size:
+            config.train_batch_size = new_batch_size
+            config.test_batch_size = new_batch_size
+        controller = Controller(config=config)
+    if config.get('find_optimal_init_lr'):       # reference main.py:86-89 (its `opt_params` write is kept when the config has one)
+        new_lr = find_optimal_init_lr(trainer, controller)
+        if new_lr is not None:
+            config.init_lr = new_lr
+            if config.get('opt_params') is not None:
+                config.opt_params['main']['lr'] = new_lr
+        controller = Controller(config=config)
     trainer.fit(controller)
+    if getattr(trainer, 'train_img_s', None) and getattr(trainer, 'rank', 0) == 0:
+        import json
+        rec = {'train_img_s': round(trainer.train_img_s, 1), 'config': str(args.config), 'prefetch_batches': trainer.prefetch_batches}
+        print('THROUGHPUT ' + json.dumps(rec))
     print('Completed!')
     return controller, trainer
 

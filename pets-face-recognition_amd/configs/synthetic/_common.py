@@ -21,10 +21,20 @@ def _rank():
     import os
     return int(os.environ.get("RANK", "0"))
 
+def _live(key, default):
+    """value of `key` in the live Config object (main.py's batch-size / lr finders write there), else the config file's own"""
+    from utils import Config, _SingletonBase
+    inst = _SingletonBase._instances.get(Config)
+    v = inst.get(key) if inst is not None else None
+    return default if v is None else v
+
+
 def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs, device, n_epochs=1, seed=0,
-         fused_optimizer=True, compute_dtype=None, limit_train_batches=None, workers=0, n_pairs=200, device_augment=False, noise=0.15):
+         fused_optimizer=True, compute_dtype=None, limit_train_batches=None, workers=0, n_pairs=200, device_augment=False, noise=0.15,
+         noise_bank=0, limit_val_batches=None):
     torch.manual_seed(seed)
-    dataset = SyntheticRecDataset(n_train_ids + n_val_ids, photos, image_size, seed=seed, noise=noise, raw_uint8=device_augment)
+    dataset = SyntheticRecDataset(n_train_ids + n_val_ids, photos, image_size, seed=seed, noise=noise, raw_uint8=device_augment,
+                                  noise_bank=noise_bank)
     train_users = list(range(n_train_ids))
     val_users = list(range(n_train_ids, n_train_ids + n_val_ids))
     labels = dataset.get_labels()
@@ -63,9 +73,10 @@ def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs
     def optimizer(model_):
         params1 = [p for i, p in model_.module.named_parameters() if 'fc' not in i]
         params2 = [p for i, p in model_.module.named_parameters() if 'fc' in i]
-        d = [{'lr': 10 ** -2 / 2, 'params': params1},
-             {'lr': 10 ** -2, 'params': params2},
-             {'lr': 10 ** -2, 'params': list(model_.add_margin.parameters()), 'weight_decay': 1 * (10 ** -4)}]
+        base = _live('init_lr', 10 ** -2)
+        d = [{'lr': base / 2, 'params': params1},
+             {'lr': base, 'params': params2},
+             {'lr': base, 'params': list(model_.add_margin.parameters()), 'weight_decay': 1 * (10 ** -4)}]
         d = [g for g in d if len(g['params'])]   # (a backbone without an `fc` layer — Swin's embedding layer is `mlp_head` — has no second group)
         if fused_optimizer and device != 'cpu':
             from optim import FusedSGD
@@ -76,10 +87,15 @@ def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs
         return [optim], [sched]
 
     def train_dataloader():
-        return DataLoader(train, train_bs, shuffle=True, drop_last=True, num_workers=workers)
+        # pinned batches for the copy stream (data_loading/prefetch.py); workers stay alive across epochs like the reference's
+        # persistent_workers loaders (fe_dogs_config.py:135-143)
+        # (batch size and the base rate are read from the config namespace at call time: main.py's find_max_batch_size /
+        # find_optimal_init_lr write train_batch_size / init_lr there, reference main.py:79-89)
+        return DataLoader(train, _live('train_batch_size', train_bs), shuffle=True, drop_last=True, num_workers=workers, pin_memory=device != 'cpu',
+                          persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
 
     def val_dataloader():
-        return DataLoader(val, test_bs, num_workers=0)
+        return DataLoader(val, _live('test_batch_size', test_bs), num_workers=0)
 
     if device_augment:
         # the reference's train/val Compose pipelines (fe_dogs_config.py:17-32) applied on the device to uint8 batches
@@ -94,7 +110,7 @@ def make(ns, arch, n_train_ids, n_val_ids, photos, image_size, train_bs, test_bs
         thrs=np.linspace(0.5, 0.99, 6), far_thr=[0.1, 0.05, 0.03, 0.01, 0.005, 0.001], k=[5, 10, 100],
         pair_generator=pair_generator, similarity_f=similarity_f, model=model, loss=loss, optimizer=optimizer,
         train_dataloader=train_dataloader, val_dataloader=val_dataloader,
-        trainer_kwargs=dict(benchmark=True, limit_train_batches=limit_train_batches),
+        trainer_kwargs=dict(benchmark=True, limit_train_batches=limit_train_batches, limit_val_batches=limit_val_batches),
         output=output, experiment_name='Synthetic', run_name=f'{arch} synthetic',
         device=device, distributed_train=not isinstance(device, str),
         world_size=len(device) if not isinstance(device, str) else None))

@@ -8,8 +8,14 @@ from torch.utils.data import Dataset
 
 
 class SyntheticRecDataset(Dataset):
-    def __init__(self, n_identities, photos_per_identity, image_size=224, seed=0, noise=0.15, raw_uint8=False):
+    def __init__(self, n_identities, photos_per_identity, image_size=224, seed=0, noise=0.15, raw_uint8=False, noise_bank=0):
         self.n_id, self.ppi, self.size, self.seed, self.noise = n_identities, photos_per_identity, image_size, seed, noise
+        # noise_bank = K > 0: the per-photo noise comes from K pre-drawn frames (photo i uses frame i % K) instead of a fresh
+        # 150 k-sample draw per item — a loader whose per-item cost is that of a cached, already decoded frame (throughput runs)
+        self.noise_bank = None
+        if noise_bank:
+            g = torch.Generator().manual_seed(seed * 104729 + 17)
+            self.noise_bank = noise * torch.randn(int(noise_bank), 3, image_size, image_size, generator=g)
         # raw_uint8: hand out the HWC uint8 frame the reference's dataset holds BEFORE its transform (dataset.py:100-121);
         # the augmentation then runs on the device for the whole batch (data_loading/augment.py)
         self.raw_uint8 = raw_uint8
@@ -34,8 +40,11 @@ class SyntheticRecDataset(Dataset):
 
     def __getitem__(self, i):
         ident = int(self.labels[i])
-        g = torch.Generator().manual_seed(self.seed * 7919 + i)
-        x = (self._pattern(ident) + self.noise * torch.randn(3, self.size, self.size, generator=g)).clamp_(0, 1)
+        if self.noise_bank is not None:
+            x = (self._pattern(ident) + self.noise_bank[i % self.noise_bank.shape[0]]).clamp_(0, 1)
+        else:
+            g = torch.Generator().manual_seed(self.seed * 7919 + i)
+            x = (self._pattern(ident) + self.noise * torch.randn(3, self.size, self.size, generator=g)).clamp_(0, 1)
         if self.raw_uint8:
             x = (x * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous()
         return {'x': x, 'label': torch.tensor(self.label_map[ident], dtype=torch.int64), 'index': torch.tensor(i, dtype=torch.int64)}

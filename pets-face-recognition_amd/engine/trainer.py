@@ -11,6 +11,7 @@ step (loops/train_loop.py:13-38); evaluation outputs are handed over as List[dat
 Distributed = one process per GPU started by torchrun (RANK / LOCAL_RANK / WORLD_SIZE), RCCL all-reduce of the flat
 gradient buffer in buckets overlapped with backward (engine/ddp.py)."""
 import os
+import time
 from pathlib import Path
 
 import torch
@@ -26,10 +27,21 @@ def _to_device(batch, device):
     return batch
 
 
+def _batch_size(batch):
+    if isinstance(batch, dict):
+        for v in batch.values():
+            if torch.is_tensor(v) and v.dim() > 0:
+                return int(v.shape[0])
+    if isinstance(batch, (list, tuple)) and batch and torch.is_tensor(batch[0]):
+        return int(batch[0].shape[0])
+    return 0
+
+
 class Trainer:
     def __init__(self, gpus=0, default_root_dir=None, strategy=None, max_epochs=1, logger=False, enable_checkpointing=False,
                  callbacks=None, num_sanity_val_steps=0, limit_train_batches=None, limit_val_batches=None,
-                 check_val_every_n_epoch=1, log_every_n_steps=50, benchmark=None, fast_dev_run=False, **_ignored):
+                 check_val_every_n_epoch=1, log_every_n_steps=50, benchmark=None, fast_dev_run=False, prefetch_batches=2,
+                 **_ignored):
         self.gpus, self.root, self.strategy = gpus, default_root_dir, strategy
         self.max_epochs = 1 if fast_dev_run else max_epochs
         self.logger = logger if logger else None
@@ -44,6 +56,9 @@ class Trainer:
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.global_step = 0
         self.ddp = None
+        # batches copied to the device ahead of the step on a copy stream (data_loading/prefetch.py); 0: plain .to() per batch
+        self.prefetch_batches = int(os.environ.get('PFR_PREFETCH', prefetch_batches))
+        self.train_img_s = None      # end-to-end images/s of the last fit() (loader + copy + step), first 5 steps excluded
 
     # ------------------------------------------------------------------
     @property
@@ -94,10 +109,20 @@ class Trainer:
         for epoch in range(self.max_epochs):
             controller.current_epoch = epoch
             controller.train()
-            for bi, batch in enumerate(controller.train_dataloader()):
+            loader = controller.train_dataloader()
+            if device.type == 'cuda' and self.prefetch_batches > 0:
+                from ..data_loading.prefetch import DevicePrefetcher
+                loader = DevicePrefetcher(loader, device, self.prefetch_batches, self.limit_train_batches)
+            t_mark, n_mark = None, 0
+            for bi, batch in enumerate(loader):
                 if self.limit_train_batches is not None and bi >= self.limit_train_batches:
                     break
+                if bi == 5:      # throughput clock: after the first steps (plan build, allocator warm-up)
+                    if device.type == 'cuda':
+                        torch.cuda.synchronize(device)
+                    t_mark, n_mark = time.perf_counter(), 0
                 batch = _to_device(batch, device)
+                n_mark += _batch_size(batch)
                 optim.zero_grad()
                 loss = controller.training_step(batch, bi)
                 loss.backward()
@@ -110,6 +135,12 @@ class Trainer:
                     history.append(lv)
                     if self.rank == 0:
                         print(f'epoch {epoch} step {self.global_step} loss {lv:.5f}')
+            if t_mark is not None and n_mark:
+                if device.type == 'cuda':
+                    torch.cuda.synchronize(device)
+                self.train_img_s = n_mark * self.world / (time.perf_counter() - t_mark)
+                if self.rank == 0:
+                    print(f'epoch {epoch} train throughput {self.train_img_s:.1f} img/s (loader + copy + step, {self.world} process(es))')
             if (epoch + 1) % self.check_val_every_n_epoch == 0:
                 self._run_eval(controller, device, 'val')
             if self.is_distributed_run:

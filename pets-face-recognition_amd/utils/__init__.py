@@ -117,9 +117,18 @@ def configure_trainer(config, lightning_logger=None, lightning_log_dir=None):
                    enable_checkpointing=True, callbacks=config.get('callbacks'), **config.get('trainer_kwargs', {}))
 
 
-def find_max_batch_size(trainer, model):  # the reference's tuner hooks need PL internals; not part of the hot path
-    raise NotImplementedError("batch-size finder is not part of the FE hot path")
+def find_max_batch_size(trainer, model):
+    """reference utils/__init__.py:137-141 (PL tuner `scale_batch_size`) — see utils/tuner.py"""
+    from .tuner import scale_batch_size
+    new_batch_size = scale_batch_size(trainer, model, **model.config.get('find_max_batch_size_kwargs', {}))
+    if new_batch_size is not None:
+        print(f'Computed new batch size = {new_batch_size}')
+        return new_batch_size
 
 
 def find_optimal_init_lr(trainer, model):
-    raise NotImplementedError("lr finder is not part of the FE hot path")
+    """reference utils/__init__.py:144-148 (PL tuner `lr_find(...).suggestion()`) — see utils/tuner.py"""
+    from .tuner import lr_find
+    new_lr = lr_find(trainer, model, **model.config.get('find_optimal_init_lr_kwargs', {})).suggestion()
+    print(f'Computed new init lr = {new_lr}')
+    return new_lr

@@ -249,3 +249,50 @@ def test_flat_ddp_hook_ordering_gloo_world2(tmp_path):
                         "127.0.0.1", "--master-port", "29637", str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count("ok") == 2
+
+
+def test_device_prefetcher_order_limit_and_errors():
+    """data_loading/prefetch.py on the CPU path and its contract: same batches in the same order as the loader, `limit` respected,
+    a loader exception reaches the consumer, early exit of the consumer stops the feeder"""
+    from pets_face_recognition_amd.data_loading import DevicePrefetcher
+    batches = [{'x': torch.full((4, 3), float(i)), 'label': torch.arange(4) + i, 'tag': i} for i in range(7)]
+    got = list(DevicePrefetcher(batches, 'cpu', depth=2))
+    assert [b['tag'] for b in got] == list(range(7)) and all(torch.equal(a['x'], b['x']) for a, b in zip(got, batches))
+    assert len(list(DevicePrefetcher(batches, 'cpu', depth=2, limit=3))) == 3
+    assert len(DevicePrefetcher(batches, 'cpu', limit=3)) == 3
+
+    def bad():
+        yield batches[0]
+        raise ValueError("decode failed")
+    with pytest.raises(ValueError):
+        list(DevicePrefetcher(bad(), 'cpu'))
+
+
+def test_synthetic_dataset_noise_bank_is_deterministic_and_labelled():
+    from pets_face_recognition_amd.data_loading import SyntheticRecDataset
+    a = SyntheticRecDataset(5, 3, 32, seed=1, raw_uint8=True, noise_bank=4)
+    b = SyntheticRecDataset(5, 3, 32, seed=1, raw_uint8=True, noise_bank=4)
+    assert torch.equal(a[7]['x'], b[7]['x']) and a[7]['x'].dtype == torch.uint8 and a[7]['x'].shape == (32, 32, 3)
+    assert int(a[7]['label']) == 2 and not torch.equal(a[7]['x'], a[8]['x'])
+
+
+def test_main_runs_batch_size_and_lr_finders(tmp_path):
+    """reference main.py:79-89: config.find_max_batch_size / find_optimal_init_lr -> utils.find_max_batch_size (power scaling) and
+    utils.find_optimal_init_lr (exponential sweep, steepest-descent suggestion); the found values reach the loaders / optimizer"""
+    cfg = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic", "fe_r18_cpu_tuned.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", cfg], cwd=tmp_path, env=dict(os.environ),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Computed new batch size = 16" in r.stdout      # 4 -> 8 -> 16: three trials
+    lr = float(r.stdout.split("Computed new init lr = ")[1].split()[0])
+    assert 1e-5 <= lr <= 1.0
+    assert "Completed!" in r.stdout
+
+
+def test_lr_finder_suggestion_is_the_steepest_descent():
+    from pets_face_recognition_amd.utils.tuner import LRFinderResult
+    lrs = list(np.geomspace(1e-6, 1, 40))
+    loss = [5.0] * 15 + list(np.linspace(5.0, 1.0, 10)) + [1.0] * 5 + list(np.linspace(1.0, 9.0, 10))
+    loss[18] -= 0.6
+    s = LRFinderResult(lrs, loss).suggestion()
+    assert s in (lrs[17], lrs[18]) and LRFinderResult(lrs[:5], loss[:5]).suggestion() is None
