@@ -209,7 +209,7 @@ def extras(args, device):
     try:
         cfg = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic", "fe_r50_mi355x_pipeline.py")
         ncpu = os.cpu_count() or 8
-        env = dict(os.environ, PFR_LIMIT_TRAIN_BATCHES="45", PFR_LIMIT_VAL_BATCHES="1", PFR_WORKERS=str(max(4, min(32, ncpu - 2))))
+        env = dict(os.environ, PFR_LIMIT_TRAIN_BATCHES="45", PFR_VAL_IDS="32", PFR_WORKERS=str(max(4, min(16, ncpu - 2))))
         import tempfile
         with tempfile.TemporaryDirectory() as td:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", cfg], env=env, cwd=td, capture_output=True,

@@ -7,7 +7,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _common import make as _make
 
-_make(globals(), arch='resnet50', n_train_ids=10000, n_val_ids=200, photos=4, image_size=224, train_bs=256, test_bs=64,
+_make(globals(), arch='resnet50', n_train_ids=10000, n_val_ids=int(os.environ.get('PFR_VAL_IDS', '200')), photos=4, image_size=224, train_bs=256, test_bs=64,
       device='cuda:0', n_epochs=1, limit_train_batches=int(os.environ.get('PFR_LIMIT_TRAIN_BATCHES', '60')),
-      workers=int(os.environ.get('PFR_WORKERS', '16')), device_augment=True, noise_bank=64,
-      limit_val_batches=int(os.environ.get('PFR_LIMIT_VAL_BATCHES', '4')))
+      workers=int(os.environ.get('PFR_WORKERS', '16')), device_augment=True, noise_bank=64)

@@ -142,6 +142,9 @@ def pair_similarity(emb, idx_a, idx_b, eps=1e-8):
     if not emb.is_cuda:
         a, b = emb[ia], emb[ib]
         return ((a * b).sum(1) / (a.norm(dim=1).clamp_min(eps) * b.norm(dim=1).clamp_min(eps)) + 1) / 2
+    if ia.numel() and (int(torch.stack([ia.min(), ib.min()]).min()) < 0 or int(torch.stack([ia.max(), ib.max()]).max()) >= emb.shape[0]):
+        # the torch indexing of the reference raises here; a device gather would read outside the embedding matrix
+        raise IndexError(f"pair index out of range for {emb.shape[0]} embeddings (evaluation truncated by limit_val_batches?)")
     e = emb.float().contiguous()
     out = torch.empty(ia.numel(), dtype=torch.float32, device=emb.device)
     lib.pfr_pair_similarity(e.data_ptr(), e.shape[1], ia.data_ptr(), ib.data_ptr(), ia.numel(), float(eps), out.data_ptr(), _stream())
