@@ -53,6 +53,17 @@ __device__ __forceinline__ void mma_kstep(const char* ldsP, const char* ldsQ, in
 }
 
 // accumulator element (reg r of a 32x32 tile) -> row within the tile; column is lane & 31.
+// 16-byte buffer store whose data registers stay untouched until the hardware has READ them.  Measured on gfx950: a
+// buffer_store_dwordx4 reads its data VGPRs from the register file late when the wave's vector-memory queue is deep (tens of LDS-DMA /
+// store instructions in flight); hipcc assumes store data is read at issue and re-uses the registers in the very next instruction
+// (an LDS read of the next pass, or just an address add that the scheduler moved up — a separate `s_waitcnt expcnt(0)` statement
+// after the store does NOT stop that), so the last quad lanes of the first data dword went out overwritten.  EXP_CNT tracks the
+// read-out: the store and the wait are ONE asm statement here, nothing can be scheduled between them.  (s_nop: soff may come
+// straight from the scalar ALU and nothing inside an asm statement is hazard-padded by the compiler.)
+__device__ __forceinline__ void buffer_store_b128_sync(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_waitcnt expcnt(0)" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ------------------------------------------------------------------------------------------------

@@ -35,6 +35,8 @@ struct SconvParams {
   float* stats_part;      // [nranges][2][N] (mean, M2) or nullptr
   const void* res;        // join: residual-branch gradient [M][N] bf16, or nullptr
   const unsigned char* res_mask;   // join: its ReLU bit mask [M][N/8]
+  const float* bias;      // inference epilogue (EP >= 2): per-cout bias of the BN-folded convolution
+  int relu;               // inference epilogue: ReLU after bias (+ residual)
   int npanels, nranges, R;    // R: rows per range (multiple of the 32-row block height)
   int npw;                    // couts of a workgroup's weight panel (64, 128 or 256)
   int interleave;             // 1: block-interleaved row assignment (needs M % 32 == 0 and M / 32 divisible by nranges)
@@ -43,16 +45,21 @@ struct SconvParams {
 };
 
 // TP: 32-cout accumulator tiles per wave (the wave's column slice is TP*32 couts), NS: ring slots per wave, STATS: BatchNorm partials
-// JOIN: y = result + (mask bit ? res : 0) — the residual join of a block's first data gradient (pfr_conv2d_dgrad_join)
-template <int TP, int NS, bool STATS, bool JOIN = false>
+// EP (epilogue): 0 plain; 1 JOIN: y = result + (mask bit ? res : 0) — the residual join of a block's first data gradient
+// (pfr_conv2d_dgrad_join); 2: y = relu?(result + bias); 3: y = relu?(result + bias + res) — the BN-folded inference convolutions
+// (Controller.validation_step / generate_tsv embedder).  EP 2 / 3 add to the bf16-rounded result in the read-back pass (the window
+// holds bf16), i.e. one more bf16 rounding of the pre-activation than the tile kernel's fp32 epilogue.
+template <int TP, int NS, bool STATS, int EP = 0>
 __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
-  static_assert(!(STATS && JOIN), "the join variant publishes no statistics");
+  constexpr bool JOIN = EP == 1;
+  constexpr bool HASRES = EP == 1 || EP == 3;
+  static_assert(!(STATS && EP != 0), "only the plain variant publishes statistics");
   constexpr int NPV = TP * 32;           // couts per wave
   constexpr int GB = 4096;               // granule bytes: [32 rows][64 k] bf16
   constexpr int GI = 4;                  // DMA instructions per granule
   constexpr int NCG = NPV / 64;          // 64-cout column groups of the epilogue
   constexpr int SB = NPV / 16;           // store instructions per block (32 rows x NPV couts x 2 B / 1 KiB)
-  constexpr int RL = JOIN ? 2 * SB : 0;  // residual + mask load instructions per block (join)
+  constexpr int RL = JOIN ? 2 * SB : (HASRES ? SB : 0);  // residual (+ mask) load instructions per block
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -87,6 +94,16 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0, p.M * p.N * 2, 0x00020000);
   __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.res_mask ? p.res_mask : (const unsigned char*)p.y), 0, p.M * (p.N >> 3), 0x00020000);
 
+  // inference epilogue: this lane's 8 couts of every column group (read-back layout), fetched before any DMA is in flight
+  float bias8[NCG][8];
+  if constexpr (EP >= 2) {
+    const int e_ch0 = lane & 7;
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias8[g][e] = p.bias[n0 + g * 64 + e_ch0 * 8 + e];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   // ---- weight panel -> LDS (once): linear LDS image, XOR swizzle on the source side
   {
     const int ninst = wbytes >> 10;
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
     // vmcnt(0) — draining the DMA ring — for any load it knows of; these are counted by hand (wait_granule, epilogue).
     u32x4 rres[NCG][4];
     uint32_t rmk[NCG][4];
-    if constexpr (JOIN) {
+    if constexpr (HASRES) {
       const uint32_t rbase = (uint32_t)((m0 * p.N + n0) * 2), kbase = (uint32_t)(m0 * (p.N >> 3) + (n0 >> 3));
 #pragma unroll
       for (int g = 0; g < NCG; ++g)
@@ -211,10 +228,11 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
                        : "=v"(rres[g][ps])
                        : "v"(y_lane + (uint32_t)(g * 128)), "s"(rrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
                        : "memory");
-          asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen"
-                       : "=v"(rmk[g][ps])
-                       : "v"(k_lane + (uint32_t)(g * 8)), "s"(mrsrc), "s"(kbase + (uint32_t)(ps * p.N))
-                       : "memory");
+          if constexpr (JOIN)
+            asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen"
+                         : "=v"(rmk[g][ps])
+                         : "v"(k_lane + (uint32_t)(g * 8)), "s"(mrsrc), "s"(kbase + (uint32_t)(ps * p.N))
+                         : "memory");
         }
     }
     // ---- granules of the block: the first one starts the accumulators from a constant-zero C operand
@@ -254,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
     hist |= 1u;
     const uint32_t wbase = ring0 + ((slot + NS - 1) % NS) * GB;
     const uint32_t ybase = (uint32_t)((m0 * p.N + n0) * 2);
-    if constexpr (JOIN) {
+    if constexpr (HASRES) {
       // the residual loads are older than the KG granules issued during this block
       if (KG == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GI) : "memory");
       else if (KG == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GI) : "memory");
@@ -295,29 +313,31 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
             s2[g][e] = __builtin_elementwise_fma(d, d, s2[g][e]);
           }
         }
-        if constexpr (JOIN) {
+        if constexpr (EP != 0) {
           float f[8], rr8[8];
           Chunk<bf16_t>::unpack(v, f);
-          Chunk<bf16_t>::unpack(rres[g][ps], rr8);
-          const uint32_t bits = rmk[g][ps];
+          if constexpr (HASRES) Chunk<bf16_t>::unpack(rres[g][ps], rr8);
+          if constexpr (JOIN) {
+            const uint32_t bits = rmk[g][ps];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += ((bits >> e) & 1u) ? rr8[e] : 0.f;
+            for (int e = 0; e < 8; ++e) f[e] += ((bits >> e) & 1u) ? rr8[e] : 0.f;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              f[e] += bias8[g][e];
+              if constexpr (HASRES) f[e] += rr8[e];
+              if (p.relu) f[e] = fmaxf(f[e], 0.f);
+            }
+          }
           const u32x4 o = Chunk<bf16_t>::pack(f);
-          __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, (int)(y_lane + (uint32_t)(g * 128)), (int)(ybase + (uint32_t)(ps * 8 * p.N * 2)), 0);
-          asm volatile("s_waitcnt expcnt(0)" ::: "memory");   // (store data read-out: see below)
+          buffer_store_b128_sync(o, yrsrc, y_lane + (uint32_t)(g * 128), ybase + (uint32_t)(ps * 8 * p.N * 2));
           continue;
         }
         // rows past M lie beyond num_records: the store is dropped
-        __builtin_amdgcn_raw_buffer_store_b128(v, yrsrc, (int)(y_lane + (uint32_t)(g * 128)), (int)(ybase + (uint32_t)(ps * 8 * p.N * 2)), 0);
-        // MEASURED on gfx950: a buffer_store_dwordx4 reads its data VGPRs from the register file LATE when the wave's vector-memory
-        // queue is deep (here up to ~28 DMA / store instructions in flight).  hipcc assumes store data is read at issue and
-        // re-uses the registers at once — for the next pass's LDS read, or the next iteration's DMA address — so the last quad
-        // lanes of the first data dword went out overwritten (tens to ~1000 rows of 800 k per launch, NaN / byte offsets).  The
-        // read-out IS tracked by EXP_CNT: wait for it after EVERY store, before anything can touch its registers.
-        asm volatile("s_waitcnt expcnt(0)" ::: "memory");
+        // (store + wait for the data read-out in one statement: buffer_store_b128_sync, pfr_mma.h)
+        buffer_store_b128_sync(v, yrsrc, y_lane + (uint32_t)(g * 128), ybase + (uint32_t)(ps * 8 * p.N * 2));
       }
     }
-    asm volatile("s_waitcnt expcnt(0)" ::: "memory");
   }
   // drain: the dummy granules issued past the end must have landed before the LDS is reused or released
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,13 +450,13 @@ bool sconv_plan(int M, int N, int K, int dtype, int out_dtype, SconvPlan* sp) {
   return true;
 }
 
-template <int TP, bool STATS, bool JOIN = false>
+template <int TP, bool STATS, int EP = 0>
 static int sconv_launch_ns(SconvParams& sp, const SconvPlan& pl, hipStream_t st) {
   const int lds = pl.np * sp.K * 2 + 8 * pl.ns * 4096;
   const dim3 grid(256), block(512);
 #define PFR_SCONV_GO(NSV)                                                                                       \
   do {                                                                                                          \
-    auto kern = sconv_kernel<TP, NSV, STATS, JOIN>;                                                                   \
+    auto kern = sconv_kernel<TP, NSV, STATS, EP>;                                                                     \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
@@ -455,8 +475,12 @@ static int sconv_launch_ns(SconvParams& sp, const SconvPlan& pl, hipStream_t st)
 // takes the launch when it is a plain 1x1 convolution of an eligible geometry; returns 1 when it is not
 int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (p.R != 1 || p.S != 1 || p.pad != 0 || p.idil_log2 != 0 || p.ldy != p.Cout) return 1;
-  if (p.bias || p.accumulate || p.out_relu || p.pro_scale || p.act || p.bnb_part[0]) return 1;
-  const bool join = p.residual != nullptr;
+  if (p.accumulate || p.pro_scale || p.act || p.bnb_part[0]) return 1;
+  // inference form: bias (+ plain residual add) (+ ReLU), no statistics; training forms: no bias / ReLU, residual only as the join
+  const bool infer = p.bias != nullptr;
+  if (infer && (p.stats_part || p.res_mask)) return 1;
+  if (!infer && p.out_relu) return 1;
+  const bool join = !infer && p.residual != nullptr;
   if (join && (!p.res_mask || p.stats_part)) return 1;   // residual only in its data-gradient join form (bit mask)
   if (p.ostride != 1 && (p.H != p.OH * p.ostride || p.W != p.OW * p.ostride)) return 1;
   if ((long)p.N * p.H * p.W * p.K * 2 >= ((long)1 << 31)) return 1;
@@ -468,12 +492,17 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.H = p.H; sp.W = p.W; sp.OH = p.OH; sp.OW = p.OW; sp.ostride = p.ostride;
   sp.stats_part = p.stats_part;
   sp.res = p.residual; sp.res_mask = p.res_mask;
+  sp.bias = p.bias; sp.relu = p.out_relu;
   sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
   static const bool il_on = !(getenv("PFR_SCONV_INTERLEAVE") && getenv("PFR_SCONV_INTERLEAVE")[0] == '0');
   sp.interleave = (il_on && p.M % 32 == 0 && (p.M / 32) % pl.nranges == 0 && (long)pl.R * pl.nranges == p.M) ? 1 : 0;
   sp.xbytes = (int)((long)p.N * p.H * p.W * p.K * 2);
   sp.div_ohow = p.div_ohow; sp.div_ow = p.div_ow;
-  if (join) return pl.tp == 2 ? sconv_launch_ns<2, false, true>(sp, pl, st) : sconv_launch_ns<4, false, true>(sp, pl, st);
+  if (infer) {
+    if (p.residual) return pl.tp == 2 ? sconv_launch_ns<2, false, 3>(sp, pl, st) : sconv_launch_ns<4, false, 3>(sp, pl, st);
+    return pl.tp == 2 ? sconv_launch_ns<2, false, 2>(sp, pl, st) : sconv_launch_ns<4, false, 2>(sp, pl, st);
+  }
+  if (join) return pl.tp == 2 ? sconv_launch_ns<2, false, 1>(sp, pl, st) : sconv_launch_ns<4, false, 1>(sp, pl, st);
   if (pl.tp == 2) return p.stats_part ? sconv_launch_ns<2, true>(sp, pl, st) : sconv_launch_ns<2, false>(sp, pl, st);
   return p.stats_part ? sconv_launch_ns<4, true>(sp, pl, st) : sconv_launch_ns<4, false>(sp, pl, st);
 }

@@ -195,10 +195,9 @@ __global__ __launch_bounds__(256, 1) void sconv3_kernel(Sconv3Params p) {
 #ifdef PFR_S3_NOSTORE
     if (v[0] != 0x12345u) return;
 #endif
-    __builtin_amdgcn_raw_buffer_store_b128(v, yrsrc, (int)(lane << 4), (int)(e_ybase + (uint32_t)(ps * p.W * 128)), 0);
-    // store data registers are read late under a deep vector-memory queue and hipcc re-uses them at once (pfr_sconv.hip):
-    // EXP_CNT tracks the read-out — wait after every store
-    asm volatile("s_waitcnt expcnt(0)" ::: "memory");
+    // store data registers are read late under a deep vector-memory queue and hipcc re-uses them at once: store + EXP_CNT wait
+    // in one asm statement (buffer_store_b128_sync, pfr_mma.h)
+    buffer_store_b128_sync(v, yrsrc, (uint32_t)(lane << 4), e_ybase + (uint32_t)(ps * p.W * 128));
   };
 
   // ---- one patch: 36 k16 steps into `cur`; in their shadow the DMA of the next tile (steps 0-7), the addresses of the one after
@@ -262,7 +261,6 @@ __global__ __launch_bounds__(256, 1) void sconv3_kernel(Sconv3Params p) {
         else if (kq < 26) epi_write(prv, kq - 18);
         else if (kq == 26) epi_shift();
         else if (kq < 31) epi_row(kq - 27);
-        else if (kq == 31) asm volatile("s_waitcnt expcnt(0)" ::: "memory");   // store data read-out (see pfr_sconv.hip)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -298,7 +296,6 @@ __global__ __launch_bounds__(256, 1) void sconv3_kernel(Sconv3Params p) {
     epi_shift();
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) epi_row(ps);
-    asm volatile("s_waitcnt expcnt(0)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef PFR_S3_TRACE

@@ -436,23 +436,27 @@ __device__ __forceinline__ u32x2 lds_read_tr16(uint32_t addr, int imm) {
 }
 template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BP, int BQ>
-__global__ __launch_bounds__(256) void wgrad3_kernel(WgradParams p) {
+// NW waves in a WGP x WGQ grid over the (cout, kk) tile: 4 waves 2x2 (64 KB of LDS, two workgroups per CU) or 8 waves 4x2 on a
+// 256-wide tile (128 KB, one workgroup per CU: half the operand bytes staged per MFMA, and the 64x128 wave tile needs 12 transpose
+// reads per 8 MFMAs instead of 8 per 4 — at full MFMA rate the 2x2 form saturates the 128 B/clk LDS port)
+template <int BP, int BQ, int NW = 4, int WGQ = 2>
+__global__ __launch_bounds__(NW * 64) void wgrad3_kernel(WgradParams p) {
   using T = bf16_t;
   constexpr int KP = 8, BMR = 32, NST = 4;
-  constexpr int TP = BP / 64, TQ = BQ / 64;
+  constexpr int WGP = NW / WGQ;
+  constexpr int TP = BP / (WGP * 32), TQ = BQ / (WGQ * 32);
   constexpr int RSP = BP * 2, RSQ = BQ * 2;
   constexpr int GPRP = RSP / 32, GPRQ = RSQ / 32;
   constexpr int TILEP = BMR * RSP, TILEQ = BMR * RSQ, STAGE = TILEP + TILEQ;
   constexpr int RPIP = 1024 / RSP, RPIQ = 1024 / RSQ;
-  constexpr int NDP = BMR / (4 * RPIP), NDQ = BMR / (4 * RPIQ);
+  constexpr int NDP = BMR / (NW * RPIP), NDQ = BMR / (NW * RPIQ);
   constexpr int IPS = NDP + NDQ, D = NST - 1;
-  static_assert(NDP >= 1 && NDQ >= 1 && NST * STAGE <= 65536, "tile geometry");
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+  static_assert(NDP >= 1 && NDQ >= 1 && NST * STAGE <= 160 * 1024 && TP >= 1 && TQ >= 1, "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wave >> 1, wq = wave & 1;
+  const int wp = wave / WGQ, wq = wave % WGQ;
   const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = p.tilesP * p.tilesQ;
   const int split = t / ntile, tile = t % ntile;
@@ -480,14 +484,14 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradParams p) {
   uint32_t voffP[NDP], voffQ[NDQ];
 #pragma unroll
   for (int j = 0; j < NDP; ++j)
-    voffP[j] = pco < p.Cout ? (uint32_t)((((j * 4 + wave) * RPIP + prsub) * p.lddy + pco) * 2) : OOB;
+    voffP[j] = pco < p.Cout ? (uint32_t)((((j * NW + wave) * RPIP + prsub) * p.lddy + pco) * 2) : OOB;
   // gathered-x walker state per DMA pass (general form only)
   int w_ow[NDQ], w_oh[NDQ], w_rem[NDQ];
   uint32_t w_nb[NDQ];
   const uint32_t hwc2 = (uint32_t)p.H * p.W * p.C * 2, wc2 = (uint32_t)p.W * p.C * 2, c2 = (uint32_t)p.C * 2;
 #pragma unroll
   for (int j = 0; j < NDQ; ++j) {
-    const int rowj = (j * 4 + wave) * RPIQ + qrsub;
+    const int rowj = (j * NW + wave) * RPIQ + qrsub;
     if (p.simple) {
       voffQ[j] = kkok ? (uint32_t)((rowj * p.C + ci) * 2) : OOB;
     } else {
@@ -516,14 +520,14 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradParams p) {
                                                                   left * p.lddy * 2, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NDP; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (__attribute__((address_space(3))) void*)(base + (j * 4 + wave) * RPIP * RSP), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (__attribute__((address_space(3))) void*)(base + (j * NW + wave) * RPIP * RSP), 16,
                                                (int)voffP[j], 0, 0, 0);
     if (p.simple) {
       __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb + (size_t)mb * p.C * 2), 0,
                                                                     left * p.C * 2, 0x00020000);
 #pragma unroll
       for (int j = 0; j < NDQ; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(qr, (__attribute__((address_space(3))) void*)(base + TILEP + (j * 4 + wave) * RPIQ * RSQ),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qr, (__attribute__((address_space(3))) void*)(base + TILEP + (j * NW + wave) * RPIQ * RSQ),
                                                  16, (int)voffQ[j], 0, 0, 0);
     } else {
 #pragma unroll
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradParams p) {
         const int ih = w_oh[j] * p.stride + dih, iw = w_ow[j] * p.stride + diw;
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && w_rem[j] > 0;
         const uint32_t off = ok ? w_nb[j] + (uint32_t)ih * wc2 + (uint32_t)iw * c2 : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + TILEP + (j * 4 + wave) * RPIQ * RSQ),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + TILEP + (j * NW + wave) * RPIQ * RSQ),
                                                  16, (int)off, 0, 0, 0);
         // advance this lane's row by BMR output pixels: columns, then rows, then images (each wraps at most once)
         int ow = w_ow[j] + p.adv_r2;
@@ -563,12 +567,12 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradParams p) {
   uint32_t laneP[TP], laneQ[TQ];
 #pragma unroll
   for (int i = 0; i < TP; ++i) {
-    const int gran = (wp * (BP / 2) + i * 32) / 16 + (g & 1);
+    const int gran = (wp * (BP / WGP) + i * 32) / 16 + (g & 1);
     laneP[i] = lds0 + r0 * RSP + ((gran ^ gran_swz<GPRP>(r0)) << 5) + (s4 & 3) * 8;
   }
 #pragma unroll
   for (int j = 0; j < TQ; ++j) {
-    const int gran = (wq * (BQ / 2) + j * 32) / 16 + (g & 1);
+    const int gran = (wq * (BQ / WGQ) + j * 32) / 16 + (g & 1);
     laneQ[j] = lds0 + TILEP + r0 * RSQ + ((gran ^ gran_swz<GPRQ>(r0)) << 5) + (s4 & 3) * 8;
   }
 
@@ -590,9 +594,17 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradParams p) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
 #pragma unroll
-        for (int i = 0; i < TP; ++i) hp[b][i][q] = lds_read_tr16(laneP[i], SLOT * STAGE + (KG * 16 + q * 4) * RSP);
+        for (int i = 0; i < TP; ++i) {
+          constexpr int off = SLOT * STAGE + (KG * 16 + 4) * RSP;   // largest offset of the pair; the ds immediate is 16 bits
+          constexpr int hi = off >= 65536 ? ((SLOT * STAGE) & ~32767) : 0;
+          hp[b][i][q] = lds_read_tr16(laneP[i] + hi, SLOT * STAGE - hi + (KG * 16 + q * 4) * RSP);
+        }
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) hq[b][j][q] = lds_read_tr16(laneQ[j], SLOT * STAGE + (KG * 16 + q * 4) * RSQ);
+        for (int j = 0; j < TQ; ++j) {
+          constexpr int off = SLOT * STAGE + (KG * 16 + 4) * RSQ + TILEP;
+          constexpr int hi = off >= 65536 ? ((SLOT * STAGE) & ~32767) : 0;
+          hq[b][j][q] = lds_read_tr16(laneQ[j] + hi, SLOT * STAGE - hi + (KG * 16 + q * 4) * RSQ);
+        }
       }
     };
     auto mma = [&](int b) __attribute__((always_inline)) {
@@ -634,10 +646,10 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradParams p) {
   for (int i = 0; i < TP; ++i)
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
-      const int col = kk0 + wq * (BQ / 2) + j * 32 + (lane & 31);
+      const int col = kk0 + wq * (BQ / WGQ) + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wp * (BP / 2) + i * 32 + acc_row(r, lane);
+        const int co = co0 + wp * (BP / WGP) + i * 32 + acc_row(r, lane);
         if (co < p.Cout && col < p.KK) out[(size_t)co * p.KK + col] = acc[i][j][r];
       }
     }
@@ -684,8 +696,12 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
   const dim3 grid((unsigned)(p.tilesP * p.tilesQ * p.splits));
   if (p.pro_scale)
     hipLaunchKernelGGL((wgrad_kernel<T, BP, BQ, true>), grid, dim3(256), 0, st, p);
-  else if (p.v2 && sizeof(T) == 2 && wgrad_v3())
-    hipLaunchKernelGGL((wgrad3_kernel<BP, BQ>), grid, dim3(256), 0, st, p);
+  else if (p.v2 && sizeof(T) == 2 && wgrad_v3()) {
+    constexpr int lds = 4 * 32 * (BP + BQ) * 2;   // ring of 4 stages of 32 rows
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)wgrad3_kernel<BP, BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((wgrad3_kernel<BP, BQ>), grid, dim3(256), lds, st, p);
+  }
   else if (p.v2)
     hipLaunchKernelGGL((wgrad2_kernel<T, BP, BQ>), grid, dim3(256), 0, st, p);
   else
@@ -701,6 +717,24 @@ static void wgrad_tiles(int Cout, int KK, int* bp, int* bq) {
   if (forced >= 0) { *bp = (forced & 1) ? 64 : 128; *bq = (forced & 2) ? 64 : 128; }
 }
 
+// 8-wave 256x256 tiles (wgrad3_kernel<256, 256, 8, 2>; bf16, no fused prologue).  PFR_WGRAD_BIG / pfr_set_tuning("wgrad_big"):
+// 0 never (default), 1 whole-tile geometries, 2 wherever the geometry allows.  MEASURED (tools/wgrad_bench.py,
+// profiles/r03_wgrad_tiles.txt): half the operand bytes per MFMA, yet 0.84-0.89x on most ResNet-50 / Swin-T geometries and at
+// best 1.06-1.18x on three — one 8-wave workgroup per CU behind ONE barrier per 32-row stage hides less latency than two
+// independent 4-wave workgroups; the kernel is bound by that hand-over, not by LDS or L2 bandwidth.
+static int g_wgrad_big = -1;
+void wgrad_set_big(int v) { g_wgrad_big = v; }
+static int wgrad_big_mode() {
+  if (g_wgrad_big < 0) { const char* e = getenv("PFR_WGRAD_BIG"); g_wgrad_big = e ? atoi(e) : 0; }
+  return g_wgrad_big;
+}
+static bool wgrad_big_geom(int M, int Cout, int KK) {
+  const int mode = wgrad_big_mode();
+  if (mode == 0 || Cout < 256 || KK < 256 || Cout % 8 || KK % 8) return false;
+  if (mode >= 2) return true;
+  return Cout % 256 == 0 && KK % 256 == 0;
+}
+
 // number of m-splits the launcher uses (the caller sizes the workspace as splits*Cout*KK floats).
 // Two workgroups fit a CU (64 KB of LDS each) and a CU runs two about as fast as one (the kernel waits on DMA latency), so a
 // launch of W = tiles*s workgroups takes ceil(W / 512) rounds of M/s rows: s is chosen to minimise
@@ -710,6 +744,11 @@ static void wgrad_tiles(int Cout, int KK, int* bp, int* bq) {
 extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   int bp, bq;
   wgrad_tiles(Cout, KK, &bp, &bq);
+  // (the 256x256 form is only taken by bf16 launches without a fused prologue; others run 128-wide tiles over the same number of
+  // slabs, which is merely a different trade-off, not an error)
+  const bool big = wgrad_big_geom(M, Cout, KK);
+  if (big) bp = bq = 256;
+  const long slots = big ? 256 : 512;
   const long tiles = (long)((Cout + bp - 1) / bp) * ((KK + bq - 1) / bq);
   const long maxs = (M + 255) / 256;       // at least 256 reduction rows per split
   const long slab = (long)Cout * KK * 4;
@@ -722,8 +761,8 @@ extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   long best = 1;
   double best_t = 1e30;
   for (long s = 1; s <= cap && s * tiles <= 4096; ++s) {
-    const long w = tiles * s, rounds = (w + 511) / 512;
-    const double t = t_pass * (double)(rounds * 512) / (double)w + (double)s * slab * 2.0 / 4.0e12;
+    const long w = tiles * s, rounds = (w + slots - 1) / slots;
+    const double t = t_pass * (double)(rounds * slots) / (double)w + (double)s * slab * 2.0 / 4.0e12;
     if (t < best_t * 0.999) { best_t = t; best = s; }
   }
   static const int forced = getenv("PFR_WGRAD_FORCE_SPLITS") ? atoi(getenv("PFR_WGRAD_FORCE_SPLITS")) : 0;   // tuning sweeps
@@ -760,6 +799,16 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.dw = direct ? dw : workspace;
   int bp, bq, rc;
   wgrad_tiles(Cout, p.KK, &bp, &bq);
+  if (dtype == PFR_BF16 && p.v2 && wgrad_v3() && wgrad_big_geom(p.M, Cout, p.KK)) {
+    p.tilesP = (p.Cout + 255) / 256;
+    p.tilesQ = (p.KK + 255) / 256;
+    constexpr int lds = 4 * 32 * (256 + 256) * 2;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)wgrad3_kernel<256, 256, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((wgrad3_kernel<256, 256, 8, 2>), dim3((unsigned)(p.tilesP * p.tilesQ * p.splits)), dim3(512), lds, stream, p);
+    PFR_CHECK_LAUNCH();
+    rc = PFR_OK;
+  } else {
 #define PFR_WG_DISPATCH(T)                                        \
   if (bp == 128 && bq == 128) rc = launch_wgrad<T, 128, 128>(p, stream); \
   else if (bp == 128) rc = launch_wgrad<T, 128, 64>(p, stream);   \
@@ -767,6 +816,7 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   else rc = launch_wgrad<T, 64, 64>(p, stream);
   if (dtype == PFR_BF16) { PFR_WG_DISPATCH(bf16_t) } else { PFR_WG_DISPATCH(float) }
 #undef PFR_WG_DISPATCH
+  }
   if (rc != PFR_OK) return rc;
   if (!direct) {
     const size_t n4 = (size_t)Cout * p.KK / 4;  // Cout*KK is a multiple of 16 (both are multiples of the 16-byte chunk)

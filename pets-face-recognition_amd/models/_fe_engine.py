@@ -47,6 +47,35 @@ def flat_layout(model):
     return offs, total
 
 
+def _batch_side(ops, batch):
+    """Experiment (PFR_WGRAD_BATCH=n): hand the weight gradients to the side stream n at a time — one fork (completion signal on
+    the main queue) per n instead of one per layer.  A deferred group is flushed before anything that waits for one of its members."""
+    out, held = [], []
+
+    def flush():
+        if held:
+            out.append(("fork", (held[0][0],)))
+            for k, op in held:
+                out.append(op)
+                out.append(("srec", (k,)))
+            held.clear()
+    i = 0
+    while i < len(ops):
+        fn, args = ops[i]
+        if fn == "fork" and i + 2 < len(ops) and ops[i + 2][0] == "srec":
+            held.append((args[0], ops[i + 1]))
+            i += 3
+            if len(held) >= batch:
+                flush()
+            continue
+        if fn in ("wait", "mwait") and held and args[0] >= held[0][0]:
+            flush()
+        out.append(ops[i])
+        i += 1
+    flush()
+    return out
+
+
 def grad_ready_marks(model):
     """The offsets `off` at which the backward pass reports "flat gradient [off, end) is final" (FEEngine._mark), in the order
     it reports them: after fc, after every residual block (last block first; a block's first parameter is conv1.weight),
@@ -840,6 +869,9 @@ class FEEngine:
             ops.append(("wait", (nside[0] - 1,)))   # the un-padding copy below reads what the stem wgrad wrote
             ops.append(("copy2d", (st.g_pad.data_ptr(), self.cp, st.g.data_ptr(), st.Cin, st.Cout * st.R * st.S, st.Cin, 1.0, acc)))
         self._mark(ops, 0)
+        batch = int(os.environ.get("PFR_WGRAD_BATCH", "1"))
+        if batch > 1:
+            ops[plan.meta["n_fwd"]:] = _batch_side(ops[plan.meta["n_fwd"]:], batch)
         plan.meta["n_side"] = nside[0]
         # workspace
         if self.ws is None or self.ws.numel() < ws_need[0]:

@@ -677,3 +677,41 @@ def test_bn_backward_reduce_finalize_one_launch(dtype, rows, C, mask_mode):
         assert ((dg_b - dg_a).abs() / scale_gx).max().item() < 2e-6
         assert torch.allclose(coef_b, coef_a, rtol=2e-4, atol=1e-5 * float(coef_a.abs().max()))
     assert torch.equal(results[0][0], results[2][0]) and torch.equal(results[0][1], results[2][1]) and torch.equal(results[0][2], results[2][2])
+
+
+@pytest.mark.parametrize("case", [
+    # (N, H, C, Cout, stride, residual, relu): the BN-folded inference convolutions the streaming kernel takes
+    (8, 56, 64, 256, 1, True, True), (8, 56, 256, 64, 1, False, True), (8, 56, 64, 64, 1, False, True), (16, 28, 512, 128, 1, False, True),
+    (16, 28, 128, 512, 1, True, True), (32, 14, 256, 1024, 1, True, True), (8, 56, 256, 512, 2, False, False), (3, 9, 64, 256, 1, True, False),
+])
+def test_streaming_1x1_inference_epilogue(case):
+    """pfr_sconv.hip, inference epilogue (y = relu?(conv + bias [+ residual]), the BN-folded eval plan): adds to the bf16-rounded
+    convolution result, so it may differ from the tile kernel's fp32 epilogue by ONE bf16 rounding of the pre-activation — checked
+    against both the tile kernel and an fp32 torch reference with exactly that bound."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, C, Co, sd, has_res, relu = case
+    g = torch.Generator().manual_seed(H * C + Co + 7)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(Co, 1, 1, C, generator=g) / C ** 0.5).to(DEV).bfloat16()
+    bias = torch.randn(Co, generator=g).to(DEV)
+    OH = (H - 1) // sd + 1
+    res = torch.randn(N, OH, OH, Co, generator=g).to(DEV).bfloat16() if has_res else None
+    outs = []
+    try:
+        for mode in (0, 2):
+            lib.pfr_set_tuning(b"sconv", mode)
+            y, _ = o.conv2d_fwd(x, w, stride=sd, pad=0, bias=bias, residual=res, out_relu=relu)
+            torch.cuda.synchronize()
+            outs.append(y.clone())
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+    conv = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=sd).permute(0, 2, 3, 1)
+    pre = conv + bias + (res.float() if has_res else 0)
+    ref = torch.relu(pre) if relu else pre
+    # bounds: output rounding (2^-9 relative of the result) + one rounding of the convolution value (2^-9 of |conv|) + fp32 noise
+    bound = 2.0 ** -8 * ref.abs() + 2.0 ** -8 * conv.abs() + 1e-6
+    assert bool(((outs[1].float() - ref).abs() <= bound).all())
+    assert bool(((outs[0].float() - ref).abs() <= bound).all())
+    assert bool(((outs[1].float() - outs[0].float()).abs() <= 2 * bound).all())
+    assert (outs[1] != outs[0]).float().mean().item() < 0.35     # most elements agree exactly; the rest by one rounding step
