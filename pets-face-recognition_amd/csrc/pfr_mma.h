@@ -61,6 +61,11 @@ __device__ __forceinline__ void mma_kstep(const char* ldsP, const char* ldsQ, in
 // read-out: the store and the wait are ONE asm statement here, nothing can be scheduled between them.  (s_nop: soff may come
 // straight from the scalar ALU and nothing inside an asm statement is hazard-padded by the compiler.)
 __device__ __forceinline__ void buffer_store_b128_sync(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+#ifdef PFR_STORE_SPLIT_AB   // A/B builds only: the earlier (fragile) form, builtin store + separate wait
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)voff, (int)soff, 0);
+  asm volatile("s_waitcnt expcnt(0)" ::: "memory");
+  return;
+#endif
   asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_waitcnt expcnt(0)" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 

@@ -30,6 +30,8 @@ struct Sconv3Params {
   void* y;
   int N, H, W;          // C = Cout = 64
   float* stats_part;    // [nparts][2][64] (mean, M2) or nullptr
+  const float* bias;    // INFER: per-cout bias of the BN-folded convolution
+  int relu;             // INFER: ReLU after the bias
   int nblk, bpw;        // patches in total, patches per workgroup (contiguous in patch order)
   int tiles_x, tpi;     // W / 8, patches per image
   FastDiv div_tpi, div_tx;
@@ -42,8 +44,11 @@ static unsigned long long* g_s3_trace = nullptr;
 extern "C" void pfr_debug_sconv3_trace(void* p) { g_s3_trace = (unsigned long long*)p; }
 #endif
 
-template <bool STATS>
+// INFER: y = relu?(result + bias) — the BN-folded inference plan; added to the bf16-rounded result in the read-back pass
+// (one more bf16 rounding of the pre-activation than the tile kernel's fp32 epilogue, as in pfr_sconv.hip)
+template <bool STATS, bool INFER = false>
 __global__ __launch_bounds__(256, 1) void sconv3_kernel(Sconv3Params p) {
+  static_assert(!(STATS && INFER), "the inference variant publishes no statistics");
   constexpr int WB = 64 * 1152;          // weight bytes
   constexpr int GB = 8192;               // ring slot: 64 pixel rows of 128 B (60 used)
   constexpr int GI = 8;                  // DMA instructions per halo tile
@@ -53,6 +58,12 @@ __global__ __launch_bounds__(256, 1) void sconv3_kernel(Sconv3Params p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float bias8[8];     // INFER: this lane's 8 couts in the read-back layout, fetched before any DMA is in flight
+  if constexpr (INFER) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = p.bias[(lane & 7) * 8 + e];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   const int blk_lo = blockIdx.x * p.bpw;
   const int blk_hi = blk_lo + p.bpw < p.nblk ? blk_lo + p.bpw : p.nblk;
   if (blk_lo >= p.nblk) return;
@@ -197,7 +208,18 @@ __global__ __launch_bounds__(256, 1) void sconv3_kernel(Sconv3Params p) {
 #endif
     // store data registers are read late under a deep vector-memory queue and hipcc re-uses them at once: store + EXP_CNT wait
     // in one asm statement (buffer_store_b128_sync, pfr_mma.h)
-    buffer_store_b128_sync(v, yrsrc, (uint32_t)(lane << 4), e_ybase + (uint32_t)(ps * p.W * 128));
+    if constexpr (INFER) {
+      float f[8];
+      Chunk<bf16_t>::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        f[e] += bias8[e];
+        if (p.relu) f[e] = fmaxf(f[e], 0.f);
+      }
+      buffer_store_b128_sync(Chunk<bf16_t>::pack(f), yrsrc, (uint32_t)(lane << 4), e_ybase + (uint32_t)(ps * p.W * 128));
+    } else {
+      buffer_store_b128_sync(v, yrsrc, (uint32_t)(lane << 4), e_ybase + (uint32_t)(ps * p.W * 128));
+    }
   };
 
   // ---- one patch: 36 k16 steps into `cur`; in their shadow the DMA of the next tile (steps 0-7), the addresses of the one after
@@ -367,13 +389,16 @@ bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride,
 }
 
 int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
-  if (p.ldy != p.Cout || p.bias || p.accumulate || p.out_relu || p.pro_scale || p.act || p.bnb_part[0] || p.residual) return 1;
+  if (p.ldy != p.Cout || p.accumulate || p.pro_scale || p.act || p.bnb_part[0] || p.residual) return 1;
+  const bool infer = p.bias != nullptr;      // inference form: bias (+ ReLU), no statistics; training form: neither
+  if (infer ? p.stats_part != nullptr : p.out_relu != 0) return 1;
   int bpw;
   if (!sconv3_geom(p.N, p.H, p.W, p.C, p.Cout, p.R, p.S, p.ostride, p.pad, p.idil_log2, p.OH, p.OW, dtype, out_dtype, &bpw)) return 1;
   Sconv3Params sp;
   sp.x = p.x; sp.w = p.w; sp.y = p.y;
   sp.N = p.N; sp.H = p.H; sp.W = p.W;
   sp.stats_part = p.stats_part;
+  sp.bias = p.bias; sp.relu = p.out_relu;
   sp.tiles_x = p.W / 8;
   sp.tpi = (p.H / 4) * sp.tiles_x;
   sp.nblk = p.N * sp.tpi;
@@ -389,9 +414,11 @@ int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) 
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)sconv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)sconv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)sconv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (p.stats_part) hipLaunchKernelGGL(sconv3_kernel<true>, grid, block, lds, st, sp);
+  if (infer) hipLaunchKernelGGL((sconv3_kernel<false, true>), grid, block, lds, st, sp);
+  else if (p.stats_part) hipLaunchKernelGGL(sconv3_kernel<true>, grid, block, lds, st, sp);
   else hipLaunchKernelGGL(sconv3_kernel<false>, grid, block, lds, st, sp);
   PFR_CHECK_LAUNCH();
   return PFR_OK;

@@ -715,3 +715,32 @@ def test_streaming_1x1_inference_epilogue(case):
     assert bool(((outs[0].float() - ref).abs() <= bound).all())
     assert bool(((outs[1].float() - outs[0].float()).abs() <= 2 * bound).all())
     assert (outs[1] != outs[0]).float().mean().item() < 0.35     # most elements agree exactly; the rest by one rounding step
+
+
+@pytest.mark.parametrize("case", [(2, 56, 56, True), (3, 16, 16, True), (1, 4, 8, False), (5, 24, 40, True), (16, 56, 56, True)])
+def test_halo_staged_3x3_inference_epilogue(case):
+    """pfr_sconv3.hip, inference epilogue (y = relu?(conv + bias), BN-folded eval plan) vs the tile kernel and an fp32 torch
+    reference, with the one-extra-bf16-rounding bound of test_streaming_1x1_inference_epilogue."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, W, relu = case
+    g = torch.Generator().manual_seed(H * W + N + 3)
+    x = torch.randn(N, H, W, 64, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(64, 3, 3, 64, generator=g) / 24.0).to(DEV).bfloat16()
+    bias = torch.randn(64, generator=g).to(DEV)
+    outs = []
+    try:
+        for mode in (0, 2):
+            lib.pfr_set_tuning(b"sconv", mode)
+            y, _ = o.conv2d_fwd(x, w, stride=1, pad=1, bias=bias, out_relu=relu)
+            torch.cuda.synchronize()
+            outs.append(y.clone())
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+    conv = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    pre = conv + bias
+    ref = torch.relu(pre) if relu else pre
+    bound = 2.0 ** -8 * ref.abs() + 2.0 ** -8 * conv.abs() + 1e-6
+    assert bool(((outs[1].float() - ref).abs() <= bound).all())
+    assert bool(((outs[0].float() - ref).abs() <= bound).all())
+    assert (outs[1] != outs[0]).float().mean().item() < 0.35
