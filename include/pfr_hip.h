@@ -149,6 +149,12 @@ int pfr_bn_finalize(const float* part, int nparts, long rows_per_part, int C, fl
  * void* wout; float* bout; long cout, k; float eps; int src_is_f32; } (80 bytes, natural alignment):
  * wout[co][k] = src[co][k] * gamma/sqrt(var+eps) in `dtype`, bout[co] = beta - mean*gamma/sqrt(var+eps) */
 int pfr_fold_bn(const void* descs, int ndesc, int dtype, pfr_stream_t stream);
+/* pfr_fold_bn that runs only when a parameter changed since the folded weights were made: a 64-bit position-weighted checksum of the
+ * fp32 master buffer [n_master] and of every record's running statistics is taken on the device and compared with the previous
+ * one; the master -> compute-dtype cast into `shadow` (may be NULL) and the fold exit at once when they agree.  state: 4 x 64-bit
+ * device words owned by the caller, {0, ~0, 0, 0} before the first call; state[2] counts folds done, state[3] calls. */
+int pfr_fold_bn_cached(const void* descs, int ndesc, int dtype, const float* master, size_t n_master, void* shadow,
+                       unsigned long long* state, pfr_stream_t stream);
 int pfr_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, pfr_stream_t stream);
 /* y = relu?( a1*x1 + b1 (+ a2*x2 + b2 | + x2) ): BN apply, ReLU and the residual add of a bottleneck in one pass */

@@ -498,6 +498,96 @@ extern "C" int pfr_fold_bn(const void* descs, int ndesc, int dtype, hipStream_t 
   return PFR_OK;
 }
 
+// ---- fold only when something changed.  The fold (and the master -> shadow cast) of an inference forward costs ~150 us — 15 % of a
+// single-image forward — although parameters rarely change between two inference calls.  Whether they did is decided ON THE DEVICE
+// (no host bookkeeping can see every writer: optimizer kernels, `.data` edits, checkpoint loads, running-statistics updates): a
+// position-weighted 64-bit checksum of the fp32 master buffer and of every layer's running statistics (integer adds: order-free,
+// exact) is compared with the one the current folded weights were made from; cast and fold exit at once when they agree.
+// state: 4 x u64 device words {checksum being accumulated, checksum of the folded weights, folds done, calls}.
+#define PFR_HASH_BLOCKS 1024
+__global__ __launch_bounds__(256) void param_hash_kernel(const uint32_t* __restrict__ master, size_t n_master,
+                                                         const FoldDesc* __restrict__ descs, unsigned long long* __restrict__ state) {
+  unsigned long long h = 0;
+  if (blockIdx.x < PFR_HASH_BLOCKS) {
+    const size_t n4 = n_master / 4, stride = (size_t)PFR_HASH_BLOCKS * 256;
+    auto mix = [&](const u32x4 v, size_t i) {
+      const unsigned long long k = 8ull * i + 1ull;   // odd multipliers 2*(4i+e)+1
+      h += v[0] * k + v[1] * (k + 2) + v[2] * (k + 4) + v[3] * (k + 6);
+    };
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {   // four 16-byte loads in flight per lane
+      const u32x4* q = reinterpret_cast<const u32x4*>(master) + i;
+      const u32x4 v0 = __builtin_nontemporal_load(q), v1 = __builtin_nontemporal_load(q + stride);
+      const u32x4 v2 = __builtin_nontemporal_load(q + 2 * stride), v3 = __builtin_nontemporal_load(q + 3 * stride);
+      mix(v0, i); mix(v1, i + stride); mix(v2, i + 2 * stride); mix(v3, i + 3 * stride);
+    }
+    for (; i < n4; i += stride) mix(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(master) + i), i);
+    if (blockIdx.x == 0)
+      for (size_t i = n4 * 4 + threadIdx.x; i < n_master; i += 256) h += master[i] * (2ull * i + 1ull);
+  } else {
+    const FoldDesc d = descs[blockIdx.x - PFR_HASH_BLOCKS];
+    const unsigned long long base = ((unsigned long long)(blockIdx.x - PFR_HASH_BLOCKS + 1) << 40) | 1ull;
+    for (long c = threadIdx.x; c < d.cout; c += 256) {
+      h += (unsigned long long)__float_as_uint(d.rm[c]) * (base + 4ull * c);
+      h += (unsigned long long)__float_as_uint(d.rv[c]) * (base + 4ull * c + 2);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&state[0], h);
+}
+__global__ void param_hash_commit_kernel(unsigned long long* state) {
+  if (state[0] != state[1]) { state[1] = state[0]; state[2] += 1; }
+  state[0] = 0;
+  state[3] += 1;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fold_bn_if_kernel(const FoldDesc* __restrict__ descs, const unsigned long long* __restrict__ state) {
+  if (state[0] == state[1]) return;
+  const FoldDesc d = descs[blockIdx.y];
+  // one row (cout) per wave pass: the per-row scale is computed once, the row is walked in 16-byte pieces where alignment allows
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long co = (long)blockIdx.x * 4 + wave; co < d.cout; co += (long)gridDim.x * 4) {
+    const float sc = (d.gamma ? d.gamma[co] : 1.f) * rsqrtf(d.rv[co] + d.eps);
+    if (lane == 0) d.bout[co] = (d.beta ? d.beta[co] : 0.f) - d.rm[co] * sc;
+    T* out = reinterpret_cast<T*>(d.wout) + co * d.k;
+    if (d.src_f32) {
+      const float* src = reinterpret_cast<const float*>(d.src) + co * d.k;
+      for (long i = lane; i < d.k; i += 64) out[i] = from_f32<T>(src[i] * sc);
+    } else {
+      const T* src = reinterpret_cast<const T*>(d.src) + co * d.k;
+      for (long i = lane; i < d.k; i += 64) out[i] = from_f32<T>(to_f32(src[i]) * sc);
+    }
+  }
+}
+template <typename TI, typename TOo>
+__global__ void cast_if_kernel(const TI* __restrict__ x, TOo* __restrict__ y, size_t n, const unsigned long long* __restrict__ state) {
+  if (state[0] == state[1]) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = from_f32<TOo>(to_f32(x[i]));
+}
+extern "C" int pfr_fold_bn_cached(const void* descs, int ndesc, int dtype, const float* master, size_t n_master, void* shadow,
+                                  unsigned long long* state, hipStream_t st) {
+  PFR_CHECK_ARG(descs && ndesc > 0 && master && state, "pfr_fold_bn_cached: bad args");
+  PFR_CHECK_ARG(dtype == PFR_F32 || dtype == PFR_BF16, "pfr_fold_bn_cached: bad dtype %d", dtype);
+  hipLaunchKernelGGL(param_hash_kernel, dim3(PFR_HASH_BLOCKS + (unsigned)ndesc), dim3(256), 0, st, (const uint32_t*)master, n_master,
+                     (const FoldDesc*)descs, state);
+  PFR_CHECK_LAUNCH();
+  if (shadow && dtype == PFR_BF16) {
+    unsigned blocks = (unsigned)((n_master + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((cast_if_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, master, (bf16_t*)shadow, n_master, state);
+    PFR_CHECK_LAUNCH();
+  }
+  const dim3 grid(64, (unsigned)ndesc);
+  if (dtype == PFR_BF16) hipLaunchKernelGGL(fold_bn_if_kernel<bf16_t>, grid, dim3(256), 0, st, (const FoldDesc*)descs, state);
+  else hipLaunchKernelGGL(fold_bn_if_kernel<float>, grid, dim3(256), 0, st, (const FoldDesc*)descs, state);
+  PFR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(param_hash_commit_kernel, dim3(1), dim3(1), 0, st, state);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 // eval-mode BN: scale/shift from running statistics
 __global__ void bn_eval_coeff_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
                                      float eps, float* scale, float* shift) {

@@ -150,6 +150,8 @@ class FEEngine:
         self.side_events = []
         self.fold_eval = os.environ.get("PFR_FOLD_BN", "1") != "0"   # inference: BN folded into the convs
         self.fold_w = None
+        self.fold_cache = os.environ.get("PFR_FOLD_CACHE", "1") != "0"   # inference: re-fold only when the parameters changed
+        self.fold_state = None
         self.graph_eval = os.environ.get("PFR_GRAPH_EVAL", "0") == "1"   # opt-in: inference plans replayed as hipGraphs
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
@@ -364,9 +366,9 @@ class FEEngine:
         return self.side_stream_enabled and _TRACER[0] is None and (self.grad_ready_hook is None or _side_with_ddp())
 
     # ------------------------------------------------------------------------------------------ weights
-    def refresh_weights(self, stream, for_backward=True):
+    def refresh_weights(self, stream, for_backward=True, cast=True):
         """master fp32 → compute-dtype shadow, channel-padded stem weights, data-gradient weight layouts."""
-        if self.dtype != torch.float32:
+        if cast and self.dtype != torch.float32:
             lib.pfr_cast(self.master.data_ptr(), 0, self.shadow.data_ptr(), self.did, self.n_flat, stream)
         st = self.stem[0]
         lib.pfr_nchw_to_nhwc(self.master.data_ptr() + 4 * st.off, st.w_pad.data_ptr(), self.did, st.Cout * st.R * st.S,
@@ -975,9 +977,18 @@ class FEEngine:
         if plan.meta.get("folded") and self.graph_eval and _TRACER[0] is None:
             return self._forward_graphed(plan, x)
         stream = torch.cuda.current_stream().cuda_stream
-        self.refresh_weights(stream, for_backward=with_backward)
-        if plan.meta.get("folded"):
-            lib.pfr_fold_bn(self.fold_desc.data_ptr(), self.fold_n, self.did, stream)
+        if plan.meta.get("folded") and self.fold_cache:
+            # inference: cast + fold only when a parameter or running statistic changed since the folded weights were made
+            # (decided on the device by a checksum, pfr_fold_bn_cached); the stem's two small layout copies are always redone
+            self.refresh_weights(stream, for_backward=False, cast=False)
+            if self.fold_state is None:
+                self.fold_state = torch.tensor([0, -1, 0, 0], dtype=torch.int64, device=self.device)
+            lib.pfr_fold_bn_cached(self.fold_desc.data_ptr(), self.fold_n, self.did, self.master.data_ptr(), self.n_flat,
+                                   self.shadow.data_ptr() if self.dtype != torch.float32 else 0, self.fold_state.data_ptr(), stream)
+        else:
+            self.refresh_weights(stream, for_backward=with_backward)
+            if plan.meta.get("folded"):
+                lib.pfr_fold_bn(self.fold_desc.data_ptr(), self.fold_n, self.did, stream)
         self._input_layout(plan, x, stream)
         if not self._run_list(plan, "fwd", stream):
             for fn, args in plan.meta["fwd"]:

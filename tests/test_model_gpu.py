@@ -377,3 +377,61 @@ def test_fused_bn_backward_sums_equal_separate_reduce(monkeypatch):
             assert names.count("pfr_conv2d_dgrad_bn") >= 40 and names.count("pfr_bn_bwd_reduce") <= 10, names.count("pfr_conv2d_dgrad_bn")
     e = ((grads[0] - grads[1]).norm() / grads[0].norm()).item()
     assert e < 1e-5, e
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inference_fold_cache_refolds_exactly_when_something_changed(dtype):
+    """pfr_fold_bn_cached: the eval plan's cast + BN fold run only when the device checksum of the master parameters / running
+    statistics differs from the one the folded weights were made from.  Every way of changing them must trigger a re-fold (torch
+    in-place ops, `.data` edits, a fused-optimizer step through raw pointers, a training forward's running-statistics update,
+    load_state_dict) and the result must equal the always-fold path bit for bit."""
+    from oracle import resnet_ref
+    from pets_face_recognition_amd.optim import FusedSGD
+    sd = resnet_ref.init_state_dict("resnet18", 512, seed=7)
+    m = build("resnet18", dtype, sd).eval()
+    x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(4)).to(DEV)
+    eng = m.hip_engine()
+    assert eng.fold_cache
+
+    def folds():
+        torch.cuda.synchronize()
+        return int(eng.fold_state[2]), int(eng.fold_state[3])
+
+    def uncached():
+        eng.fold_cache = False
+        try:
+            with torch.no_grad():
+                return m(x).clone()
+        finally:
+            eng.fold_cache = True
+
+    with torch.no_grad():
+        a = m(x).clone()
+        b = m(x).clone()
+    assert folds() == (1, 2) and torch.equal(a, b) and torch.equal(a, uncached())
+    with torch.no_grad():
+        m.layer2[0].conv1.weight.mul_(1.5)                      # torch in-place op on a parameter view
+        c = m(x).clone()
+    assert folds() == (2, 3) and not torch.equal(c, a) and torch.equal(c, uncached())
+    m.layer1[0].bn1.weight.data.add_(0.25)                      # `.data` edit: invisible to torch's version counters
+    with torch.no_grad():
+        d = m(x).clone()
+    assert folds() == (3, 4) and not torch.equal(d, c) and torch.equal(d, uncached())
+    m.layer3[0].bn2.running_var.mul_(2.0)                       # a buffer
+    with torch.no_grad():
+        e = m(x).clone()
+    assert folds() == (4, 5) and not torch.equal(e, d) and torch.equal(e, uncached())
+    # a training step: running statistics (bn_finalize) and parameters (fused optimizer) are written through raw pointers
+    m.train()
+    opt = FusedSGD([{"params": [p for p in m.parameters() if p.requires_grad]}], 0.05, momentum=0.9)
+    m(x).square().mean().backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        f = m(x).clone()
+        g = m(x).clone()
+    assert folds() == (5, 7) and not torch.equal(f, e) and torch.equal(f, g) and torch.equal(f, uncached())
+    m.load_state_dict({k: v.to(DEV) for k, v in build("resnet18", dtype, resnet_ref.init_state_dict("resnet18", 512, seed=8)).state_dict().items()})
+    with torch.no_grad():
+        h = m(x).clone()
+    assert folds() == (6, 8) and not torch.equal(h, f) and torch.equal(h, uncached())
