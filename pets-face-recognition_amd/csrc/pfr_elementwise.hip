@@ -504,15 +504,18 @@ extern "C" int pfr_fold_bn(const void* descs, int ndesc, int dtype, hipStream_t 
 // position-weighted 64-bit checksum of the fp32 master buffer and of every layer's running statistics (integer adds: order-free,
 // exact) is compared with the one the current folded weights were made from; cast and fold exit at once when they agree.
 // state: 4 x u64 device words {checksum being accumulated, checksum of the folded weights, folds done, calls}.
-#define PFR_HASH_BLOCKS 1024
+#define PFR_HASH_BLOCKS 512
 __global__ __launch_bounds__(256) void param_hash_kernel(const uint32_t* __restrict__ master, size_t n_master,
                                                          const FoldDesc* __restrict__ descs, unsigned long long* __restrict__ state) {
   unsigned long long h = 0;
   if (blockIdx.x < PFR_HASH_BLOCKS) {
     const size_t n4 = n_master / 4, stride = (size_t)PFR_HASH_BLOCKS * 256;
     auto mix = [&](const u32x4 v, size_t i) {
-      const unsigned long long k = 8ull * i + 1ull;   // odd multipliers 2*(4i+e)+1
-      h += v[0] * k + v[1] * (k + 2) + v[2] * (k + 4) + v[3] * (k + 6);
+      const uint32_t k = (uint32_t)(8 * i + 1);   // odd 32-bit multipliers 2*(4i+e)+1: one v_mad_u64_u32 per word
+      h += (unsigned long long)v[0] * k;
+      h += (unsigned long long)v[1] * (k + 2u);
+      h += (unsigned long long)v[2] * (k + 4u);
+      h += (unsigned long long)v[3] * (k + 6u);
     };
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (; i + 3 * stride < n4; i += 4 * stride) {   // four 16-byte loads in flight per lane
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256) void param_hash_kernel(const uint32_t* __restr
     }
     for (; i < n4; i += stride) mix(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(master) + i), i);
     if (blockIdx.x == 0)
-      for (size_t i = n4 * 4 + threadIdx.x; i < n_master; i += 256) h += master[i] * (2ull * i + 1ull);
+      for (size_t i = n4 * 4 + threadIdx.x; i < n_master; i += 256) h += (unsigned long long)master[i] * (uint32_t)(2 * i + 1);
   } else {
     const FoldDesc d = descs[blockIdx.x - PFR_HASH_BLOCKS];
     const unsigned long long base = ((unsigned long long)(blockIdx.x - PFR_HASH_BLOCKS + 1) << 40) | 1ull;
@@ -534,7 +537,11 @@ __global__ __launch_bounds__(256) void param_hash_kernel(const uint32_t* __restr
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&state[0], h);
+  // ONE atomic per workgroup (thousands of same-address atomics serialise: 4 per workgroup cost 40 us of the kernel's 62)
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&state[0], part[0] + part[1] + part[2] + part[3]);
 }
 __global__ void param_hash_commit_kernel(unsigned long long* state) {
   if (state[0] != state[1]) { state[1] = state[0]; state[2] += 1; }

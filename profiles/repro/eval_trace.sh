@@ -8,7 +8,7 @@ import bench
 a = types.SimpleNamespace(arch="resnet50", dtype="bf16", classes=10000, batch=256)
 ml, _ = bench.build(a, torch.device("cuda:0"))
 ml.eval()
-x = torch.rand(256, 3, 224, 224, device="cuda:0")
+x = torch.rand(int(os.environ.get("EVAL_BS", "256")), 3, 224, 224, device="cuda:0")
 with torch.no_grad():
     for _ in range(6):
         e = ml(x)
