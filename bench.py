@@ -35,8 +35,8 @@ PEAK_HBM_GBS = 8000.0
 
 # every C-ABI entry point whose launches execute the FLOPs counted by conv_flops_per_img (conv / Linear forward, data and
 # weight gradients incl. the fused-epilogue variants, windowed attention)
-CONV_FAMILY = ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_conv2d_dgrad_join", "pfr_gemm_act", "pfr_window_attn_fwd",
-               "pfr_window_attn_bwd")
+CONV_FAMILY = ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_conv2d_dgrad_join", "pfr_conv2d_dgrad_bn", "pfr_gemm_act",
+               "pfr_window_attn_fwd", "pfr_window_attn_bwd")
 
 
 def conv_flops_per_img(arch):
@@ -470,6 +470,12 @@ def main():
                 key = "dgrad_join N%d H%d W%d C%d Co%d R%d dil%d OH%d" % (a[4], a[5], a[6], a[7], a[8], a[9], a[12], a[13])
                 fl = 2.0 * a[4] * a[13] * a[14] * a[8] * a[9] * a[10] * a[7] / (4 ** a[12])
                 by = esz * (a[4] * a[5] * a[6] * a[7] + 2 * a[4] * a[13] * a[14] * a[8] + a[8] * a[9] * a[10] * a[7])
+            elif name == "pfr_conv2d_dgrad_bn":
+                # (dy, wt, dx, dtype, N, H, W, C, Cout, R, S, pad, idil, OH, OW, res, mask, acc, bn_x, ...): the data gradient (+ join)
+                # that also reads the BN input for the BatchNorm-backward sums (what pfr_bn_bwd_reduce read in a separate pass)
+                key = "dgrad_bn%s N%d H%d W%d C%d Co%d R%d dil%d OH%d" % ("_join" if a[15] else "", a[4], a[5], a[6], a[7], a[8], a[9], a[12], a[13])
+                fl = 2.0 * a[4] * a[13] * a[14] * a[8] * a[9] * a[10] * a[7] / (4 ** a[12])
+                by = esz * (a[4] * a[5] * a[6] * a[7] + (3 if a[15] else 2) * a[4] * a[13] * a[14] * a[8] + a[8] * a[9] * a[10] * a[7])
             else:
                 key, fl, by = name, 0.0, 0.0
             d = det.setdefault(key, [0, 0.0, fl, by])

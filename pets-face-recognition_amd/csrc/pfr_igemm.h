@@ -68,6 +68,9 @@ bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride,
                  int out_dtype, int* bpw);
 int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
 void wgrad_set_big(int v);   // pfr_wgrad.hip: 256x256 8-wave weight-gradient tiles (0 off, 1 heuristic, 2 forced)
+int sconv_bnb_mode();
+void sconv_set_bnb_mode(int v);
+int sconv_bnb_parts(int M, int N, int K, int dtype);
 void sconv3_set_enabled(int v);
 // parity-class mode of the persistent kernel: data gradient of a stride-2 conv (input dilation 1 << 1) over even output sizes
 static inline bool igemm_pclass_ok(const IgemmParams& p) {

@@ -844,6 +844,10 @@ extern "C" int pfr_conv2d_dgrad_join(const void* dy, const void* wt, void* dx, i
 extern "C" int pfr_conv2d_dgrad_bn_parts(int dtype, int N, int H, int W, int C, int Cout, int R, int S, int idil_log2, int OH,
                                          int OW) {
   const int kp = dtype == PFR_BF16 ? 8 : 4;
+  if (sconv_bnb_mode() == 2) {   // streaming kernels only: 1x1 / stride 1 data gradients they take (one BN; see pfr_sconv.hip)
+    if (R != 1 || S != 1 || idil_log2 != 0 || OH != H || OW != W) return 0;
+    return sconv_bnb_parts(N * OH * OW, Cout, C, dtype);
+  }
   if (C % (4 * kp) != 0 || Cout % kp != 0) return 0;
   if (idil_log2 == 1 && (OH % 2) == 0 && (OW % 2) == 0) return 0;
   int bq;
@@ -870,6 +874,8 @@ extern "C" int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int
   PFR_CHECK_ARG((res == nullptr) == (res_mask == nullptr), "pfr_conv2d_dgrad_bn: res and res_mask go together");
   PFR_CHECK_ARG(pfr_conv2d_dgrad_bn_parts(dtype, N, H, W, C, Cout, R, S, idil_log2, OH, OW) > 0,
                 "pfr_conv2d_dgrad_bn: geometry not supported by the fused form (see pfr_conv2d_dgrad_bn_parts)");
+  PFR_CHECK_ARG(sconv_bnb_mode() != 2 || (!bn2_part && !accumulate && (!res || bn_mask)),
+                "pfr_conv2d_dgrad_bn: the streaming form (bnb mode 2) takes one BN, no accumulation, and a bit mask with the join");
   BnbArgs b;
   b.x[0] = bn_x; b.coef[0] = bn_coef; b.part[0] = bn_part;
   b.x[1] = bn2_x; b.coef[1] = bn2_coef; b.part[1] = bn2_part;

@@ -35,8 +35,15 @@ struct SconvParams {
   float* stats_part;      // [nranges][2][N] (mean, M2) or nullptr
   const void* res;        // join: residual-branch gradient [M][N] bf16, or nullptr
   const unsigned char* res_mask;   // join: its ReLU bit mask [M][N/8]
-  const float* bias;      // inference epilogue (EP >= 2): per-cout bias of the BN-folded convolution
+  const float* bias;      // inference epilogue (EP 2 / 3): per-cout bias of the BN-folded convolution
   int relu;               // inference epilogue: ReLU after bias (+ residual)
+  // EP 4 / 5: BatchNorm-backward sums of the BN whose output gradient y is (pfr_conv2d_dgrad_bn): x of that BN [M][N], its
+  // coefficient rows [4][N] (mean, invstd, scale, shift), its ReLU bit mask [M][N/8] or nullptr (then scale*x + shift > 0),
+  // partial sums [nranges][2][N] = (sum g*mask, sum g*mask*xhat), g = the value stored to y
+  const void* bnx;
+  const float* bn_coef;
+  const unsigned char* bn_mask;
+  float* bn_part;
   int npanels, nranges, R;    // R: rows per range (multiple of the 32-row block height)
   int npw;                    // couts of a workgroup's weight panel (64, 128 or 256)
   int interleave;             // 1: block-interleaved row assignment (needs M % 32 == 0 and M / 32 divisible by nranges)
@@ -49,17 +56,23 @@ struct SconvParams {
 // (pfr_conv2d_dgrad_join); 2: y = relu?(result + bias); 3: y = relu?(result + bias + res) — the BN-folded inference convolutions
 // (Controller.validation_step / generate_tsv embedder).  EP 2 / 3 add to the bf16-rounded result in the read-back pass (the window
 // holds bf16), i.e. one more bf16 rounding of the pre-activation than the tile kernel's fp32 epilogue.
+// EP 4: plain data gradient + the BatchNorm-backward sums of the BN it feeds (mask recomputed or bit mask); EP 5: the join + those
+// sums (bit mask) — pfr_bn_bwd_reduce's pass over (gradient, BN input, mask) becomes one extra row read in this epilogue.
 template <int TP, int NS, bool STATS, int EP = 0>
 __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
-  constexpr bool JOIN = EP == 1;
-  constexpr bool HASRES = EP == 1 || EP == 3;
+  constexpr bool JOIN = EP == 1 || EP == 5;
+  constexpr bool HASRES = EP == 1 || EP == 3 || EP == 5;
+  constexpr bool BNB = EP == 4 || EP == 5;
+  constexpr bool INFER = EP == 2 || EP == 3;
   static_assert(!(STATS && EP != 0), "only the plain variant publishes statistics");
   constexpr int NPV = TP * 32;           // couts per wave
   constexpr int GB = 4096;               // granule bytes: [32 rows][64 k] bf16
   constexpr int GI = 4;                  // DMA instructions per granule
   constexpr int NCG = NPV / 64;          // 64-cout column groups of the epilogue
   constexpr int SB = NPV / 16;           // store instructions per block (32 rows x NPV couts x 2 B / 1 KiB)
-  constexpr int RL = JOIN ? 2 * SB : (HASRES ? SB : 0);  // residual (+ mask) load instructions per block
+  // residual (+ mask) and BN-input (+ mask) load instructions per block (BNB always issues its mask-byte load: with a recomputed
+  // mask it reads one dummy byte, the count per block stays a compile-time constant)
+  constexpr int RL = (JOIN ? 2 * SB : (HASRES ? SB : 0)) + (BNB ? 2 * SB : 0);
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -96,12 +109,38 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 
   // inference epilogue: this lane's 8 couts of every column group (read-back layout), fetched before any DMA is in flight
   float bias8[NCG][8];
-  if constexpr (EP >= 2) {
+  if constexpr (INFER) {
     const int e_ch0 = lane & 7;
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
       for (int e = 0; e < 8; ++e) bias8[g][e] = p.bias[n0 + g * 64 + e_ch0 * 8 + e];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // BN-backward coefficients of this lane's 8 couts per column group (read-back layout): xhat = ca*x + cb, mask = sc*x + sh > 0
+  float bca[NCG][8], bcb[NCG][8], bsc[NCG][8], bsh[NCG][8];
+  f32x2 b1[NCG][4], b2[NCG][4];
+  __amdgpu_buffer_rsrc_t bxrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BNB ? p.bnx : p.y), 0, p.M * p.N * 2, 0x00020000);
+  __amdgpu_buffer_rsrc_t bmrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(BNB && p.bn_mask ? p.bn_mask : (const unsigned char*)p.y), 0, BNB && p.bn_mask ? p.M * (p.N >> 3) : 16, 0x00020000);
+  const bool bn_bits = BNB && p.bn_mask != nullptr;
+  if constexpr (BNB) {
+    const int e_ch0 = lane & 7;
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = n0 + g * 64 + e_ch0 * 8 + e;
+        const float mu = p.bn_coef[c], is = p.bn_coef[p.N + c];
+        bca[g][e] = is;
+        bcb[g][e] = -mu * is;
+        bsc[g][e] = bn_bits ? 0.f : p.bn_coef[2 * p.N + c];
+        bsh[g][e] = bn_bits ? 1.f : p.bn_coef[3 * p.N + c];
+      }
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { b1[g][e] = (f32x2){0.f, 0.f}; b2[g][e] = (f32x2){0.f, 0.f}; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // ---- weight panel -> LDS (once): linear LDS image, XOR swizzle on the source side
@@ -235,6 +274,25 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
                          : "memory");
         }
     }
+    u32x4 bxr[NCG][4];
+    uint32_t bmk[NCG][4];
+    if constexpr (BNB) {
+      const uint32_t rbase = (uint32_t)((m0 * p.N + n0) * 2), kbase = (uint32_t)(m0 * (p.N >> 3) + (n0 >> 3));
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+                       : "=v"(bxr[g][ps])
+                       : "v"(y_lane + (uint32_t)(g * 128)), "s"(bxrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
+                       : "memory");
+          // (recomputed mask: the descriptor covers 16 bytes of y, every lane reads byte 0 or gets the out-of-range zero)
+          asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen"
+                       : "=v"(bmk[g][ps])
+                       : "v"(bn_bits ? k_lane + (uint32_t)(g * 8) : 0u), "s"(bmrsrc), "s"(bn_bits ? kbase + (uint32_t)(ps * p.N) : 0u)
+                       : "memory");
+        }
+    }
     // ---- granules of the block: the first one starts the accumulators from a constant-zero C operand
 #pragma unroll 1
     for (int kc = 0; kc < KG; ++kc) {
@@ -272,8 +330,8 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
     hist |= 1u;
     const uint32_t wbase = ring0 + ((slot + NS - 1) % NS) * GB;
     const uint32_t ybase = (uint32_t)((m0 * p.N + n0) * 2);
-    if constexpr (HASRES) {
-      // the residual loads are older than the KG granules issued during this block
+    if constexpr (HASRES || BNB) {
+      // the residual / BN-input loads are older than the KG granules issued during this block
       if (KG == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GI) : "memory");
       else if (KG == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GI) : "memory");
       else if (KG == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * GI) : "memory");
@@ -321,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
             const uint32_t bits = rmk[g][ps];
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += ((bits >> e) & 1u) ? rr8[e] : 0.f;
-          } else {
+          } else if constexpr (INFER) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               f[e] += bias8[g][e];
@@ -330,6 +388,26 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
             }
           }
           const u32x4 o = Chunk<bf16_t>::pack(f);
+          if constexpr (BNB) {
+            // sums over the value AS STORED (what pfr_bn_bwd_reduce would read back) through the BN's own ReLU mask
+            float xv[8];
+            Chunk<bf16_t>::unpack(bxr[g][ps], xv);
+            const uint32_t bits = bmk[g][ps];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 gs = {__uint_as_float(o[e] << 16), __uint_as_float(o[e] & 0xffff0000u)};
+              f32x2 gm;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int q = 2 * e + h;
+                const bool keep = bn_bits ? ((bits >> q) & 1u) != 0 : fmaf(xv[q], bsc[g][q], bsh[g][q]) > 0.f;
+                gm[h] = keep ? gs[h] : 0.f;
+              }
+              const f32x2 xh = {fmaf(xv[2 * e], bca[g][2 * e], bcb[g][2 * e]), fmaf(xv[2 * e + 1], bca[g][2 * e + 1], bcb[g][2 * e + 1])};
+              b1[g][e] += gm;
+              b2[g][e] = __builtin_elementwise_fma(gm, xh, b2[g][e]);
+            }
+          }
           buffer_store_b128_sync(o, yrsrc, y_lane + (uint32_t)(g * 128), ybase + (uint32_t)(ps * 8 * p.N * 2));
           continue;
         }
@@ -341,6 +419,41 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   }
   // drain: the dummy granules issued past the end must have landed before the LDS is reused or released
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (BNB) {
+    __syncthreads();   // every wave is past its last panel read and ring use: the LDS is reused below
+    // rows past M: the store was dropped, but their (zero + residual-out-of-range-zero) value entered the sums as g = 0: nothing to undo
+    float* red = reinterpret_cast<float*>(smem);   // [8 waves][2][NPV]
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float a = b1[g][e][h], q = b2[g][e][h];
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {   // lanes with equal e_ch hold partials of the same couts
+            a += __shfl_xor(a, o, 64);
+            q += __shfl_xor(q, o, 64);
+          }
+          if (lane < 8) {
+            const int c = g * 64 + lane * 8 + e * 2 + h;
+            red[(wave * 2 + 0) * NPV + c] = a;
+            red[(wave * 2 + 1) * NPV + c] = q;
+          }
+        }
+    __syncthreads();
+    for (int c = tid; c < NPW; c += 512) {
+      const int sl = c / NPV, cc = c - sl * NPV;
+      float a = 0.f, q = 0.f;
+      for (int wr = 0; wr < nrw; ++wr) {   // fixed order: deterministic
+        const int w = wr * nsub + sl;
+        a += red[(w * 2 + 0) * NPV + cc];
+        q += red[(w * 2 + 1) * NPV + cc];
+      }
+      p.bn_part[((size_t)r * 2 + 0) * p.N + pn * NPW + c] = a;
+      p.bn_part[((size_t)r * 2 + 1) * p.N + pn * NPW + c] = q;
+    }
+  }
   if (STATS) {
     __syncthreads();   // every wave is past its last panel read and ring use: the LDS is reused below
     // rows this wave processed; those past M contributed y = 0, i.e. d = -ksh: taken out again below
@@ -475,7 +588,11 @@ static int sconv_launch_ns(SconvParams& sp, const SconvPlan& pl, hipStream_t st)
 // takes the launch when it is a plain 1x1 convolution of an eligible geometry; returns 1 when it is not
 int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (p.R != 1 || p.S != 1 || p.pad != 0 || p.idil_log2 != 0 || p.ldy != p.Cout) return 1;
-  if (p.accumulate || p.pro_scale || p.act || p.bnb_part[0]) return 1;
+  if (p.accumulate || p.pro_scale || p.act) return 1;
+  // BatchNorm-backward sums in the epilogue (pfr_conv2d_dgrad_bn): one BN, no statistics / bias; with the join its bit mask is required
+  const bool bnb = p.bnb_part[0] != nullptr;
+  if (bnb && (sconv_bnb_mode() != 2 || p.bnb_part[1] || p.bias || p.stats_part || p.out_relu || (p.residual && !(p.res_mask && p.bnb_mask))))
+    return 1;
   // inference form: bias (+ plain residual add) (+ ReLU), no statistics; training forms: no bias / ReLU, residual only as the join
   const bool infer = p.bias != nullptr;
   if (infer && (p.stats_part || p.res_mask)) return 1;
@@ -493,11 +610,16 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.stats_part = p.stats_part;
   sp.res = p.residual; sp.res_mask = p.res_mask;
   sp.bias = p.bias; sp.relu = p.out_relu;
+  sp.bnx = p.bnb_x[0]; sp.bn_coef = p.bnb_coef[0]; sp.bn_mask = p.bnb_mask; sp.bn_part = p.bnb_part[0];
   sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
   static const bool il_on = !(getenv("PFR_SCONV_INTERLEAVE") && getenv("PFR_SCONV_INTERLEAVE")[0] == '0');
   sp.interleave = (il_on && p.M % 32 == 0 && (p.M / 32) % pl.nranges == 0 && (long)pl.R * pl.nranges == p.M) ? 1 : 0;
   sp.xbytes = (int)((long)p.N * p.H * p.W * p.K * 2);
   sp.div_ohow = p.div_ohow; sp.div_ow = p.div_ow;
+  if (bnb) {   // 64-cout column slices keep the residual / BN-input rows and both sums inside the register budget
+    pl.tp = 2;
+    return p.residual ? sconv_launch_ns<2, false, 5>(sp, pl, st) : sconv_launch_ns<2, false, 4>(sp, pl, st);
+  }
   if (infer) {
     if (p.residual) return pl.tp == 2 ? sconv_launch_ns<2, false, 3>(sp, pl, st) : sconv_launch_ns<4, false, 3>(sp, pl, st);
     return pl.tp == 2 ? sconv_launch_ns<2, false, 2>(sp, pl, st) : sconv_launch_ns<4, false, 2>(sp, pl, st);
@@ -505,6 +627,21 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (join) return pl.tp == 2 ? sconv_launch_ns<2, false, 1>(sp, pl, st) : sconv_launch_ns<4, false, 1>(sp, pl, st);
   if (pl.tp == 2) return p.stats_part ? sconv_launch_ns<2, true>(sp, pl, st) : sconv_launch_ns<2, false>(sp, pl, st);
   return p.stats_part ? sconv_launch_ns<4, true>(sp, pl, st) : sconv_launch_ns<4, false>(sp, pl, st);
+}
+
+// pfr_conv2d_dgrad_bn through the streaming kernel: PFR_FUSE_BNB / pfr_set_tuning("bnb"): 1 = tile kernels (round-2 form),
+// 2 = streaming kernels only (geometries they do not take keep the separate pfr_bn_bwd_reduce pass)
+static int g_bnb_mode = -1;
+int sconv_bnb_mode() {
+  if (g_bnb_mode < 0) { const char* e = getenv("PFR_FUSE_BNB"); g_bnb_mode = e ? atoi(e) : 0; }
+  return g_bnb_mode;
+}
+void sconv_set_bnb_mode(int v) { g_bnb_mode = v; }
+// partial rows (= row ranges) the streaming kernel leaves for a 1x1 data gradient + BN sums of this geometry, 0 when it does not take it
+int sconv_bnb_parts(int M, int N, int K, int dtype) {
+  SconvPlan pl;
+  if (sconv_bnb_mode() != 2 || !sconv_plan(M, N, K, dtype, dtype, &pl)) return 0;
+  return pl.nranges;
 }
 
 // rows per statistics partial when this kernel takes a (post-op free) 1x1 launch of the geometry, 0 when it does not

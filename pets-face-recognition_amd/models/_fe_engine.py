@@ -173,7 +173,11 @@ class FEEngine:
         # read of g per BN layer (-5.7 GB/step) and 45 launches, but MEASURED SLOWER (25.2 vs 23.2 ms/step): the data-gradient
         # kernels are bound by their vector-memory path into LDS, not by HBM, so the extra x reads and the registers of the sums
         # lengthen them (3.5 -> 7.4 ms) by more than the HBM-speed reduce kernels (2.1 ms at 4.5 TB/s) cost.  DESIGN.md §6.
-        self.fuse_bnb = os.environ.get("PFR_FUSE_BNB", "0") == "1"
+        # PFR_FUSE_BNB=2 (round 3): the same fusion through the STREAMING kernels only (pfr_sconv.hip EP 4 / 5: their epilogue has
+        # the slack the tile kernel's lacks) — 1x1 data gradients with one consuming BN; everything else keeps the separate pass.
+        # Measured (profiles/r03_bnb_streaming.txt): 19.64 -> 19.35 ms/step; default.  0 = separate pass everywhere.
+        self.fuse_bnb = int(os.environ.get("PFR_FUSE_BNB", "2") or 0)
+        lib.pfr_set_tuning(b"bnb", self.fuse_bnb)
         # Opt-in (PFR_FUSE_FIN=1): BatchNorm backward reduce + finalize in one launch (the last workgroups to arrive merge the
         # partial rows, pfr_bn_bwd_reduce_finalize) — 53 dependent 7 us launches fewer per ResNet-50 step, but MEASURED SLOWER
         # (profiles/r03_finalize_fusion.txt): with release fences 26.1 vs 19.5 ms/step (every fence is an L2 write-back scan), with
@@ -725,8 +729,8 @@ class FEEngine:
                                                0 if gres is None else gres.data_ptr(), self.did, rows, C)))
             release(part)
 
-        def dgrad_parts(dyshape, c, dxshape):
-            if not self.fuse_bnb:
+        def dgrad_parts(dyshape, c, dxshape, two_bns=False, accumulates=False):
+            if not self.fuse_bnb or (self.fuse_bnb == 2 and (two_bns or accumulates)):
                 return 0
             return lib.pfr_conv2d_dgrad_bn_parts(self.did, dyshape[0], dyshape[1], dyshape[2], dyshape[3], c.Cin, c.R, c.S,
                                                  {1: 0, 2: 1}[c.stride], dxshape[1], dxshape[2])
@@ -811,7 +815,7 @@ class FEEngine:
                 # main branch first (writes all of dxin), then the projection shortcut ACCUMULATES: for its 1x1 / stride-2
                 # conv only the (even, even) positions of dxin receive anything, and only those rows are touched
                 dgrad(dy, dyshape, c0, dxin, xshape)
-                npart = dgrad_parts(oshape, dc, xshape) if nxt is not None else 0
+                npart = dgrad_parts(oshape, dc, xshape, accumulates=True) if nxt is not None else 0
                 if npart > 0:
                     part = G((npart, 2, xshape[3]), torch.float32)
                     part2 = G((npart, 2, xshape[3]), torch.float32) if nxt[3] is not None else None
@@ -824,7 +828,7 @@ class FEEngine:
             else:
                 # identity shortcut: dxin = dgrad(conv1) + dcur ∘ mask in the data-gradient epilogue
                 log2 = {1: 0, 2: 1}[c0.stride]
-                npart = dgrad_parts(dyshape, c0, xshape) if nxt is not None else 0
+                npart = dgrad_parts(dyshape, c0, xshape, two_bns=nxt is not None and nxt[3] is not None) if nxt is not None else 0
                 if npart > 0:
                     part = G((npart, 2, xshape[3]), torch.float32)
                     part2 = G((npart, 2, xshape[3]), torch.float32) if nxt[3] is not None else None

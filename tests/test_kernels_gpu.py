@@ -744,3 +744,65 @@ def test_halo_staged_3x3_inference_epilogue(case):
     assert bool(((outs[1].float() - ref).abs() <= bound).all())
     assert bool(((outs[0].float() - ref).abs() <= bound).all())
     assert (outs[1] != outs[0]).float().mean().item() < 0.35
+
+
+@pytest.mark.parametrize("case", [
+    # (N, H, C = channels of dy, Co = channels of dx, join): streaming data gradient + BatchNorm-backward sums (pfr_sconv.hip EP 4 / 5)
+    (2, 56, 256, 64, False), (3, 28, 512, 128, False), (2, 56, 64, 256, True), (3, 28, 128, 512, True), (5, 14, 256, 1024, True),
+    (1, 9, 64, 64, False), (4, 23, 128, 256, True),
+])
+def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
+    """pfr_conv2d_dgrad_bn in streaming mode (pfr_set_tuning("bnb", 2)): dx must be BIT-identical to the plain data gradient / join,
+    and the partial sums must finalise (pfr_bn_bwd_finalize) to the dgamma / dbeta / coefficients of the separate
+    pfr_bn_bwd_reduce pass over the finished gradient — recomputed mask (inner BNs) and bit mask (block-output BN with the join)."""
+    from pets_face_recognition_amd._hip import lib
+    N, H, C, Co, join = case
+    g = torch.Generator().manual_seed(H * C + Co + 11)
+    M = N * H * H
+    dy = torch.randn(N, H, H, C, generator=g).to(DEV).bfloat16()
+    wt = (torch.randn(Co, 1, 1, C, generator=g) / C ** 0.5).to(DEV).bfloat16()
+    bnx = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16()
+    coef = torch.stack([torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) + 0.5, torch.rand(Co, generator=g) + 0.5,
+                        torch.randn(Co, generator=g) * 0.3]).to(DEV).contiguous()     # mean, invstd, scale, shift
+    gamma = (torch.rand(Co, generator=g) + 0.5).to(DEV)
+    res = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16() if join else None
+    rmask = torch.randint(0, 256, (M, Co // 8), generator=g, dtype=torch.uint8).to(DEV) if join else None
+    bmask = torch.randint(0, 256, (M, Co // 8), generator=g, dtype=torch.uint8).to(DEV) if join else None
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: 0 if t is None else t.data_ptr()
+    try:
+        lib.pfr_set_tuning(b"sconv", 2)
+        # reference: plain gradient (streaming kernel, already proven bit-identical to the tile kernel) + separate reduce
+        dx0 = torch.full((N, H, H, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
+        if join:
+            lib.pfr_conv2d_dgrad_join(dy.data_ptr(), wt.data_ptr(), dx0.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H, res.data_ptr(), rmask.data_ptr(), st)
+        else:
+            lib.pfr_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx0.data_ptr(), 1, 1, N, H, H, C, Co, 1, 1, 1, 0, 0, H, H, Co, 0, 0, 0, 0, 0, 0, 0, 0, st)
+        nb = lib.pfr_colreduce_blocks(Co, 1, M)
+        part0 = torch.zeros(nb, 2, Co, device=DEV)
+        lib.pfr_bn_bwd_reduce(dx0.data_ptr(), P(bmask), bnx.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+                              coef[3].data_ptr(), 3 if join else 2, 1, M, Co, part0.data_ptr(), st)
+        fin0 = [torch.empty(Co, device=DEV), torch.empty(Co, device=DEV), torch.empty(3, Co, device=DEV)]
+        lib.pfr_bn_bwd_finalize(part0.data_ptr(), nb, Co, float(M), gamma.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                fin0[0].data_ptr(), fin0[1].data_ptr(), fin0[2].data_ptr(), 0, st)
+        # fused
+        lib.pfr_set_tuning(b"bnb", 2)
+        np_ = lib.pfr_conv2d_dgrad_bn_parts(1, N, H, H, C, Co, 1, 1, 0, H, H)
+        assert 0 < np_ <= 256
+        part1 = torch.full((np_, 2, Co), float("nan"), device=DEV)
+        dx1 = torch.full((N, H, H, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
+        for _ in range(2):
+            lib.pfr_conv2d_dgrad_bn(dy.data_ptr(), wt.data_ptr(), dx1.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H, P(res), P(rmask), 0,
+                                    bnx.data_ptr(), coef.data_ptr(), P(bmask), part1.data_ptr(), 0, 0, 0, st)
+        fin1 = [torch.empty(Co, device=DEV), torch.empty(Co, device=DEV), torch.empty(3, Co, device=DEV)]
+        lib.pfr_bn_bwd_finalize(part1.data_ptr(), np_, Co, float(M), gamma.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                fin1[0].data_ptr(), fin1[1].data_ptr(), fin1[2].data_ptr(), 0, st)
+        torch.cuda.synchronize()
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+        lib.pfr_set_tuning(b"bnb", 0)
+    assert torch.equal(dx0, dx1)
+    sg, sgx = part0[:, 0].abs().sum(0) + 1e-3, part0[:, 1].abs().sum(0) + 1e-3
+    assert ((fin1[1] - fin0[1]).abs() / sg).max().item() < 5e-5          # dbeta = sum g
+    assert ((fin1[0] - fin0[0]).abs() / sgx).max().item() < 5e-5         # dgamma = sum g xhat
+    assert torch.allclose(fin1[2], fin0[2], rtol=3e-4, atol=1e-5 * float(fin0[2].abs().max()))

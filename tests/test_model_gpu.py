@@ -435,3 +435,35 @@ def test_inference_fold_cache_refolds_exactly_when_something_changed(dtype):
     with torch.no_grad():
         h = m(x).clone()
     assert folds() == (6, 8) and not torch.equal(h, f) and torch.equal(h, uncached())
+
+
+def test_streaming_bn_backward_sums_in_the_train_step(monkeypatch):
+    """PFR_FUSE_BNB=2: the BatchNorm-backward sums of the 1x1 data gradients / residual joins the streaming kernels take come out of
+    their epilogue; the step's gradients must equal the default path's up to the fp32 summation order (bf16, ResNet-50)."""
+    from oracle import resnet_ref
+    from pets_face_recognition_amd._hip import lib
+    sd = resnet_ref.init_state_dict("resnet50", 512, seed=9)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(8, 3, 128, 128, generator=g).to(DEV)
+    demb = (torch.randn(8, 512, generator=g) * 0.05).to(DEV)
+    grads = []
+    try:
+        lib.pfr_set_tuning(b"sconv", 2)      # small test batch: take every eligible geometry
+        for flag in ("0", "2"):
+            monkeypatch.setenv("PFR_FUSE_BNB", flag)
+            m = build("resnet50", torch.bfloat16, sd).train()
+            assert m.hip_engine().fuse_bnb == int(flag)
+            m(x).backward(demb)
+            torch.cuda.synchronize()
+            grads.append(torch.cat([p.grad.flatten() for p in m.parameters()]).double().cpu())
+            names = [f.__name__ for f, _ in m.hip_engine()._last_plan.meta["bwd0"] if hasattr(f, "__name__")]
+            if flag == "2":
+                assert names.count("pfr_conv2d_dgrad_bn") >= 12, names.count("pfr_conv2d_dgrad_bn")
+            else:
+                assert names.count("pfr_conv2d_dgrad_bn") == 0
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+        lib.pfr_set_tuning(b"bnb", 0)
+    assert torch.isfinite(grads[1]).all()
+    e = ((grads[0] - grads[1]).norm() / grads[0].norm()).item()
+    assert e < 2e-2, e
