@@ -874,8 +874,8 @@ extern "C" int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int
   PFR_CHECK_ARG((res == nullptr) == (res_mask == nullptr), "pfr_conv2d_dgrad_bn: res and res_mask go together");
   PFR_CHECK_ARG(pfr_conv2d_dgrad_bn_parts(dtype, N, H, W, C, Cout, R, S, idil_log2, OH, OW) > 0,
                 "pfr_conv2d_dgrad_bn: geometry not supported by the fused form (see pfr_conv2d_dgrad_bn_parts)");
-  PFR_CHECK_ARG(sconv_bnb_mode() != 2 || (!bn2_part && !accumulate && (!res || bn_mask)),
-                "pfr_conv2d_dgrad_bn: the streaming form (bnb mode 2) takes one BN, no accumulation, and a bit mask with the join");
+  PFR_CHECK_ARG(sconv_bnb_mode() != 2 || (!accumulate && (!res || bn_mask) && (!bn2_part || res)),
+                "pfr_conv2d_dgrad_bn: the streaming form (bnb mode 2) takes no accumulation, a bit mask with the join, a second BN only with the join");
   BnbArgs b;
   b.x[0] = bn_x; b.coef[0] = bn_coef; b.part[0] = bn_part;
   b.x[1] = bn2_x; b.coef[1] = bn2_coef; b.part[1] = bn2_part;

@@ -44,6 +44,10 @@ struct SconvParams {
   const float* bn_coef;
   const unsigned char* bn_mask;
   float* bn_part;
+  // EP 6: a second BN consuming the same gradient through the same bit mask (projection shortcut of the previous block)
+  const void* bnx2;
+  const float* bn_coef2;
+  float* bn_part2;
   int npanels, nranges, R;    // R: rows per range (multiple of the 32-row block height)
   int npw;                    // couts of a workgroup's weight panel (64, 128 or 256)
   int interleave;             // 1: block-interleaved row assignment (needs M % 32 == 0 and M / 32 divisible by nranges)
@@ -60,9 +64,10 @@ struct SconvParams {
 // sums (bit mask) — pfr_bn_bwd_reduce's pass over (gradient, BN input, mask) becomes one extra row read in this epilogue.
 template <int TP, int NS, bool STATS, int EP = 0>
 __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
-  constexpr bool JOIN = EP == 1 || EP == 5;
-  constexpr bool HASRES = EP == 1 || EP == 3 || EP == 5;
-  constexpr bool BNB = EP == 4 || EP == 5;
+  constexpr bool JOIN = EP == 1 || EP == 5 || EP == 6;
+  constexpr bool HASRES = EP == 1 || EP == 3 || EP == 5 || EP == 6;
+  constexpr bool BNB = EP == 4 || EP == 5 || EP == 6;
+  constexpr bool BNB2 = EP == 6;     // + the projection-shortcut BN of the previous block (same g, same mask, its own x)
   constexpr bool INFER = EP == 2 || EP == 3;
   static_assert(!(STATS && EP != 0), "only the plain variant publishes statistics");
   constexpr int NPV = TP * 32;           // couts per wave
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   constexpr int SB = NPV / 16;           // store instructions per block (32 rows x NPV couts x 2 B / 1 KiB)
   // residual (+ mask) and BN-input (+ mask) load instructions per block (BNB always issues its mask-byte load: with a recomputed
   // mask it reads one dummy byte, the count per block stays a compile-time constant)
-  constexpr int RL = (JOIN ? 2 * SB : (HASRES ? SB : 0)) + (BNB ? 2 * SB : 0);
+  constexpr int RL = (JOIN ? 2 * SB : (HASRES ? SB : 0)) + (BNB ? 2 * SB : 0) + (BNB2 ? SB : 0);
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -120,6 +125,9 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   // BN-backward coefficients of this lane's 8 couts per column group (read-back layout): xhat = ca*x + cb, mask = sc*x + sh > 0
   float bca[NCG][8], bcb[NCG][8], bsc[NCG][8], bsh[NCG][8];
   f32x2 b1[NCG][4], b2[NCG][4];
+  float cca[NCG][8], ccb[NCG][8];   // second BN: xhat coefficients and its sum g*mask*xhat
+  f32x2 c2[NCG][4];
+  __amdgpu_buffer_rsrc_t cxrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BNB2 ? p.bnx2 : p.y), 0, p.M * p.N * 2, 0x00020000);
   __amdgpu_buffer_rsrc_t bxrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BNB ? p.bnx : p.y), 0, p.M * p.N * 2, 0x00020000);
   __amdgpu_buffer_rsrc_t bmrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(BNB && p.bn_mask ? p.bn_mask : (const unsigned char*)p.y), 0, BNB && p.bn_mask ? p.M * (p.N >> 3) : 16, 0x00020000);
@@ -140,7 +148,18 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { b1[g][e] = (f32x2){0.f, 0.f}; b2[g][e] = (f32x2){0.f, 0.f}; }
+      for (int e = 0; e < 4; ++e) { b1[g][e] = (f32x2){0.f, 0.f}; b2[g][e] = (f32x2){0.f, 0.f}; c2[g][e] = (f32x2){0.f, 0.f}; }
+    if constexpr (BNB2) {
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = n0 + g * 64 + e_ch0 * 8 + e;
+          const float mu = p.bn_coef2[c], is = p.bn_coef2[p.N + c];
+          cca[g][e] = is;
+          ccb[g][e] = -mu * is;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // ---- weight panel -> LDS (once): linear LDS image, XOR swizzle on the source side
@@ -274,8 +293,19 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
                          : "memory");
         }
     }
-    u32x4 bxr[NCG][4];
+    u32x4 bxr[NCG][4], cxr[NCG][4];
     uint32_t bmk[NCG][4];
+    if constexpr (BNB2) {
+      const uint32_t rbase = (uint32_t)((m0 * p.N + n0) * 2);
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+                       : "=v"(cxr[g][ps])
+                       : "v"(y_lane + (uint32_t)(g * 128)), "s"(cxrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
+                       : "memory");
+    }
     if constexpr (BNB) {
       const uint32_t rbase = (uint32_t)((m0 * p.N + n0) * 2), kbase = (uint32_t)(m0 * (p.N >> 3) + (n0 >> 3));
 #pragma unroll
@@ -406,6 +436,11 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
               const f32x2 xh = {fmaf(xv[2 * e], bca[g][2 * e], bcb[g][2 * e]), fmaf(xv[2 * e + 1], bca[g][2 * e + 1], bcb[g][2 * e + 1])};
               b1[g][e] += gm;
               b2[g][e] = __builtin_elementwise_fma(gm, xh, b2[g][e]);
+              if constexpr (BNB2) {
+                const float x0 = __uint_as_float(cxr[g][ps][e] << 16), x1 = __uint_as_float(cxr[g][ps][e] & 0xffff0000u);
+                const f32x2 yh = {fmaf(x0, cca[g][2 * e], ccb[g][2 * e]), fmaf(x1, cca[g][2 * e + 1], ccb[g][2 * e + 1])};
+                c2[g][e] = __builtin_elementwise_fma(gm, yh, c2[g][e]);
+              }
             }
           }
           buffer_store_b128_sync(o, yrsrc, y_lane + (uint32_t)(g * 128), ybase + (uint32_t)(ps * 8 * p.N * 2));
@@ -422,36 +457,43 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   if constexpr (BNB) {
     __syncthreads();   // every wave is past its last panel read and ring use: the LDS is reused below
     // rows past M: the store was dropped, but their (zero + residual-out-of-range-zero) value entered the sums as g = 0: nothing to undo
-    float* red = reinterpret_cast<float*>(smem);   // [8 waves][2][NPV]
+    float* red = reinterpret_cast<float*>(smem);   // [8 waves][3][NPV]
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          float a = b1[g][e][h], q = b2[g][e][h];
+          float a = b1[g][e][h], q = b2[g][e][h], q2 = BNB2 ? c2[g][e][h] : 0.f;
 #pragma unroll
           for (int o = 8; o < 64; o <<= 1) {   // lanes with equal e_ch hold partials of the same couts
             a += __shfl_xor(a, o, 64);
             q += __shfl_xor(q, o, 64);
+            if constexpr (BNB2) q2 += __shfl_xor(q2, o, 64);
           }
           if (lane < 8) {
             const int c = g * 64 + lane * 8 + e * 2 + h;
-            red[(wave * 2 + 0) * NPV + c] = a;
-            red[(wave * 2 + 1) * NPV + c] = q;
+            red[(wave * 3 + 0) * NPV + c] = a;
+            red[(wave * 3 + 1) * NPV + c] = q;
+            red[(wave * 3 + 2) * NPV + c] = q2;
           }
         }
     __syncthreads();
     for (int c = tid; c < NPW; c += 512) {
       const int sl = c / NPV, cc = c - sl * NPV;
-      float a = 0.f, q = 0.f;
+      float a = 0.f, q = 0.f, q2 = 0.f;
       for (int wr = 0; wr < nrw; ++wr) {   // fixed order: deterministic
         const int w = wr * nsub + sl;
-        a += red[(w * 2 + 0) * NPV + cc];
-        q += red[(w * 2 + 1) * NPV + cc];
+        a += red[(w * 3 + 0) * NPV + cc];
+        q += red[(w * 3 + 1) * NPV + cc];
+        q2 += red[(w * 3 + 2) * NPV + cc];
       }
       p.bn_part[((size_t)r * 2 + 0) * p.N + pn * NPW + c] = a;
       p.bn_part[((size_t)r * 2 + 1) * p.N + pn * NPW + c] = q;
+      if constexpr (BNB2) {   // the second BN sees the same g and mask: its first sum is the same number
+        p.bn_part2[((size_t)r * 2 + 0) * p.N + pn * NPW + c] = a;
+        p.bn_part2[((size_t)r * 2 + 1) * p.N + pn * NPW + c] = q2;
+      }
     }
   }
   if (STATS) {
@@ -591,7 +633,8 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (p.accumulate || p.pro_scale || p.act) return 1;
   // BatchNorm-backward sums in the epilogue (pfr_conv2d_dgrad_bn): one BN, no statistics / bias; with the join its bit mask is required
   const bool bnb = p.bnb_part[0] != nullptr;
-  if (bnb && (sconv_bnb_mode() != 2 || p.bnb_part[1] || p.bias || p.stats_part || p.out_relu || (p.residual && !(p.res_mask && p.bnb_mask))))
+  if (bnb && (sconv_bnb_mode() != 2 || p.bias || p.stats_part || p.out_relu || (p.residual && !(p.res_mask && p.bnb_mask)) ||
+              (p.bnb_part[1] && !(p.residual && p.bnb_mask))))
     return 1;
   // inference form: bias (+ plain residual add) (+ ReLU), no statistics; training forms: no bias / ReLU, residual only as the join
   const bool infer = p.bias != nullptr;
@@ -611,6 +654,7 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.res = p.residual; sp.res_mask = p.res_mask;
   sp.bias = p.bias; sp.relu = p.out_relu;
   sp.bnx = p.bnb_x[0]; sp.bn_coef = p.bnb_coef[0]; sp.bn_mask = p.bnb_mask; sp.bn_part = p.bnb_part[0];
+  sp.bnx2 = p.bnb_x[1]; sp.bn_coef2 = p.bnb_coef[1]; sp.bn_part2 = p.bnb_part[1];
   sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
   static const bool il_on = !(getenv("PFR_SCONV_INTERLEAVE") && getenv("PFR_SCONV_INTERLEAVE")[0] == '0');
   sp.interleave = (il_on && p.M % 32 == 0 && (p.M / 32) % pl.nranges == 0 && (long)pl.R * pl.nranges == p.M) ? 1 : 0;
@@ -618,6 +662,7 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.div_ohow = p.div_ohow; sp.div_ow = p.div_ow;
   if (bnb) {   // 64-cout column slices keep the residual / BN-input rows and both sums inside the register budget
     pl.tp = 2;
+    if (p.bnb_part[1]) return sconv_launch_ns<2, false, 6>(sp, pl, st);
     return p.residual ? sconv_launch_ns<2, false, 5>(sp, pl, st) : sconv_launch_ns<2, false, 4>(sp, pl, st);
   }
   if (infer) {

@@ -828,7 +828,7 @@ class FEEngine:
             else:
                 # identity shortcut: dxin = dgrad(conv1) + dcur ∘ mask in the data-gradient epilogue
                 log2 = {1: 0, 2: 1}[c0.stride]
-                npart = dgrad_parts(dyshape, c0, xshape, two_bns=nxt is not None and nxt[3] is not None) if nxt is not None else 0
+                npart = dgrad_parts(dyshape, c0, xshape) if nxt is not None else 0   # (the join form also takes the two-BN case)
                 if npart > 0:
                     part = G((npart, 2, xshape[3]), torch.float32)
                     part2 = G((npart, 2, xshape[3]), torch.float32) if nxt[3] is not None else None

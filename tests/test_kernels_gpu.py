@@ -749,7 +749,7 @@ def test_halo_staged_3x3_inference_epilogue(case):
 @pytest.mark.parametrize("case", [
     # (N, H, C = channels of dy, Co = channels of dx, join): streaming data gradient + BatchNorm-backward sums (pfr_sconv.hip EP 4 / 5)
     (2, 56, 256, 64, False), (3, 28, 512, 128, False), (2, 56, 64, 256, True), (3, 28, 128, 512, True), (5, 14, 256, 1024, True),
-    (1, 9, 64, 64, False), (4, 23, 128, 256, True),
+    (1, 9, 64, 64, False), (4, 23, 128, 256, True), (2, 56, 64, 256, "two"), (5, 14, 256, 1024, "two"), (3, 11, 128, 512, "two"),
 ])
 def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
     """pfr_conv2d_dgrad_bn in streaming mode (pfr_set_tuning("bnb", 2)): dx must be BIT-identical to the plain data gradient / join,
@@ -757,6 +757,8 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
     pfr_bn_bwd_reduce pass over the finished gradient — recomputed mask (inner BNs) and bit mask (block-output BN with the join)."""
     from pets_face_recognition_amd._hip import lib
     N, H, C, Co, join = case
+    two = join == "two"      # + the projection-shortcut BN of the previous block: same gradient, same bit mask, its own input
+    join = bool(join)
     g = torch.Generator().manual_seed(H * C + Co + 11)
     M = N * H * H
     dy = torch.randn(N, H, H, C, generator=g).to(DEV).bfloat16()
@@ -785,15 +787,29 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
         fin0 = [torch.empty(Co, device=DEV), torch.empty(Co, device=DEV), torch.empty(3, Co, device=DEV)]
         lib.pfr_bn_bwd_finalize(part0.data_ptr(), nb, Co, float(M), gamma.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                                 fin0[0].data_ptr(), fin0[1].data_ptr(), fin0[2].data_ptr(), 0, st)
+        bnx2 = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16() if two else None
+        coef2 = torch.stack([torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) + 0.5, torch.ones(Co), torch.zeros(Co)]).to(DEV).contiguous() if two else None
+        if two:
+            part02 = torch.zeros(nb, 2, Co, device=DEV)
+            lib.pfr_bn_bwd_reduce(dx0.data_ptr(), P(bmask), bnx2.data_ptr(), coef2[0].data_ptr(), coef2[1].data_ptr(), coef2[2].data_ptr(),
+                                  coef2[3].data_ptr(), 3, 1, M, Co, part02.data_ptr(), st)
+            fin02 = [torch.empty(Co, device=DEV), torch.empty(Co, device=DEV), torch.empty(3, Co, device=DEV)]
+            lib.pfr_bn_bwd_finalize(part02.data_ptr(), nb, Co, float(M), gamma.data_ptr(), coef2[0].data_ptr(), coef2[1].data_ptr(),
+                                    fin02[0].data_ptr(), fin02[1].data_ptr(), fin02[2].data_ptr(), 0, st)
         # fused
         lib.pfr_set_tuning(b"bnb", 2)
         np_ = lib.pfr_conv2d_dgrad_bn_parts(1, N, H, H, C, Co, 1, 1, 0, H, H)
         assert 0 < np_ <= 256
         part1 = torch.full((np_, 2, Co), float("nan"), device=DEV)
+        part12 = torch.full((np_, 2, Co), float("nan"), device=DEV) if two else None
         dx1 = torch.full((N, H, H, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
         for _ in range(2):
             lib.pfr_conv2d_dgrad_bn(dy.data_ptr(), wt.data_ptr(), dx1.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H, P(res), P(rmask), 0,
-                                    bnx.data_ptr(), coef.data_ptr(), P(bmask), part1.data_ptr(), 0, 0, 0, st)
+                                    bnx.data_ptr(), coef.data_ptr(), P(bmask), part1.data_ptr(), P(bnx2), P(coef2), P(part12), st)
+        if two:
+            fin12 = [torch.empty(Co, device=DEV), torch.empty(Co, device=DEV), torch.empty(3, Co, device=DEV)]
+            lib.pfr_bn_bwd_finalize(part12.data_ptr(), np_, Co, float(M), gamma.data_ptr(), coef2[0].data_ptr(), coef2[1].data_ptr(),
+                                    fin12[0].data_ptr(), fin12[1].data_ptr(), fin12[2].data_ptr(), 0, st)
         fin1 = [torch.empty(Co, device=DEV), torch.empty(Co, device=DEV), torch.empty(3, Co, device=DEV)]
         lib.pfr_bn_bwd_finalize(part1.data_ptr(), np_, Co, float(M), gamma.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                                 fin1[0].data_ptr(), fin1[1].data_ptr(), fin1[2].data_ptr(), 0, st)
@@ -806,3 +822,8 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
     assert ((fin1[1] - fin0[1]).abs() / sg).max().item() < 5e-5          # dbeta = sum g
     assert ((fin1[0] - fin0[0]).abs() / sgx).max().item() < 5e-5         # dgamma = sum g xhat
     assert torch.allclose(fin1[2], fin0[2], rtol=3e-4, atol=1e-5 * float(fin0[2].abs().max()))
+    if two:
+        sgx2 = part02[:, 1].abs().sum(0) + 1e-3
+        assert ((fin12[1] - fin02[1]).abs() / sg).max().item() < 5e-5
+        assert ((fin12[0] - fin02[0]).abs() / sgx2).max().item() < 5e-5
+        assert torch.allclose(fin12[2], fin02[2], rtol=3e-4, atol=1e-5 * float(fin02[2].abs().max()))
