@@ -655,6 +655,249 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming weight gradient of the HBM-bound 1x1 / stride-1 layers (bf16; round 3).  The tile kernels above hand every 32-row stage
+// from the DMA to the MFMAs through a workgroup barrier and reach 0.45-0.55 of the HBM bound on the 56x56 layers (two operands
+// streamed once, a [Cout][C] output of 16-64 k values).  Here, as in pfr_sconv.hip, every wave owns a PRIVATE ring of LDS-DMA
+// slots and there is NO barrier in the loop: 256 persistent workgroups of 8 waves; the workgroup's output tile [PW][QW] is split
+// over WP x WQ waves (each GP x GQ column blocks of 64 channels = 2GP x 2GQ MFMA tiles), and WM = 8 / (WP*WQ) wave groups take
+// different 16-row reduction steps; the chip walks the tensors as ONE moving window (step b of the tensor goes to workgroup
+// (b / WM) % nsplit, wave group b % WM).  A step's operand block is [16 rows][64 channels] = 2 DMA instructions (8 rows x 128 B,
+// whole lines); 32-byte granules are XOR-swizzled by row on the SOURCE side so that the transposing `ds_read_b64_tr_b16` reads are
+// conflict free.  Operand blocks shared by waves of a workgroup are fetched once per wave (from L2 the second time): the price of
+// the missing barrier is 1.2-2x the LDS-DMA volume, which only shapes with a narrow operand can afford (host heuristic).
+// Wave groups are summed through LDS at the end (fixed order), one fp32 slab per workgroup, then wgrad_reduce_kernel.
+struct SwgradParams {
+  const void* x;     // [M][Q]
+  const void* dy;    // [M][lddy], Cout = P columns used
+  float* slabs;      // [nsplit][P][Q]
+  int M, P, Q, lddy;
+  int nsplit, tilesP, tilesQ;
+  int WP, WQ, WM;    // wave grid (WP * WQ * WM == 8)
+  int nit;           // reduction steps per wave
+};
+template <int GP, int GQ, int NS>
+__global__ __launch_bounds__(512, 1) void swgrad_kernel(SwgradParams p) {
+  constexpr int NB = GP + GQ;              // operand blocks per step
+  constexpr int SLOT = NB * 2048, IPS = NB * 2;
+  constexpr int TP = 2 * GP, TQ = 2 * GQ;
+  static_assert(8 * NS * SLOT <= 160 * 1024 && TP * TQ <= 8, "tile geometry");
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / (p.WP * p.WQ), wr = wave % (p.WP * p.WQ), wq = wr / p.WP, wp = wr % p.WP;
+  // workgroup -> (split, tile): the tiles of one split run on one XCD (they share an operand; block b is observed on XCD b % 8)
+  const int b = blockIdx.x, xcd = b & 7, j8 = b >> 3, ntile = p.tilesP * p.tilesQ;
+  const int tile = j8 % ntile, split = (j8 / ntile) * 8 + xcd;
+  if (split >= p.nsplit) return;
+  const int tq = tile % p.tilesQ, tpp = tile / p.tilesQ;
+  const int co0 = (tpp * p.WP + wp) * GP * 64, c0 = (tq * p.WQ + wq) * GQ * 64;
+
+  // ---- DMA lane geometry: instruction h of a block covers rows 8h .. 8h+7 x 128 B; lane -> (row, physical 16-byte chunk)
+  const int drow = lane >> 3, pc = lane & 7;
+  uint32_t voffA[2], voffB[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * h + drow;
+    const int lc = ((((pc >> 1) ^ (((row >> 1) & 1) << 1)) << 1) | (pc & 1));   // logical chunk landing in physical chunk pc
+    voffA[h] = (uint32_t)((row * p.lddy + co0 + lc * 8) * 2);
+    voffB[h] = (uint32_t)((row * p.Q + c0 + lc * 8) * 2);
+  }
+  const char* dyb = reinterpret_cast<const char*>(p.dy);
+  const char* xb = reinterpret_cast<const char*>(p.x);
+  char* const ring = smem + wave * (NS * SLOT);
+  const long nb = ((long)p.M + 15) >> 4;
+  auto issue = [&](int slot, long it) __attribute__((always_inline)) {
+    const long blk = (it * p.nsplit + split) * p.WM + wm;
+    const long m0 = blk << 4;
+    const long left = blk < nb ? (long)p.M - m0 : 0;                 // rows past M (and steps past the end) read zeros
+    const long rows = left > 16 ? 16 : left;
+    const long mb = blk < nb ? m0 : 0;
+    __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dyb + mb * p.lddy * 2), 0, (int)(rows * p.lddy * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb + mb * p.Q * 2), 0, (int)(rows * p.Q * 2), 0x00020000);
+    char* base = ring + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < GP; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (__attribute__((address_space(3))) void*)(base + i * 2048 + h * 1024), 16,
+                                                 (int)voffA[h], i * 128, 0, 0);
+#pragma unroll
+    for (int j = 0; j < GQ; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)(base + (GP + j) * 2048 + h * 1024), 16,
+                                                 (int)voffB[h], j * 128, 0, 0);
+  };
+
+  f32x16 acc[TP][TQ];
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- transpose-read lane bases (one per 32-channel half of a block): row (g>>1)*8 + (s4>>2), swizzled 32-byte granule, piece s4&3
+  const int g = lane >> 4, s4 = lane & 15;
+  const int r0 = (g >> 1) * 8 + (s4 >> 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)(wave * (NS * SLOT));
+  uint32_t laneT[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int gran = 2 * t + (g & 1);
+    laneT[t] = lds0 + r0 * 128 + ((gran ^ (((r0 >> 1) & 1) << 1)) << 5) + (s4 & 3) * 8;
+  }
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s, s);
+
+  auto step = [&](auto slot_c, long it) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    issue((S + NS - 1) % NS, it + NS - 1);
+    wg_wait_vm<(NS - 1) * IPS>();
+    u32x2 hp[TP][2], hq[TQ][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int i = 0; i < TP; ++i) hp[i][q] = lds_read_tr16(laneT[i & 1], S * SLOT + (i >> 1) * 2048 + q * 512);
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) hq[j][q] = lds_read_tr16(laneT[j & 1], S * SLOT + (GP + (j >> 1)) * 2048 + q * 512);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(hp[i][q]));
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(hq[j][q]));
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        const u32x4 ua = {hp[i][0][0], hp[i][0][1], hp[i][1][0], hp[i][1][1]};
+        const u32x4 ub = {hq[j][0][0], hq[j][0][1], hq[j][1][0], hq[j][1][1]};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), acc[i][j], 0, 0, 0);
+      }
+  };
+  for (long it = 0; it < p.nit; it += NS) {
+    step(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < p.nit) step(std::integral_constant<int, 1>{}, it + 1);
+    if constexpr (NS > 2) { if (it + 2 < p.nit) step(std::integral_constant<int, 2>{}, it + 2); }
+    if constexpr (NS > 3) { if (it + 3 < p.nit) step(std::integral_constant<int, 3>{}, it + 3); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (MFMA -> VALU read-after-write distance across the loop's back edge is software-managed: see pfr_sconv.hip)
+#pragma unroll
+  for (int i = 0; i < TP; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) asm volatile("s_nop 15" : "+v"(acc[i][j]));
+  __syncthreads();
+
+  // ---- sum the WM wave groups (tree over LDS, fixed order), then one slab per workgroup
+  float* red = reinterpret_cast<float*>(smem);
+  const int nwt = p.WP * p.WQ;                 // waves per group
+  for (int stride = p.WM >> 1; stride >= 1; stride >>= 1) {
+    if (wm >= stride && wm < 2 * stride) {
+      float* dst = red + (size_t)((wm - stride) * nwt + wr) * (TP * TQ * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) dst[((i * TQ + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (wm < stride) {
+      const float* src = red + (size_t)(wm * nwt + wr) * (TP * TQ * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += src[((i * TQ + j) * 16 + e) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wm == 0) {
+    float* out = p.slabs + (size_t)split * p.P * p.Q;
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        const int col = c0 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = co0 + i * 32 + acc_row(e, lane);
+          out[(size_t)co * p.Q + col] = acc[i][j][e];
+        }
+      }
+  }
+}
+
+// PFR_SWGRAD / pfr_set_tuning("swgrad"): 0 never, 1 where measured faster (default), 2 wherever the geometry allows
+static int g_swgrad = -1;
+void swgrad_set_mode(int v) { g_swgrad = v; }
+static int swgrad_mode() {
+  if (g_swgrad < 0) { const char* e = getenv("PFR_SWGRAD"); g_swgrad = e ? atoi(e) : 1; }
+  return g_swgrad;
+}
+struct SwgradPlan { int gp, gq, wp, wq, wm, tilesP, tilesQ, nsplit; };
+// geometry-only decision (pfr_conv2d_wgrad_splits sees only M, Cout, KK: a 3x3 layer with the same (Cout, KK) merely gets room
+// for this many slabs; the launcher takes the streaming kernel only for 1x1 / stride-1 bf16 launches without a fused prologue)
+static bool swgrad_plan(int M, int P, int Q, SwgradPlan* sp) {
+  const int mode = swgrad_mode();
+  if (mode == 0 || P % 64 || Q % 64 || P < 64 || Q < 64 || P > 1024 || Q > 1024) return false;
+  int gp, gq;
+  if (P >= 128 && P >= Q) { gp = 2; gq = 1; } else if (Q >= 128) { gp = 1; gq = 2; } else { gp = 1; gq = 1; }
+  // workgroup tile: up to 256 x 128 / 128 x 256 / 256 x 256 channels in 8 waves
+  int pw = P, qw = Q;
+  if (pw > 256) pw = 256;
+  if (qw > 256) qw = 256;
+  if (P % pw || Q % qw || pw % (gp * 64) || qw % (gq * 64)) return false;
+  int wp = pw / (gp * 64), wq = qw / (gq * 64);
+  if (wp * wq > 8) { if (qw > 128 && gq == 1) qw = 128; else if (pw > 128 && gp == 1) pw = 128; wp = pw / (gp * 64); wq = qw / (gq * 64); }
+  if (wp * wq > 8 || 8 % (wp * wq) || P % pw || Q % qw) return false;
+  const int wm = 8 / (wp * wq);
+  const int tilesP = P / pw, tilesQ = Q / qw, ntile = tilesP * tilesQ;
+  if (ntile > 32 || 256 % ntile) return false;
+  int nsplit = 256 / ntile;
+  const long slab = (long)P * Q * 4;
+  while (nsplit > 8 && nsplit * slab > (48L << 20)) nsplit >>= 1;
+  const long nb = ((long)M + 15) / 16;
+  if (nb < (long)nsplit * wm * 8) return false;     // too few steps per wave for a pipeline
+  if (mode == 1) {
+    // measured (tools/wgrad_bench.py): the private copies pay only where one operand is narrow
+    const int amp_num = P * wq + Q * wp, amp_den = P + Q;   // LDS-DMA volume over unique bytes, per workgroup tile
+    if (amp_num * 10 > amp_den * 13 || M < 100000) return false;
+  }
+  sp->gp = gp; sp->gq = gq; sp->wp = wp; sp->wq = wq; sp->wm = wm; sp->tilesP = tilesP; sp->tilesQ = tilesQ; sp->nsplit = nsplit;
+  return true;
+}
+template <int GP, int GQ, int NS>
+static void swgrad_go(const SwgradParams& sp, hipStream_t st) {
+  constexpr int lds = 8 * NS * (GP + GQ) * 2048;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)swgrad_kernel<GP, GQ, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  hipLaunchKernelGGL((swgrad_kernel<GP, GQ, NS>), dim3(256), dim3(512), lds, st, sp);
+}
+static int swgrad_launch(const WgradParams& p, const SwgradPlan& pl, float* slabs, hipStream_t st) {
+  SwgradParams sp;
+  sp.x = p.x; sp.dy = p.dy; sp.slabs = slabs;
+  sp.M = p.M; sp.P = p.Cout; sp.Q = p.KK; sp.lddy = p.lddy;
+  sp.nsplit = pl.nsplit; sp.tilesP = pl.tilesP; sp.tilesQ = pl.tilesQ;
+  sp.WP = pl.wp; sp.WQ = pl.wq; sp.WM = pl.wm;
+  const long nb = ((long)p.M + 15) / 16, per = (long)pl.nsplit * pl.wm;
+  sp.nit = (int)((nb + per - 1) / per);
+  if (pl.gp == 2) swgrad_go<2, 1, 3>(sp, st);
+  else if (pl.gq == 2) swgrad_go<1, 2, 3>(sp, st);
+  else swgrad_go<1, 1, 4>(sp, st);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 // sums the split slabs: block = 64 columns (of 4 floats) x 4 split-lanes; every lane keeps 4 independent loads in flight
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4,
                                                            int splits, float scale, int accumulate) {
@@ -767,6 +1010,8 @@ extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   }
   static const int forced = getenv("PFR_WGRAD_FORCE_SPLITS") ? atoi(getenv("PFR_WGRAD_FORCE_SPLITS")) : 0;   // tuning sweeps
   if (forced > 0) best = forced < maxs ? forced : maxs;
+  SwgradPlan spl;
+  if (swgrad_plan(M, Cout, KK, &spl) && spl.nsplit > best) best = spl.nsplit;   // (room for the streaming kernel's slabs)
   return (int)best;
 }
 
@@ -799,7 +1044,13 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.dw = direct ? dw : workspace;
   int bp, bq, rc;
   wgrad_tiles(Cout, p.KK, &bp, &bq);
-  if (dtype == PFR_BF16 && p.v2 && wgrad_v3() && wgrad_big_geom(p.M, Cout, p.KK)) {
+  SwgradPlan spl;
+  if (dtype == PFR_BF16 && p.v2 && p.simple && !direct && p.lddy % 8 == 0 && (long)p.M * p.lddy * 2 < (1L << 31) &&
+      (long)p.M * p.KK * 2 < (1L << 31) && swgrad_plan(p.M, Cout, p.KK, &spl)) {
+    rc = swgrad_launch(p, spl, workspace, stream);
+    if (rc != PFR_OK) return rc;
+    p.splits = spl.nsplit;
+  } else if (dtype == PFR_BF16 && p.v2 && wgrad_v3() && wgrad_big_geom(p.M, Cout, p.KK)) {
     p.tilesP = (p.Cout + 255) / 256;
     p.tilesQ = (p.KK + 255) / 256;
     constexpr int lds = 4 * 32 * (256 + 256) * 2;

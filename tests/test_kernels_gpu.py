@@ -827,3 +827,33 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
         assert ((fin12[1] - fin02[1]).abs() / sg).max().item() < 5e-5
         assert ((fin12[0] - fin02[0]).abs() / sgx2).max().item() < 5e-5
         assert torch.allclose(fin12[2], fin02[2], rtol=3e-4, atol=1e-5 * float(fin02[2].abs().max()))
+
+
+@pytest.mark.parametrize("case", [
+    # (N, H, C, Cout): 1x1 / stride-1 weight gradients through the streaming kernel (pfr_wgrad.hip swgrad_kernel), incl. ragged M
+    (16, 56, 64, 256), (16, 56, 256, 64), (8, 56, 64, 64), (9, 28, 128, 512), (9, 28, 512, 128), (33, 14, 256, 1024), (16, 28, 256, 256),
+    (3, 55, 64, 256), (5, 37, 128, 128),
+])
+def test_streaming_1x1_weight_gradient(case):
+    """dw = dy^T x of a 1x1 convolution through the barrier-free streaming kernel (per-wave LDS-DMA rings, transposing LDS reads,
+    wave groups summed through LDS) vs the tile kernel and an fp32 torch reference; deterministic from launch to launch."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, C, Co = case
+    g = torch.Generator().manual_seed(H * C + Co + 13)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV).bfloat16()
+    dy = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16()
+    outs = []
+    try:
+        for mode in (0, 2, 2):
+            lib.pfr_set_tuning(b"swgrad", mode)
+            dw = o.conv2d_wgrad(x, dy, 1, 1, 1, 0)
+            torch.cuda.synchronize()
+            outs.append(dw.clone())
+    finally:
+        lib.pfr_set_tuning(b"swgrad", 1)
+    ref = (dy.float().reshape(-1, Co).t().double() @ x.float().reshape(-1, C).double()).float().reshape(Co, 1, 1, C)
+    scale = ref.abs().max()
+    assert (outs[0] - ref).abs().max() <= 2e-5 * scale + 1e-3
+    assert (outs[1] - ref).abs().max() <= 2e-5 * scale + 1e-3
+    assert torch.equal(outs[1], outs[2])
