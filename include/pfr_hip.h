@@ -96,7 +96,9 @@ int pfr_conv2d_dgrad_join(const void* dy, const void* wt, void* dx, int dtype, i
  * optional second BN consuming the same gradient through the same bit mask (projection shortcut).  res/res_mask = the residual
  * join of pfr_conv2d_dgrad_join (both or neither), accumulate adds into dx.  pfr_conv2d_dgrad_bn_parts -> number of partial
  * rows per BN for the geometry (feed pfr_bn_bwd_finalize with it), or 0 when the fused form does not apply (run
- * pfr_bn_bwd_reduce instead). */
+ * pfr_bn_bwd_reduce instead).  With pfr_set_tuning("bnb", 2) (PFR_FUSE_BNB=2) the fused form is provided by the streaming kernels
+ * only (1x1 / stride-1 geometries pfr_sconv.hip takes; parts = its row ranges): one BN, or two with the join; no accumulate, but `res`
+ * without `res_mask` is a plain add and may alias dx (a gradient already accumulated there). */
 int pfr_conv2d_dgrad_bn_parts(int dtype, int N, int H, int W, int C, int Cout, int R, int S, int idil_log2, int OH, int OW);
 int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int R, int S,
                         int pad, int idil_log2, int OH, int OW, const void* res, const unsigned char* res_mask, int accumulate,

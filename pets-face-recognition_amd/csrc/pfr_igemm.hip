@@ -871,7 +871,8 @@ extern "C" int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int
                                    float* bn2_part, hipStream_t stream) {
   PFR_CHECK_ARG(bn_x && bn_coef && bn_part, "pfr_conv2d_dgrad_bn: null pointer");
   PFR_CHECK_ARG(!bn2_part || (bn2_x && bn2_coef && bn_mask), "pfr_conv2d_dgrad_bn: the second BN needs x, coef and the shared bit mask");
-  PFR_CHECK_ARG((res == nullptr) == (res_mask == nullptr), "pfr_conv2d_dgrad_bn: res and res_mask go together");
+  PFR_CHECK_ARG(sconv_bnb_mode() == 2 ? (res != nullptr || res_mask == nullptr) : ((res == nullptr) == (res_mask == nullptr)),
+                "pfr_conv2d_dgrad_bn: res and res_mask go together (streaming form: res without a mask = plain add, res may be dx)");
   PFR_CHECK_ARG(pfr_conv2d_dgrad_bn_parts(dtype, N, H, W, C, Cout, R, S, idil_log2, OH, OW) > 0,
                 "pfr_conv2d_dgrad_bn: geometry not supported by the fused form (see pfr_conv2d_dgrad_bn_parts)");
   PFR_CHECK_ARG(sconv_bnb_mode() != 2 || (!accumulate && (!res || bn_mask) && (!bn2_part || res)),

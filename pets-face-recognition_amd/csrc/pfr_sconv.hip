@@ -110,7 +110,11 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.M * p.N * 2, 0x00020000);
   const uint32_t OOBB = 0xF0000000u;
   __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0, p.M * p.N * 2, 0x00020000);
-  __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.res_mask ? p.res_mask : (const unsigned char*)p.y), 0, p.M * (p.N >> 3), 0x00020000);
+  // (join without a mask = plain add of `res`, e.g. a gradient already accumulated in y itself: the mask-byte load then reads one
+  //  dummy byte so that the per-block load count stays a compile-time constant)
+  const bool has_rmask = p.res_mask != nullptr;
+  __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(has_rmask ? p.res_mask : (const unsigned char*)p.y), 0,
+                                                                   has_rmask ? p.M * (p.N >> 3) : 16, 0x00020000);
 
   // inference epilogue: this lane's 8 couts of every column group (read-back layout), fetched before any DMA is in flight
   float bias8[NCG][8];
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
           if constexpr (JOIN)
             asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen"
                          : "=v"(rmk[g][ps])
-                         : "v"(k_lane + (uint32_t)(g * 8)), "s"(mrsrc), "s"(kbase + (uint32_t)(ps * p.N))
+                         : "v"(has_rmask ? k_lane + (uint32_t)(g * 8) : 0u), "s"(mrsrc), "s"(has_rmask ? kbase + (uint32_t)(ps * p.N) : 0u)
                          : "memory");
         }
     }
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
           Chunk<bf16_t>::unpack(v, f);
           if constexpr (HASRES) Chunk<bf16_t>::unpack(rres[g][ps], rr8);
           if constexpr (JOIN) {
-            const uint32_t bits = rmk[g][ps];
+            const uint32_t bits = has_rmask ? rmk[g][ps] : 0xffu;
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += ((bits >> e) & 1u) ? rr8[e] : 0.f;
           } else if constexpr (INFER) {
@@ -633,7 +637,7 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (p.accumulate || p.pro_scale || p.act) return 1;
   // BatchNorm-backward sums in the epilogue (pfr_conv2d_dgrad_bn): one BN, no statistics / bias; with the join its bit mask is required
   const bool bnb = p.bnb_part[0] != nullptr;
-  if (bnb && (sconv_bnb_mode() != 2 || p.bias || p.stats_part || p.out_relu || (p.residual && !(p.res_mask && p.bnb_mask)) ||
+  if (bnb && (sconv_bnb_mode() != 2 || p.bias || p.stats_part || p.out_relu || (p.residual && !p.bnb_mask) ||
               (p.bnb_part[1] && !(p.residual && p.bnb_mask))))
     return 1;
   // inference form: bias (+ plain residual add) (+ ReLU), no statistics; training forms: no bias / ReLU, residual only as the join
@@ -641,7 +645,8 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (infer && (p.stats_part || p.res_mask)) return 1;
   if (!infer && p.out_relu) return 1;
   const bool join = !infer && p.residual != nullptr;
-  if (join && (!p.res_mask || p.stats_part)) return 1;   // residual only in its data-gradient join form (bit mask)
+  // residual only in its data-gradient join form (bit mask), or — with the BN sums — as a plain add (res may be y itself)
+  if (join && ((!p.res_mask && !bnb) || p.stats_part)) return 1;
   if (p.ostride != 1 && (p.H != p.OH * p.ostride || p.W != p.OW * p.ostride)) return 1;
   if ((long)p.N * p.H * p.W * p.K * 2 >= ((long)1 << 31)) return 1;
   SconvPlan pl;

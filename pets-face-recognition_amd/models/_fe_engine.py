@@ -812,11 +812,27 @@ class FEEngine:
                        pre=None if (p3 is None or p3[1] is None) else p3[1])      # projection-shortcut BN: g = dcur ∘ mask
                 release(dcur)
                 wgrad(xin, xshape, dgd, oshape, dc)
-                # main branch first (writes all of dxin), then the projection shortcut ACCUMULATES: for its 1x1 / stride-2
-                # conv only the (even, even) positions of dxin receive anything, and only those rows are touched
-                dgrad(dy, dyshape, c0, dxin, xshape)
-                npart = dgrad_parts(oshape, dc, xshape, accumulates=True) if nxt is not None else 0
-                if npart > 0:
+                # (opt-in, PFR_BNB_INPLACE=1: measured SLOWER, 19.09 -> 19.24 ms/step — the projection data gradient then has to write
+                #  all of dxin (zeros where its stride skips) and the main branch reads it back: two more passes over the block input
+                #  than the accumulate form below costs, for one saved reduce pass)
+                npart2 = dgrad_parts(dyshape, c0, xshape) if (nxt is not None and self.fuse_bnb == 2 and nxt[3] is None
+                                                                and os.environ.get("PFR_BNB_INPLACE") == "1") else 0
+                if npart2 > 0:
+                    # streaming form: the projection shortcut writes dxin first (all of it: zeros where its stride skips), then the
+                    # main branch adds to it IN PLACE (res = dx, no mask) and leaves the previous block's BN-backward sums
+                    dgrad(dgd, oshape, dc, dxin, xshape)
+                    part = G((npart2, 2, xshape[3]), torch.float32)
+                    dgrad_bn(dy, dyshape, c0, dxin, xshape, (nxt[0], nxt[1], nxt[2], part), None, res=dxin, res_mask=None)
+                    pre3[k - 1] = ((part, npart2), None)
+                    npart = -1
+                else:
+                    # main branch first (writes all of dxin), then the projection shortcut ACCUMULATES: for its 1x1 / stride-2
+                    # conv only the (even, even) positions of dxin receive anything, and only those rows are touched
+                    dgrad(dy, dyshape, c0, dxin, xshape)
+                    npart = dgrad_parts(oshape, dc, xshape, accumulates=True) if nxt is not None else 0
+                if npart < 0:
+                    pass
+                elif npart > 0:
                     part = G((npart, 2, xshape[3]), torch.float32)
                     part2 = G((npart, 2, xshape[3]), torch.float32) if nxt[3] is not None else None
                     dgrad_bn(dgd, oshape, dc, dxin, xshape, (nxt[0], nxt[1], nxt[2], part),

@@ -750,6 +750,7 @@ def test_halo_staged_3x3_inference_epilogue(case):
     # (N, H, C = channels of dy, Co = channels of dx, join): streaming data gradient + BatchNorm-backward sums (pfr_sconv.hip EP 4 / 5)
     (2, 56, 256, 64, False), (3, 28, 512, 128, False), (2, 56, 64, 256, True), (3, 28, 128, 512, True), (5, 14, 256, 1024, True),
     (1, 9, 64, 64, False), (4, 23, 128, 256, True), (2, 56, 64, 256, "two"), (5, 14, 256, 1024, "two"), (3, 11, 128, 512, "two"),
+    (2, 56, 128, 256, "inplace"), (3, 28, 256, 512, "inplace"), (5, 14, 512, 1024, "inplace"),
 ])
 def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
     """pfr_conv2d_dgrad_bn in streaming mode (pfr_set_tuning("bnb", 2)): dx must be BIT-identical to the plain data gradient / join,
@@ -758,6 +759,7 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
     from pets_face_recognition_amd._hip import lib
     N, H, C, Co, join = case
     two = join == "two"      # + the projection-shortcut BN of the previous block: same gradient, same bit mask, its own input
+    inplace = join == "inplace"   # res = dx itself, no residual mask: the main branch adds to what the projection shortcut left there
     join = bool(join)
     g = torch.Generator().manual_seed(H * C + Co + 11)
     M = N * H * H
@@ -768,7 +770,7 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
                         torch.randn(Co, generator=g) * 0.3]).to(DEV).contiguous()     # mean, invstd, scale, shift
     gamma = (torch.rand(Co, generator=g) + 0.5).to(DEV)
     res = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16() if join else None
-    rmask = torch.randint(0, 256, (M, Co // 8), generator=g, dtype=torch.uint8).to(DEV) if join else None
+    rmask = torch.randint(0, 256, (M, Co // 8), generator=g, dtype=torch.uint8).to(DEV) if (join and not inplace) else None
     bmask = torch.randint(0, 256, (M, Co // 8), generator=g, dtype=torch.uint8).to(DEV) if join else None
     st = torch.cuda.current_stream().cuda_stream
     P = lambda t: 0 if t is None else t.data_ptr()
@@ -776,7 +778,10 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
         lib.pfr_set_tuning(b"sconv", 2)
         # reference: plain gradient (streaming kernel, already proven bit-identical to the tile kernel) + separate reduce
         dx0 = torch.full((N, H, H, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
-        if join:
+        if inplace:
+            dx0.copy_(res)
+            lib.pfr_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx0.data_ptr(), 1, 1, N, H, H, C, Co, 1, 1, 1, 0, 0, H, H, Co, 0, 0, 1, 0, 0, 0, 0, 0, st)
+        elif join:
             lib.pfr_conv2d_dgrad_join(dy.data_ptr(), wt.data_ptr(), dx0.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H, res.data_ptr(), rmask.data_ptr(), st)
         else:
             lib.pfr_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx0.data_ptr(), 1, 1, N, H, H, C, Co, 1, 1, 1, 0, 0, H, H, Co, 0, 0, 0, 0, 0, 0, 0, 0, st)
@@ -804,7 +809,10 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
         part12 = torch.full((np_, 2, Co), float("nan"), device=DEV) if two else None
         dx1 = torch.full((N, H, H, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
         for _ in range(2):
-            lib.pfr_conv2d_dgrad_bn(dy.data_ptr(), wt.data_ptr(), dx1.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H, P(res), P(rmask), 0,
+            if inplace:
+                dx1.copy_(res)
+            lib.pfr_conv2d_dgrad_bn(dy.data_ptr(), wt.data_ptr(), dx1.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H,
+                                    dx1.data_ptr() if inplace else P(res), P(rmask), 0,
                                     bnx.data_ptr(), coef.data_ptr(), P(bmask), part1.data_ptr(), P(bnx2), P(coef2), P(part12), st)
         if two:
             fin12 = [torch.empty(Co, device=DEV), torch.empty(Co, device=DEV), torch.empty(3, Co, device=DEV)]
