@@ -524,6 +524,10 @@ def main():
                 "traffic_note": "HBM bytes per step of the same launches (PMC), algorithmic minimum = activations+weights once",
                 "traffic_stale": traffic_stale,
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(total_ms, 3),
+                # launches of the family that ALSO do the BatchNorm-backward reduction in their epilogue (pfr_conv2d_dgrad_bn): their
+                # time is in conv_ms although part of it is work the separate pfr_bn_bwd_reduce pass did before round 3
+                "fused_bn_sums_ms_per_step": round(summ["pfr_conv2d_dgrad_bn"][1] / nprof, 3) if "pfr_conv2d_dgrad_bn" in summ else 0.0,
+                "bn_bwd_reduce_ms_per_step": round(summ["pfr_bn_bwd_reduce"][1] / nprof, 3) if "pfr_bn_bwd_reduce" in summ else 0.0,
                 "whole_step_frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
                 "layer_bound": {"bound_ms": round(lb_ms, 3), "hbm_only_ms": round(lb_hbm, 3), "measured_ms": round(lb_meas, 3),
                                 "frac": round(lb_ms / lb_meas, 4) if lb_meas else None,
