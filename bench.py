@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0
 
 # every C-ABI entry point whose launches execute the FLOPs counted by conv_flops_per_img (conv / Linear forward, data and
 # weight gradients incl. the fused-epilogue variants, windowed attention)
-CONV_FAMILY = ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_conv2d_dgrad_join", "pfr_conv2d_dgrad_bn", "pfr_gemm_act",
+CONV_FAMILY = ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_conv2d_dgrad_join", "pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub", "pfr_gemm_act",
                "pfr_window_attn_fwd", "pfr_window_attn_bwd")
 
 
@@ -476,6 +476,11 @@ def main():
                 key = "dgrad_bn%s N%d H%d W%d C%d Co%d R%d dil%d OH%d" % ("_join" if a[15] else "", a[4], a[5], a[6], a[7], a[8], a[9], a[12], a[13])
                 fl = 2.0 * a[4] * a[13] * a[14] * a[8] * a[9] * a[10] * a[7] / (4 ** a[12])
                 by = esz * (a[4] * a[5] * a[6] * a[7] + (3 if a[15] else 2) * a[4] * a[13] * a[14] * a[8] + a[8] * a[9] * a[10] * a[7])
+            elif name == "pfr_conv2d_dgrad_bn_sub":
+                # (dy, wt, dx, dtype, N, H, W, C, Cout, OH, OW, res_compact, bn_x, ...): 1x1 data gradient + compact shortcut gradient + BN sums
+                key = "dgrad_bn_sub N%d H%d W%d C%d Co%d" % (a[4], a[5], a[6], a[7], a[8])
+                fl = 2.0 * a[4] * a[9] * a[10] * a[8] * a[7]
+                by = esz * (a[4] * a[5] * a[6] * a[7] + 2.25 * a[4] * a[9] * a[10] * a[8] + a[8] * a[7])
             else:
                 key, fl, by = name, 0.0, 0.0
             d = det.setdefault(key, [0, 0.0, fl, by])
@@ -504,7 +509,7 @@ def main():
         # The roofline fraction is quoted for launches that do ONLY convolution work.  pfr_conv2d_dgrad_bn launches (data gradient +
         # the BatchNorm-backward reduction in the epilogue, round 3) are a different, HBM-bound kernel whose time contains what the
         # separate pfr_bn_bwd_reduce pass used to do: their time AND their FLOPs are taken out of this ratio and reported next to it.
-        fused_ms = summ["pfr_conv2d_dgrad_bn"][1] / nprof if "pfr_conv2d_dgrad_bn" in summ else 0.0
+        fused_ms = sum(summ[k][1] for k in ("pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub") if k in summ) / nprof
         fused_flops = sum(v[0] / nprof * v[2] for k, v in det.items() if k.startswith("dgrad_bn"))
         conv_ms = conv_ms_all - fused_ms
         ach = (flops - fused_flops) / (conv_ms * 1e-3) / 1e12
@@ -535,7 +540,7 @@ def main():
                 "bn_sum_launch_tflop_per_step": round(fused_flops / 1e12, 4),
                 # the launches that ALSO do the BatchNorm-backward reduction in their epilogue (pfr_conv2d_dgrad_bn) and what is left
                 # of the separate pfr_bn_bwd_reduce pass
-                "fused_bn_sums_ms_per_step": round(summ["pfr_conv2d_dgrad_bn"][1] / nprof, 3) if "pfr_conv2d_dgrad_bn" in summ else 0.0,
+                "fused_bn_sums_ms_per_step": round(fused_ms, 3),
                 "bn_bwd_reduce_ms_per_step": round(summ["pfr_bn_bwd_reduce"][1] / nprof, 3) if "pfr_bn_bwd_reduce" in summ else 0.0,
                 "whole_step_frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
                 "layer_bound": {"bound_ms": round(lb_ms, 3), "hbm_only_ms": round(lb_hbm, 3), "measured_ms": round(lb_meas, 3),

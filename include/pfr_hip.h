@@ -105,6 +105,14 @@ int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int dtype, int
                         const void* bn_x, const float* bn_coef, const unsigned char* bn_mask, float* bn_part, const void* bn2_x,
                         const float* bn2_coef, float* bn2_part, pfr_stream_t stream);
 
+/* Main-branch data gradient of a block with a 1x1 / stride-2 projection shortcut: dx = dgrad(dy) + up2(res_compact) and the
+ * BatchNorm-backward sums of the BN whose output gradient dx is.  res_compact [N][OH/2][OW/2][Cout] = the shortcut's gradient,
+ * computed densely on its own grid (a plain pfr_conv2d_fwd over its dy with the pfr_weight_dgrad_layout weights), added at the
+ * pixels with even (oh, ow).  Streaming form only (pfr_set_tuning("bnb", 2), pfr_conv2d_dgrad_bn_parts > 0, even OH / OW). */
+int pfr_conv2d_dgrad_bn_sub(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int OH, int OW,
+                            const void* res_compact, const void* bn_x, const float* bn_coef, const unsigned char* bn_mask,
+                            float* bn_part, pfr_stream_t stream);
+
 /* pfr_conv2d_wgrad replaces the autograd weight gradient of nn.Conv2d / nn.Linear / F.linear:
  *   dw[co][r][s][c] (fp32) = scale * sum_m dy[m][co] * act(x)[...]  (+ dw if accumulate)
  * workspace: fp32 [pfr_conv2d_wgrad_splits(M,Cout,R*S*C)][Cout][R*S*C] (may be NULL when splits == 1). */

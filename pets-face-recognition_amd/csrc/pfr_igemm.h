@@ -24,6 +24,7 @@ struct IgemmParams {
                //    to the row's candidate list  (y = cand u64 [M][cap], y2 = thrk u32 [M])
   void* y2;
   int* ccnt;   // act 4: candidate counters [M]
+  int res_sub;                     // streaming join only: `residual` is compact [N][OH/2][OW/2][Cout], added at even (oh, ow)
   const unsigned char* res_mask;   // optional bit mask of `residual` ([M][ldy / KPACK] bytes, pfr_bn_act_mask): masked-out elements add 0
   int cap, col0, self_excl;   // act 4: list capacity, gallery index of column 0, skip column == row (all-vs-all evaluation)
   FastDiv div_ohow, div_ow;

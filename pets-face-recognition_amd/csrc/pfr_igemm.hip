@@ -765,6 +765,10 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
       if (rc != 1) return rc;
     }
   }
+  if (p.res_sub) {   // only the streaming join reads a compact residual: never fall through to a kernel that would read it as full size
+    pfr_set_error("pfr_conv2d_dgrad_bn_sub: geometry not taken by the streaming kernel");
+    return PFR_ERR_UNSUPPORTED;
+  }
   if (!stats_postop && igemm_ws_mode() && igemm_ws_eligible(p, dtype, out_dtype) &&
       (igemm_pclass_ok(p) || pick_ws(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr)))
     return igemm_ws_launch(p, st);
@@ -814,6 +818,7 @@ struct BnbArgs {
   const float* coef[2];
   float* part[2];
   const unsigned char* mask;
+  int res_sub = 0;    // the residual is the compact gradient of a stride-2 projection shortcut (streaming join only)
 };
 static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
                            int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
@@ -885,6 +890,27 @@ extern "C" int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int
                          0, nullptr, nullptr, 0, nullptr, res_mask, stream, &b);
 }
 
+// dx = dgrad(dy) + up2(res_compact) + BN sums: the main-branch data gradient of a block whose projection shortcut is a 1x1 / stride-2
+// conv.  The shortcut's gradient is computed DENSELY on its own (OH/2 x OW/2) grid by a plain pfr_conv2d_fwd into res_compact
+// [N][OH/2][OW/2][Cout] and added here at the pixels with even (oh, ow) — instead of a scattered accumulate pass over dx — and the
+// launch leaves the BatchNorm-backward sums of the BN whose output gradient dx is (bit mask), as pfr_conv2d_dgrad_bn.  Streaming
+// kernels only: pfr_conv2d_dgrad_bn_parts (with pfr_set_tuning("bnb", 2)) > 0 and even OH, OW are required.
+extern "C" int pfr_conv2d_dgrad_bn_sub(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int OH,
+                                       int OW, const void* res_compact, const void* bn_x, const float* bn_coef,
+                                       const unsigned char* bn_mask, float* bn_part, hipStream_t stream) {
+  PFR_CHECK_ARG(dy && wt && dx && res_compact && bn_x && bn_coef && bn_mask && bn_part, "pfr_conv2d_dgrad_bn_sub: null pointer");
+  PFR_CHECK_ARG(sconv_bnb_mode() == 2 && OH == H && OW == W && !(OH & 1) && !(OW & 1) &&
+                    pfr_conv2d_dgrad_bn_parts(dtype, N, H, W, C, Cout, 1, 1, 0, OH, OW) > 0,
+                "pfr_conv2d_dgrad_bn_sub: needs the streaming form (bnb mode 2, an eligible 1x1 geometry, even extents)");
+  BnbArgs b;
+  b.x[0] = bn_x; b.coef[0] = bn_coef; b.part[0] = bn_part;
+  b.x[1] = nullptr; b.coef[1] = nullptr; b.part[1] = nullptr;
+  b.mask = bn_mask;
+  b.res_sub = 1;
+  return conv2d_fwd_impl(dy, wt, dx, dtype, dtype, N, H, W, C, Cout, 1, 1, 1, 0, 0, OH, OW, Cout, nullptr, res_compact, 0, 0, nullptr,
+                         nullptr, 0, nullptr, nullptr, stream, &b);
+}
+
 static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
                            int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW,
                            int ldy, const float* bias, const void* residual, int accumulate, int out_relu,
@@ -906,10 +932,10 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int
   p.Cout = Cout; p.ldy = ldy > 0 ? ldy : Cout;
   p.M = N * OH * OW; p.K = R * S * C;
   p.stats_part = stats_part; p.bias = bias; p.residual = residual; p.accumulate = accumulate; p.out_relu = out_relu;
-  p.act = 0; p.y2 = nullptr; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = res_mask;
+  p.act = 0; p.y2 = nullptr; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = res_mask; p.res_sub = 0;
   p.bnb_mask = nullptr;
   for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
-  if (bnb) { p.bnb_mask = bnb->mask; for (int q = 0; q < 2; ++q) { p.bnb_x[q] = bnb->x[q]; p.bnb_coef[q] = bnb->coef[q]; p.bnb_part[q] = bnb->part[q]; } }
+  if (bnb) { p.res_sub = bnb->res_sub; p.bnb_mask = bnb->mask; for (int q = 0; q < 2; ++q) { p.bnb_x[q] = bnb->x[q]; p.bnb_coef[q] = bnb->coef[q]; p.bnb_part[q] = bnb->part[q]; } }
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
@@ -962,7 +988,7 @@ static int gemm_act_impl(const void* x, const void* w, void* y, int dtype, long 
   p.M = (int)M; p.K = K;
   p.stats_part = stats_part; p.bias = bias; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
   p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
-  p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = nullptr;
+  p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = nullptr; p.res_sub = 0;
   p.bnb_mask = nullptr;
   for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
   p.div_ohow = make_fastdiv(1u);
@@ -1005,7 +1031,7 @@ extern "C" int pfr_match_scores_filter(const void* q, const void* g, int dtype, 
   p.M = Q; p.K = D;
   p.stats_part = nullptr; p.bias = nullptr; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
   p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
-  p.act = 4; p.y2 = t.thrk; p.ccnt = t.ccnt; p.cap = cap; p.col0 = col0; p.self_excl = exclude_self; p.res_mask = nullptr;
+  p.act = 4; p.y2 = t.thrk; p.ccnt = t.ccnt; p.cap = cap; p.col0 = col0; p.self_excl = exclude_self; p.res_mask = nullptr; p.res_sub = 0;
   p.bnb_mask = nullptr;
   for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
   p.div_ohow = make_fastdiv(1u);

@@ -35,6 +35,8 @@ struct SconvParams {
   float* stats_part;      // [nranges][2][N] (mean, M2) or nullptr
   const void* res;        // join: residual-branch gradient [M][N] bf16, or nullptr
   const unsigned char* res_mask;   // join: its ReLU bit mask [M][N/8]
+  int res_sub;            // join: `res` is COMPACT [n][OH/2][OW/2][N] and adds to the pixels with even (oh, ow) only (the data
+                          // gradient of a 1x1 / stride-2 projection shortcut, computed densely on its own grid); others add 0
   const float* bias;      // inference epilogue (EP 2 / 3): per-cout bias of the BN-folded convolution
   int relu;               // inference epilogue: ReLU after bias (+ residual)
   // EP 4 / 5: BatchNorm-backward sums of the BN whose output gradient y is (pfr_conv2d_dgrad_bn): x of that BN [M][N], its
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.xbytes, 0x00020000);
   __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.M * p.N * 2, 0x00020000);
   const uint32_t OOBB = 0xF0000000u;
-  __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0, p.M * p.N * 2, 0x00020000);
+  __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0,
+                                                                   p.res_sub ? (p.M >> 2) * p.N * 2 : p.M * p.N * 2, 0x00020000);
   // (join without a mask = plain add of `res`, e.g. a gradient already accumulated in y itself: the mask-byte load then reads one
   //  dummy byte so that the per-block load count stays a compile-time constant)
   const bool has_rmask = p.res_mask != nullptr;
@@ -285,10 +288,20 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
       for (int g = 0; g < NCG; ++g)
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
+          uint32_t rvo = y_lane + (uint32_t)(g * 128), rso = rbase + (uint32_t)(ps * 8 * p.N * 2);
+          if (JOIN && p.res_sub) {
+            // compact residual: row m = (n, oh, ow) reads compact row (n, oh/2, ow/2) when both are even, else zeros (out of range)
+            const uint32_t m = (uint32_t)(m0 + ps * 8 + e_row);
+            const uint32_t n_img = fdiv(m, p.div_ohow), rem = m - n_img * (uint32_t)(p.OH * p.OW);
+            const uint32_t oh = fdiv(rem, p.div_ow), ow = rem - oh * (uint32_t)p.OW;
+            const uint32_t crow = (n_img * (uint32_t)(p.OH >> 1) + (oh >> 1)) * (uint32_t)(p.OW >> 1) + (ow >> 1);
+            rvo = (((oh | ow) & 1u) || m >= (uint32_t)p.M) ? OOBB : (crow * (uint32_t)p.N + (uint32_t)(n0 + g * 64 + e_ch * 8)) * 2u;
+            rso = 0;
+          }
           // (s_nop: the scalar offsets come straight from the SALU; nothing inside an asm statement is padded by the compiler)
           asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
                        : "=v"(rres[g][ps])
-                       : "v"(y_lane + (uint32_t)(g * 128)), "s"(rrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
+                       : "v"(rvo), "s"(rrsrc), "s"(rso)
                        : "memory");
           if constexpr (JOIN)
             asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen"
@@ -647,6 +660,7 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   const bool join = !infer && p.residual != nullptr;
   // residual only in its data-gradient join form (bit mask), or — with the BN sums — as a plain add (res may be y itself)
   if (join && ((!p.res_mask && !bnb) || p.stats_part)) return 1;
+  if (p.res_sub && (!bnb || p.res_mask || p.ostride != 1 || (p.OH & 1) || (p.OW & 1))) return 1;
   if (p.ostride != 1 && (p.H != p.OH * p.ostride || p.W != p.OW * p.ostride)) return 1;
   if ((long)p.N * p.H * p.W * p.K * 2 >= ((long)1 << 31)) return 1;
   SconvPlan pl;
@@ -657,6 +671,7 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.H = p.H; sp.W = p.W; sp.OH = p.OH; sp.OW = p.OW; sp.ostride = p.ostride;
   sp.stats_part = p.stats_part;
   sp.res = p.residual; sp.res_mask = p.res_mask;
+  sp.res_sub = p.res_sub;
   sp.bias = p.bias; sp.relu = p.out_relu;
   sp.bnx = p.bnb_x[0]; sp.bn_coef = p.bnb_coef[0]; sp.bn_mask = p.bnb_mask; sp.bn_part = p.bnb_part[0];
   sp.bnx2 = p.bnb_x[1]; sp.bn_coef2 = p.bnb_coef[1]; sp.bn_part2 = p.bnb_part[1];

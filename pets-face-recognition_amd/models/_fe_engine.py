@@ -817,7 +817,23 @@ class FEEngine:
                 #  than the accumulate form below costs, for one saved reduce pass)
                 npart2 = dgrad_parts(dyshape, c0, xshape) if (nxt is not None and self.fuse_bnb == 2 and nxt[3] is None
                                                                 and os.environ.get("PFR_BNB_INPLACE") == "1") else 0
-                if npart2 > 0:
+                npart3 = 0
+                if (npart2 == 0 and nxt is not None and self.fuse_bnb == 2 and nxt[3] is None and dc.R == 1 and dc.stride == 2
+                        and xshape[1] % 2 == 0 and xshape[2] % 2 == 0 and os.environ.get("PFR_BNB_SUB", "1") != "0"):
+                    npart3 = dgrad_parts(dyshape, c0, xshape)
+                if npart3 > 0:
+                    # the shortcut's gradient densely on its own grid (a plain GEMM), then the main branch's streaming join adds it at
+                    # the even pixels and leaves the previous block's BN-backward sums: no scattered accumulate pass over dxin
+                    comp = G((xshape[0], oshape[1], oshape[2], xshape[3]))
+                    self._conv_fwd(ops, dgd, oshape, dc.wt, comp, dc, 1, 0, oshape[1], oshape[2], idil=0, Cout=dc.Cin)
+                    part = G((npart3, 2, xshape[3]), torch.float32)
+                    ops.append((lib.pfr_conv2d_dgrad_bn_sub, (dy.data_ptr(), c0.wt.data_ptr(), dxin.data_ptr(), self.did, dyshape[0], dyshape[1],
+                                                              dyshape[2], dyshape[3], c0.Cin, xshape[1], xshape[2], comp.data_ptr(),
+                                                              nxt[0].data_ptr(), nxt[1].coef.data_ptr(), nxt[2].data_ptr(), part.data_ptr())))
+                    pre3[k - 1] = ((part, npart3), None)
+                    release(comp)
+                    npart = -1
+                elif npart2 > 0:
                     # streaming form: the projection shortcut writes dxin first (all of it: zeros where its stride skips), then the
                     # main branch adds to it IN PLACE (res = dx, no mask) and leaves the previous block's BN-backward sums
                     dgrad(dgd, oshape, dc, dxin, xshape)

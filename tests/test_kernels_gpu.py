@@ -751,6 +751,7 @@ def test_halo_staged_3x3_inference_epilogue(case):
     (2, 56, 256, 64, False), (3, 28, 512, 128, False), (2, 56, 64, 256, True), (3, 28, 128, 512, True), (5, 14, 256, 1024, True),
     (1, 9, 64, 64, False), (4, 23, 128, 256, True), (2, 56, 64, 256, "two"), (5, 14, 256, 1024, "two"), (3, 11, 128, 512, "two"),
     (2, 56, 128, 256, "inplace"), (3, 28, 256, 512, "inplace"), (5, 14, 512, 1024, "inplace"),
+    (2, 56, 128, 256, "sub"), (3, 28, 256, 512, "sub"), (5, 14, 512, 1024, "sub"), (3, 10, 64, 64, "sub"),
 ])
 def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
     """pfr_conv2d_dgrad_bn in streaming mode (pfr_set_tuning("bnb", 2)): dx must be BIT-identical to the plain data gradient / join,
@@ -760,6 +761,7 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
     N, H, C, Co, join = case
     two = join == "two"      # + the projection-shortcut BN of the previous block: same gradient, same bit mask, its own input
     inplace = join == "inplace"   # res = dx itself, no residual mask: the main branch adds to what the projection shortcut left there
+    sub = join == "sub"           # res = the COMPACT gradient of a stride-2 projection shortcut, added at even (oh, ow) (pfr_conv2d_dgrad_bn_sub)
     join = bool(join)
     g = torch.Generator().manual_seed(H * C + Co + 11)
     M = N * H * H
@@ -770,7 +772,8 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
                         torch.randn(Co, generator=g) * 0.3]).to(DEV).contiguous()     # mean, invstd, scale, shift
     gamma = (torch.rand(Co, generator=g) + 0.5).to(DEV)
     res = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16() if join else None
-    rmask = torch.randint(0, 256, (M, Co // 8), generator=g, dtype=torch.uint8).to(DEV) if (join and not inplace) else None
+    rmask = torch.randint(0, 256, (M, Co // 8), generator=g, dtype=torch.uint8).to(DEV) if (join and not inplace and not sub) else None
+    comp = torch.randn(N, H // 2, H // 2, Co, generator=g).to(DEV).bfloat16() if sub else None
     bmask = torch.randint(0, 256, (M, Co // 8), generator=g, dtype=torch.uint8).to(DEV) if join else None
     st = torch.cuda.current_stream().cuda_stream
     P = lambda t: 0 if t is None else t.data_ptr()
@@ -778,7 +781,12 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
         lib.pfr_set_tuning(b"sconv", 2)
         # reference: plain gradient (streaming kernel, already proven bit-identical to the tile kernel) + separate reduce
         dx0 = torch.full((N, H, H, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
-        if inplace:
+        if sub:
+            lib.pfr_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx0.data_ptr(), 1, 1, N, H, H, C, Co, 1, 1, 1, 0, 0, H, H, Co, 0, 0, 0, 0, 0, 0, 0, 0, st)
+            up = torch.zeros(N, H, H, Co, device=DEV)
+            up[:, 0::2, 0::2] = comp.float()
+            dx0 = (dx0.float() + up).bfloat16()
+        elif inplace:
             dx0.copy_(res)
             lib.pfr_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx0.data_ptr(), 1, 1, N, H, H, C, Co, 1, 1, 1, 0, 0, H, H, Co, 0, 0, 1, 0, 0, 0, 0, 0, st)
         elif join:
@@ -809,6 +817,10 @@ def test_streaming_1x1_dgrad_with_bn_backward_sums(case):
         part12 = torch.full((np_, 2, Co), float("nan"), device=DEV) if two else None
         dx1 = torch.full((N, H, H, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
         for _ in range(2):
+            if sub:
+                lib.pfr_conv2d_dgrad_bn_sub(dy.data_ptr(), wt.data_ptr(), dx1.data_ptr(), 1, N, H, H, C, Co, H, H, comp.data_ptr(),
+                                            bnx.data_ptr(), coef.data_ptr(), bmask.data_ptr(), part1.data_ptr(), st)
+                continue
             if inplace:
                 dx1.copy_(res)
             lib.pfr_conv2d_dgrad_bn(dy.data_ptr(), wt.data_ptr(), dx1.data_ptr(), 1, N, H, H, C, Co, 1, 1, 0, 0, H, H,
