@@ -647,7 +647,10 @@ static int sconv_launch_ns(SconvParams& sp, const SconvPlan& pl, hipStream_t st)
 // takes the launch when it is a plain 1x1 convolution of an eligible geometry; returns 1 when it is not
 int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (p.R != 1 || p.S != 1 || p.pad != 0 || p.idil_log2 != 0 || p.ldy != p.Cout) return 1;
-  if (p.accumulate || p.pro_scale || p.act) return 1;
+  if (p.pro_scale || p.act) return 1;
+  // y += conv: the join with res = y itself and no mask (each wave reads its rows of y at the block start and writes them in its epilogue)
+  const bool acc_inplace = p.accumulate && !p.residual && !p.bias && !p.stats_part && !p.out_relu && !p.bnb_part[0] && !p.res_sub;
+  if (p.accumulate && !acc_inplace) return 1;
   // BatchNorm-backward sums in the epilogue (pfr_conv2d_dgrad_bn): one BN, no statistics / bias; with the join its bit mask is required
   const bool bnb = p.bnb_part[0] != nullptr;
   if (bnb && (sconv_bnb_mode() != 2 || p.bias || p.stats_part || p.out_relu || (p.residual && !p.bnb_mask) ||
@@ -657,9 +660,9 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   const bool infer = p.bias != nullptr;
   if (infer && (p.stats_part || p.res_mask)) return 1;
   if (!infer && p.out_relu) return 1;
-  const bool join = !infer && p.residual != nullptr;
-  // residual only in its data-gradient join form (bit mask), or — with the BN sums — as a plain add (res may be y itself)
-  if (join && ((!p.res_mask && !bnb) || p.stats_part)) return 1;
+  const bool join = !infer && (p.residual != nullptr || acc_inplace);
+  // residual only in its data-gradient join form (bit mask), or — with the BN sums / as the accumulate form — as a plain add
+  if (join && ((!p.res_mask && !bnb && !acc_inplace) || p.stats_part)) return 1;
   if (p.res_sub && (!bnb || p.res_mask || p.ostride != 1 || (p.OH & 1) || (p.OW & 1))) return 1;
   if (p.ostride != 1 && (p.H != p.OH * p.ostride || p.W != p.OW * p.ostride)) return 1;
   if ((long)p.N * p.H * p.W * p.K * 2 >= ((long)1 << 31)) return 1;
@@ -670,7 +673,7 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.M = p.M; sp.K = p.K; sp.N = p.Cout;
   sp.H = p.H; sp.W = p.W; sp.OH = p.OH; sp.OW = p.OW; sp.ostride = p.ostride;
   sp.stats_part = p.stats_part;
-  sp.res = p.residual; sp.res_mask = p.res_mask;
+  sp.res = acc_inplace ? p.y : p.residual; sp.res_mask = p.res_mask;
   sp.res_sub = p.res_sub;
   sp.bias = p.bias; sp.relu = p.out_relu;
   sp.bnx = p.bnb_x[0]; sp.bn_coef = p.bnb_coef[0]; sp.bn_mask = p.bnb_mask; sp.bn_part = p.bnb_part[0];

@@ -877,3 +877,28 @@ def test_streaming_1x1_weight_gradient(case):
     assert (outs[0] - ref).abs().max() <= 2e-5 * scale + 1e-3
     assert (outs[1] - ref).abs().max() <= 2e-5 * scale + 1e-3
     assert torch.equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize("case", [(2, 56, 256, 64), (3, 28, 128, 512), (1, 9, 64, 64), (4, 14, 256, 1024)])
+def test_streaming_1x1_accumulate_bit_identical(case):
+    """y += conv through the streaming kernel (the join with res = y itself, no mask) vs the tile kernel's accumulate epilogue"""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, C, Co = case
+    g = torch.Generator().manual_seed(H * C + Co + 17)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(Co, 1, 1, C, generator=g) / C ** 0.5).to(DEV).bfloat16()
+    y0 = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16()
+    outs = []
+    try:
+        for mode in (0, 2):
+            lib.pfr_set_tuning(b"sconv", mode)
+            y = y0.clone()
+            o.conv2d_fwd(x, w, stride=1, pad=0, out=y, accumulate=True)
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+    assert torch.equal(outs[0], outs[1])
+    ref = (x.float().reshape(-1, C) @ w.float().reshape(Co, C).t()).bfloat16().float().reshape(N, H, H, Co) + y0.float()
+    assert (outs[1].float() - ref).abs().max() <= 2e-2 * ref.abs().max()
