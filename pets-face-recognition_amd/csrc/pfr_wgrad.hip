@@ -429,6 +429,9 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(WgradParams p) {
 //     num_records on the scalar ALU, so row tails are zero-filled by the bounds check with no vector compare;
 //   * gathered x (3x3 / strided): (n, oh, ow) is decoded once and then ADVANCED by 32 rows per stage with carries;
 //   * ring of 4 stages of 32 rows, counted vmcnt; reads are inline asm (a compiler-visible LDS read drains the DMAs in flight).
+#ifndef PFR_WGRAD_NST
+#define PFR_WGRAD_NST 4   // LDS ring depth of wgrad3_kernel (3: 48 KB per 128x128 workgroup, three workgroups per CU)
+#endif
 __device__ __forceinline__ u32x2 lds_read_tr16(uint32_t addr, int imm) {
   u32x2 v;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm) : "memory");
@@ -442,7 +445,7 @@ template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_
 template <int BP, int BQ, int NW = 4, int WGQ = 2>
 __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(WgradParams p) {
   using T = bf16_t;
-  constexpr int KP = 8, BMR = 32, NST = 4;
+  constexpr int KP = 8, BMR = 32, NST = PFR_WGRAD_NST;
   constexpr int WGP = NW / WGQ;
   constexpr int TP = BP / (WGP * 32), TQ = BQ / (WGQ * 32);
   constexpr int RSP = BP * 2, RSQ = BQ * 2;
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(WgradParams p) {
     stage(std::integral_constant<int, 0>{}, kt0);
     if (kt0 + 1 < nk) stage(std::integral_constant<int, 1>{}, kt0 + 1);
     if (kt0 + 2 < nk) stage(std::integral_constant<int, 2>{}, kt0 + 2);
-    if (kt0 + 3 < nk) stage(std::integral_constant<int, 3>{}, kt0 + 3);
+    if constexpr (NST > 3) { if (kt0 + 3 < nk) stage(std::integral_constant<int, 3>{}, kt0 + 3); }
   }
 
   float* out = p.dw + (size_t)split * p.Cout * p.KK;
@@ -940,7 +943,7 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
   if (p.pro_scale)
     hipLaunchKernelGGL((wgrad_kernel<T, BP, BQ, true>), grid, dim3(256), 0, st, p);
   else if (p.v2 && sizeof(T) == 2 && wgrad_v3()) {
-    constexpr int lds = 4 * 32 * (BP + BQ) * 2;   // ring of 4 stages of 32 rows
+    constexpr int lds = PFR_WGRAD_NST * 32 * (BP + BQ) * 2;   // ring of NST stages of 32 rows
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)wgrad3_kernel<BP, BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
     hipLaunchKernelGGL((wgrad3_kernel<BP, BQ>), grid, dim3(256), lds, st, p);
@@ -1053,7 +1056,7 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   } else if (dtype == PFR_BF16 && p.v2 && wgrad_v3() && wgrad_big_geom(p.M, Cout, p.KK)) {
     p.tilesP = (p.Cout + 255) / 256;
     p.tilesQ = (p.KK + 255) / 256;
-    constexpr int lds = 4 * 32 * (256 + 256) * 2;
+    constexpr int lds = PFR_WGRAD_NST * 32 * (256 + 256) * 2;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)wgrad3_kernel<256, 256, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
     hipLaunchKernelGGL((wgrad3_kernel<256, 256, 8, 2>), dim3((unsigned)(p.tilesP * p.tilesQ * p.splits)), dim3(512), lds, stream, p);
