@@ -178,6 +178,7 @@ class FEEngine:
         # Measured (profiles/r03_bnb_streaming.txt): 19.64 -> 19.35 ms/step; default.  0 = separate pass everywhere.
         self.fuse_bnb = int(os.environ.get("PFR_FUSE_BNB", "2") or 0)
         lib.pfr_set_tuning(b"bnb", self.fuse_bnb)
+        self._bnb_min_rows = int(os.environ.get("PFR_BNB_MIN_ROWS", "0"))   # experiment: keep the separate pass for small tensors
         # Opt-in (PFR_FUSE_FIN=1): BatchNorm backward reduce + finalize in one launch (the last workgroups to arrive merge the
         # partial rows, pfr_bn_bwd_reduce_finalize) — 53 dependent 7 us launches fewer per ResNet-50 step, but MEASURED SLOWER
         # (profiles/r03_finalize_fusion.txt): with release fences 26.1 vs 19.5 ms/step (every fence is an L2 write-back scan), with
@@ -731,6 +732,8 @@ class FEEngine:
 
         def dgrad_parts(dyshape, c, dxshape, two_bns=False, accumulates=False):
             if not self.fuse_bnb or (self.fuse_bnb == 2 and (two_bns or accumulates)):
+                return 0
+            if self.fuse_bnb == 2 and dxshape[0] * dxshape[1] * dxshape[2] < self._bnb_min_rows:
                 return 0
             return lib.pfr_conv2d_dgrad_bn_parts(self.did, dyshape[0], dyshape[1], dyshape[2], dyshape[3], c.Cin, c.R, c.S,
                                                  {1: 0, 2: 1}[c.stride], dxshape[1], dxshape[2])
