@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — FE train images/sec on MI355X (BASELINE.json metric), one process per GPU.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus 1 --steps 100 --warmup 20      (the defaults: SURVEY 8d's 20 warm-up + 100 timed steps)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = forward + backward + optimizer (+ gradient all-reduce when N > 1) of ResNet-50 → ArcFace(10 000 ids) on a
@@ -154,6 +154,49 @@ def cpu_thread_sweep(args):
             "sample": f"{args.arch}+ArcFace(C={args.classes}) train steps at bs={B}, PyTorch-CPU fp32 oracle restatement (torchvision "
                       f"absent): thread sweep with 1 warm-up + 1 timed step per count, then 2 warm-up + 5 timed steps at the best "
                       f"({best} threads of {ncpu})"}
+
+
+def cpu_extra_legs(args):
+    """BASELINE.md §3's remaining CPU legs, bounded: (2) ResNet-50 + ArcFace at bs = 256 (1 warm-up + 2 timed steps) and
+    (4) Swin-T + ArcFace at bs = 16 (2 warm-up + 5 timed steps), PyTorch-CPU fp32 on the host cores."""
+    from oracle import resnet_ref, arcface_ref
+    out = {}
+    nt = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(nt)
+    g = torch.Generator().manual_seed(123)
+
+    def leg(fwd, params, B, warm, timed, what):
+        w = (torch.randn(args.classes, 512, generator=g) * 0.02).requires_grad_(True)
+        x = torch.rand(B, 3, 224, 224, generator=g)
+        y = torch.randint(0, args.classes, (B,), generator=g)
+        opt = torch.optim.SGD(list(params) + [w], 0.01, momentum=0.9)
+
+        def step():
+            opt.zero_grad()
+            arcface_ref.focal_loss(arcface_ref.arc_margin_logits(fwd(x), w, y, 64.0, 0.5), y).backward()
+            opt.step()
+        for _ in range(warm):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            step()
+        dt = time.perf_counter() - t0
+        return {"value": round(B * timed / dt, 2), "unit": "images/sec", "cores": nt, "kind": "port",
+                "sample": f"{what} + ArcFace(C={args.classes}) train steps at bs={B}, PyTorch-CPU fp32, {warm} warm-up + {timed} timed, {nt} threads"}
+
+    sd = resnet_ref.init_state_dict("resnet50", 512, seed=0)
+    names = resnet_ref.param_names(sd)
+    ps = {k: (v.requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    out["resnet50_bs256"] = leg(lambda x: resnet_ref.forward(ps, x, "resnet50", train=True), [ps[k] for k in names], 256, 1, 2,
+                                "resnet50 (oracle restatement; torchvision absent)")
+    del sd, ps
+    # Swin-T: the package's models/swin.py on CPU tensors is the plain torch.nn restatement whose embeddings equal the reference's
+    # (tests/golden/swin_t.npz); no HIP code runs on this leg
+    import pets_face_recognition_amd.models as M
+    torch.manual_seed(0)
+    sw = M.swin_t(num_classes=512).train()
+    out["swin_t_bs16"] = leg(sw, [p for p in sw.parameters() if p.requires_grad], 16, 2, 5, "swin_t (models/swin.py on CPU tensors = torch.nn restatement pinned to the reference's embeddings)")
+    return out
 
 
 def extras(args, device):
@@ -354,8 +397,8 @@ def augment_extra(device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--classes", type=int, default=10000)
@@ -506,14 +549,14 @@ def main():
         conv_ms_all = sum(v[1] for k, v in summ.items() if k in CONV_FAMILY) / nprof
         total_ms = sum(v[1] for v in summ.values()) / nprof
         flops = conv_flops_per_img(args.arch) * args.batch
-        # The roofline fraction is quoted for launches that do ONLY convolution work.  pfr_conv2d_dgrad_bn launches (data gradient +
-        # the BatchNorm-backward reduction in the epilogue, round 3) are a different, HBM-bound kernel whose time contains what the
-        # separate pfr_bn_bwd_reduce pass used to do: their time AND their FLOPs are taken out of this ratio and reported next to it.
+        # roofline.frac = ALL conv / linear FLOPs of the step / the time of ALL conv-family launches / peak.  The data-gradient
+        # launches that also do the BatchNorm-backward reduction in their epilogue (pfr_conv2d_dgrad_bn[_sub]) are conv launches: their
+        # FLOPs and their time both count.  The ratio without them is kept under its own key (`frac_excl_bn_sum_launches`).
         fused_ms = sum(summ[k][1] for k in ("pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub") if k in summ) / nprof
         fused_flops = sum(v[0] / nprof * v[2] for k, v in det.items() if k.startswith("dgrad_bn"))
-        conv_ms = conv_ms_all - fused_ms
-        ach = (flops - fused_flops) / (conv_ms * 1e-3) / 1e12
-        ach_all = flops / (conv_ms_all * 1e-3) / 1e12
+        conv_ms = conv_ms_all
+        ach = flops / (conv_ms_all * 1e-3) / 1e12
+        ach_excl = (flops - fused_flops) / ((conv_ms_all - fused_ms) * 1e-3) / 1e12 if conv_ms_all > fused_ms else None
         peak = PEAK_TFLOPS[args.dtype]
         traffic = None
         traffic_stale = None
@@ -531,12 +574,14 @@ def main():
                 with open(fn, "rb") as f:
                     h.update(f.read())
             traffic_stale = tj.get("csrc_sha256") != h.hexdigest()   # counters collected with other kernel sources
-        roof = {"bound": "mfma", "kernel": "conv/linear launches of a step that do only convolution work: igemm_kernel (tiles), sconv_kernel / sconv3_kernel (weight-stationary streaming 1x1 / halo-staged 3x3), wgrad3_kernel / swgrad_kernel; the data-gradient launches that also do the BatchNorm-backward reduction (pfr_conv2d_dgrad_bn) are listed separately",
+        roof = {"bound": "mfma", "kernel": "all conv / linear launches of a step (forward, data gradient, weight gradient): igemm_kernel (tiles), sconv_kernel / sconv3_kernel (weight-stationary streaming 1x1 / halo-staged 3x3, incl. the data-gradient launches whose epilogue also does the BatchNorm-backward sums), wgrad3_kernel / swgrad_kernel",
+                "definition": "conv_flops_per_step / conv_ms_per_step / peak (SURVEY 8d); conv_ms_per_step = HIP-event time of every launch of the CONV_FAMILY entry points",
                 "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes per step of the same launches (PMC), algorithmic minimum = activations+weights once",
                 "traffic_stale": traffic_stale,
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(total_ms, 3),
-                "frac_incl_bn_sum_launches": round(ach_all / peak, 4), "conv_ms_incl_bn_sum_launches": round(conv_ms_all, 3),
+                "conv_tflop_per_step": round(flops / 1e12, 4),
+                "frac_excl_bn_sum_launches": round(ach_excl / peak, 4) if ach_excl else None,
                 "bn_sum_launch_tflop_per_step": round(fused_flops / 1e12, 4),
                 # the launches that ALSO do the BatchNorm-backward reduction in their epilogue (pfr_conv2d_dgrad_bn) and what is left
                 # of the separate pfr_bn_bwd_reduce pass
@@ -559,6 +604,11 @@ def main():
         extra = extras(args, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_thread_sweep(args)
+        if cpu is not None and args.arch == "resnet50" and not args.no_extras:
+            try:
+                cpu["other_legs"] = cpu_extra_legs(args)   # bs = 256 ResNet-50 and Swin-T bs = 16 on the host cores
+            except Exception as e:   # noqa: BLE001
+                cpu["other_legs"] = {"error": repr(e)[:300]}
 
     if rank == 0:
         line = {"metric": f"FE train images/sec @224^2 bs={args.batch}/GPU", "value": round(value, 1), "unit": "images/sec",

@@ -53,8 +53,94 @@ def ref_similarity_f():
     return ns["similarity_f"]
 
 
-def ref_controller():
-    """engine/controller.py with stand-ins for the two missing third-party packages (test-side stubs only)."""
+def _tm_binary_clf_curve(preds, target):
+    """torchmetrics.functional.classification.precision_recall_curve._binary_clf_curve (0.7 - 0.11, the releases contemporary with
+    the reference's pytorch-lightning==1.5.9 pin; torchmetrics itself is unpinned and not installable here), restated from its
+    published algorithm: descending sort, one operating point per run of equal scores, integer cumulative counts."""
+    order = torch.argsort(preds, descending=True)
+    preds, target = preds[order], target[order]
+    distinct = torch.where(preds[1:] - preds[:-1])[0]
+    idx = torch.nn.functional.pad(distinct, [0, 1], value=target.size(0) - 1)
+    target = (target == 1).to(torch.long)
+    tps = torch.cumsum(target, dim=0)[idx]
+    fps = 1 + idx - tps
+    return fps, tps, preds[idx]
+
+
+def torchmetrics_standins():
+    """The eight torchmetrics classes engine/controller.py:12 imports, as test-side stand-ins that follow torchmetrics' published
+    binary-input semantics (float scores in [0, 1] against 0/1 targets, `preds >= threshold`, float32 curves).  Each one is
+    cross-checked against scikit-learn by gen_evaluate()."""
+    class ROC:
+        def __call__(self, s, l):
+            fps, tps, thr = _tm_binary_clf_curve(s, l)
+            tps = torch.cat([torch.zeros(1, dtype=tps.dtype), tps])
+            fps = torch.cat([torch.zeros(1, dtype=fps.dtype), fps])
+            thr = torch.cat([thr[0][None] + 1, thr])
+            return fps / fps[-1], tps / tps[-1], thr
+
+    class AUROC:
+        def __call__(self, s, l):
+            fpr, tpr, _ = ROC()(s, l)
+            return torch.trapz(tpr, fpr)
+
+    class AveragePrecision:
+        def __call__(self, s, l):
+            fps, tps, _ = _tm_binary_clf_curve(s, l)
+            precision = tps / (tps + fps)
+            recall = tps / tps[-1]
+            last = int(torch.where(tps == tps[-1])[0][0])
+            precision = torch.cat([precision[:last + 1].flip(0), torch.ones(1)])
+            recall = torch.cat([recall[:last + 1].flip(0), torch.zeros(1)])
+            return -torch.sum((recall[1:] - recall[:-1]) * precision[:-1])
+
+    def stat(s, l, thr):
+        pred = (s >= thr).int()
+        tp = ((pred == 1) & (l == 1)).sum()
+        fp = ((pred == 1) & (l == 0)).sum()
+        tn = ((pred == 0) & (l == 0)).sum()
+        fn = ((pred == 0) & (l == 1)).sum()
+        return tp, fp, tn, fn
+
+    class _Thr:
+        def __init__(self, *a, threshold=0.5, **k):
+            self.threshold = threshold
+
+    class StatScores(_Thr):
+        def __call__(self, s, l):
+            tp, fp, tn, fn = stat(s, l, self.threshold)
+            return torch.stack([tp, fp, tn, fn, tp + fn])
+
+    class Accuracy(_Thr):
+        def __call__(self, s, l):
+            tp, fp, tn, fn = stat(s, l, self.threshold)
+            return (tp + tn) / (tp + tn + fp + fn)
+
+    class Precision(_Thr):
+        def __call__(self, s, l):
+            tp, fp, tn, fn = stat(s, l, self.threshold)
+            return tp / (tp + fp) if int(tp + fp) else torch.tensor(0.0)     # zero_division = 0
+
+    class Recall(_Thr):
+        def __call__(self, s, l):
+            tp, fp, tn, fn = stat(s, l, self.threshold)
+            return tp / (tp + fn) if int(tp + fn) else torch.tensor(0.0)
+
+    class ConfusionMatrix(_Thr):
+        def __init__(self, num_classes, threshold=0.5):
+            super().__init__(threshold=threshold)
+
+        def __call__(self, s, l):
+            tp, fp, tn, fn = stat(s, l, self.threshold)
+            return torch.stack([torch.stack([tn, fp]), torch.stack([fn, tp])])     # [target][prediction]
+
+    return dict(ROC=ROC, AUROC=AUROC, AveragePrecision=AveragePrecision, StatScores=StatScores, Accuracy=Accuracy,
+                Precision=Precision, Recall=Recall, ConfusionMatrix=ConfusionMatrix)
+
+
+def ref_controller(full=False):
+    """engine/controller.py with stand-ins for the two missing third-party packages (test-side stubs only).  full=True: all
+    eight torchmetrics classes (what Controller._evaluate needs), else the AUROC / ROC pair test_epoch_end needs."""
     from sklearn.metrics import roc_auc_score, roc_curve
 
     pl = types.ModuleType("pytorch_lightning")
@@ -79,6 +165,9 @@ def ref_controller():
     tm.AUROC, tm.ROC = AUROC, ROC
     for n in ("AveragePrecision", "Recall", "Precision", "StatScores", "Accuracy", "ConfusionMatrix"):
         setattr(tm, n, object)
+    if full:
+        for n, c in torchmetrics_standins().items():
+            setattr(tm, n, c)
     sys.modules.update({"pytorch_lightning": pl, "pytorch_lightning.loggers": lg, "pytorch_lightning.utilities": ut,
                         "pytorch_lightning.utilities.types": ty, "torchmetrics": tm})
     return load_ref_module("ref_controller", "engine/controller.py")
@@ -180,6 +269,84 @@ def gen_recall(ctrl_mod, sim_f):
         out[f"{name}_pair_scores"] = sc.numpy()
         print(f"recall {name}: ref R@10={vals['Recall@K=10']:.4f} R@100={vals['Recall@K=100']:.4f} counts={ours}")
     np.savez_compressed(os.path.join(OUT, "recall.npz"), **out)
+
+
+def gen_evaluate(sim_f):
+    """The reference's own Controller._evaluate (engine/controller.py:95-203) run on the three seeded sets of recall.npz (same
+    embeddings, classes and pairs) with config.k = [5, 10, 100], two thrs, far_thr / frr_thr lists incl. values whose index
+    rule lands on int(...) == 0 — the printed metrics dict is the golden, key for key."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    import tempfile
+    from sklearn.metrics import roc_auc_score, average_precision_score
+    plt.pause = lambda *_a, **_k: None
+    ctrl_mod = ref_controller(full=True)
+    rec = np.load(os.path.join(OUT, "recall.npz"))
+    out = {}
+    thrs = np.array([0.5, 0.598])          # config.thrs is a numpy array in the reference's configs (fe_dogs_config.py:71)
+    far = [0.1, 0.05, 0.01, 0.001]
+    frr = [0.1, 0.03, 0.001]
+    ks = [5, 10, 100]
+    # "edge": impostor pairs of identical rows (score exactly 1) and genuine pairs of opposite rows (score exactly 0), so that
+    # the far / frr index rule lands on thr in (0, 1) and the reference SKIPS those keys (controller.py:170,177)
+    g = torch.Generator().manual_seed(77)
+    e_emb = torch.randn(64, 512, generator=g)
+    e_cls = torch.arange(64) // 8
+    e_emb[8] = e_emb[0]; e_emb[16] = e_emb[0]; e_emb[24] = e_emb[0]          # different identities, same vector
+    e_emb[2] = -e_emb[1]; e_emb[4] = -e_emb[3]                                # same identity, opposite vectors
+    e_pairs = [(0, 8), (0, 16), (8, 16), (0, 24), (8, 24), (16, 24), (1, 2), (3, 4), (2, 1)] + \
+              [(int(a), int(b)) for a, b in torch.randint(0, 64, (111, 2), generator=g).tolist()]
+    e_lab = [int(e_cls[a] == e_cls[b]) for a, b in e_pairs]
+    out["edge_emb"] = e_emb.numpy(); out["edge_classes"] = e_cls.numpy()
+    out["edge_pairs"] = np.array(e_pairs); out["edge_plabels"] = np.array(e_lab)
+    for name in ("n256", "n400", "ties", "edge"):
+        src = out if name == "edge" else rec
+        emb = torch.from_numpy(src[f"{name}_emb"])
+        classes = torch.from_numpy(src[f"{name}_classes"])
+        pairs = [(int(a), int(b)) for a, b in src[f"{name}_pairs"]]
+        plabels = [int(v) for v in src[f"{name}_plabels"]]
+        N = emb.shape[0]
+        idx = torch.randperm(N, generator=torch.Generator().manual_seed(5 + N))
+
+        class PG:
+            corrected_indices = pairs
+            labels = plabels
+
+        with tempfile.TemporaryDirectory() as td:
+            class Cfg(dict):
+                def pair_generator(self, i):
+                    return "Val", PG
+
+                similarity_f = staticmethod(sim_f)
+
+            cfg = Cfg(far_thr=far, frr_thr=frr, img_dir=td)
+            cfg.thrs, cfg.k = thrs, ks
+            c = ctrl_mod.Controller.__new__(ctrl_mod.Controller)
+            torch.nn.Module.__init__(c)
+            c.config = cfg
+            c.current_epoch = 0
+            c.logger = None
+            emb_s, cls_s = emb[idx], classes[idx]
+            batches = [{"emb": emb_s[i:i + 20], "label": cls_s[i:i + 20], "index": idx[i:i + 20]} for i in range(0, N, 20)]
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                c._evaluate([batches])
+        vals = {k: float(v) for k, v in re.findall(r"^Val ([^\t\n]+)\t([0-9.eE+-]+|nan|inf)$", buf.getvalue(), flags=re.M)}
+        cm = re.search(r"Conf Mat thr = [^ ]+ tensor\(\[\[ *(\d+), *(\d+)\],\s*\[ *(\d+), *(\d+)\]\]\)", buf.getvalue())
+        sc = sim_f([(emb[a], emb[b]) for a, b in pairs])
+        lab = np.array(plabels)
+        # the stand-ins against scikit-learn (an independent implementation of the same definitions)
+        assert abs(vals["ROC AUC"] - roc_auc_score(lab, sc.numpy())) < 1e-6, name
+        assert abs(vals["AveragePrecision"] - average_precision_score(lab, sc.numpy())) < 1e-6, name
+        keys = list(vals.keys())
+        out[f"{name}_keys"] = np.array(keys)
+        out[f"{name}_values"] = np.array([vals[k] for k in keys], dtype=np.float64)
+        out[f"{name}_confmat"] = np.array([int(v) for v in cm.groups()]).reshape(2, 2)
+        out[f"{name}_pair_scores"] = sc.numpy()
+        print(f"evaluate {name}:", {k: round(v, 5) for k, v in vals.items()})
+    out["thrs"] = thrs; out["far_thr"] = np.array(far); out["frr_thr"] = np.array(frr); out["k"] = np.array(ks)
+    np.savez_compressed(os.path.join(OUT, "evaluate.npz"), **out)
 
 
 def gen_pairs():
@@ -444,12 +611,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "calc_scores":
         gen_calc_scores()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "evaluate":
+        gen_evaluate(ref_similarity_f())
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "arcface":
         gen_arcface(ref_losses())
         sys.exit(0)
     L = ref_losses()
     gen_arcface(L)
     gen_recall(ref_controller(), ref_similarity_f())
+    gen_evaluate(ref_similarity_f())
     gen_pairs()
     gen_calc_scores()
     gen_augment()

@@ -8,7 +8,8 @@
   _evaluate, compute_accuracy, *_dataloader, configure_optimizers                                   (95-246)
 
 The O(N²) python pair loop of the reference (77-90, 143-160: ≈ 8.4 µs per scored pair) is replaced by the match module
-(one MFMA GEMM per gallery chunk + running top-K); metric NAMES are kept ('ROC AUC', 'Accuracy', 'Recall@K=10', …).
+(one MFMA GEMM per gallery chunk + running top-K); the metrics dict has the reference's keys and threshold rules (pinned to the
+reference's own `_evaluate` run, tests/golden/evaluate.npz).
 Unlike the reference (39: `self.logger.run_id` unconditionally), a missing logger is fine."""
 import json
 import time
@@ -101,9 +102,8 @@ class Controller(nn.Module):
             emb, classes = self._gather(outputs[i])
             name, pair_generator = self.config.pair_generator(i)
             scores, labels = self._pair_scores(emb, pair_generator)
-            fpr, tpr, thr = M.roc_curve(scores, labels)
-            acc, _ = M.best_threshold_accuracy(scores, labels, thr, fpr, 1 - tpr)
-            metrics = {'ROC AUC': M.auroc(scores, labels), 'Accuracy': acc}
+            ps = M.PairStats(scores, labels)
+            metrics = {'ROC AUC': ps.auroc(), 'Accuracy': ps.best_threshold_accuracy()[0]}
             rk = self._recall(emb, classes, [10, 100])
             metrics.update({f'Recall@K={k}': (x / y if y else float('nan')) for k, (x, y) in rk.items()})
             print('', *[f'{name} {k}\t{v}' for k, v in metrics.items()], sep='\n')
@@ -118,33 +118,47 @@ class Controller(nn.Module):
         return m
 
     def _evaluate(self, outputs):
+        """The metrics dict of the reference's `_evaluate` (controller.py:95-183): the same keys in the same order
+        ('ROC AUC', 'AveragePrecision', 'Accuracy', 'Opt thr', f'Accuracy thr={thr}' / 'Precision thr=…' / 'Recall thr=…' over
+        config.thrs, f'Recall@K={k}' over config.k, f'TAR@FAR={far}' + f'TH@FAR={far}', f'TRR@FRR={frr}' + f'TH@FRR={frr}') and the
+        same threshold rules (engine/metrics.py) — pinned key for key to the reference's own run, tests/golden/evaluate.npz."""
         cfg = self.config
         all_metrics = {}
+        self.last_confmat = {}
         rocs = []
         for i in range(len(outputs)):
             emb, classes = self._gather(outputs[i])
             name, pair_generator = cfg.pair_generator(i)
             scores, labels = self._pair_scores(emb, pair_generator)
-            fpr, tpr, thr = M.roc_curve(scores, labels)
-            acc, opt_thr = M.best_threshold_accuracy(scores, labels, thr, fpr, 1 - tpr)
-            metrics = {'ROC AUC': M.auroc(scores, labels), 'Accuracy': acc, 'AP': M.average_precision(scores, labels)}
-            cm = M.stats_at_threshold(scores, labels, opt_thr)
-            metrics.update({'Optimal threshold': opt_thr, 'TP': cm['tp'], 'FP': cm['fp'], 'TN': cm['tn'], 'FN': cm['fn']})
-            for t in cfg.get('thrs', []):
-                st = M.stats_at_threshold(scores, labels, float(t))
-                metrics.update({f'Accuracy@thr={t:.3f}': st['accuracy'], f'Precision@thr={t:.3f}': st['precision'],
-                                f'Recall@thr={t:.3f}': st['recall']})
-            for far in cfg.get('far_thr', []):
-                metrics[f'TAR@FAR={far}'] = M.tar_at_far(fpr, tpr, far)
-            for frr in cfg.get('frr_thr', []):
-                metrics[f'TRR@FRR={frr}'] = M.tar_at_far(1 - tpr.flip(0), 1 - fpr.flip(0), frr)
-            rk = self._recall(emb, classes, cfg.get('k', [10, 100]))
-            metrics.update({f'Recall@K={k}': (x / y if y else float('nan')) for k, (x, y) in rk.items()})
+            ps = M.PairStats(scores, labels)
+            fpr, tpr, thr = ps.roc()
+            opt_thr = ps.opt_threshold()
+            cm = ps.stats_at(opt_thr)
+            confmat = [[cm['tn'], cm['fp']], [cm['fn'], cm['tp']]]          # [target][prediction], torchmetrics.ConfusionMatrix
+            print(name, f'\nConf Mat thr = {opt_thr}', confmat)
+            metrics = {'ROC AUC': ps.auroc(), 'AveragePrecision': ps.average_precision(),
+                       'Accuracy': ps.best_threshold_accuracy(thr, fpr, 1 - tpr)[0], 'Opt thr': opt_thr}
+            thrs = cfg.get('thrs', ())
+            at = [ps.stats_at(float(t)) for t in thrs]
+            metrics.update((f'Accuracy thr={t}', st['accuracy']) for t, st in zip(thrs, at))
+            metrics.update((f'Precision thr={t}', st['precision']) for t, st in zip(thrs, at))
+            metrics.update((f'Recall thr={t}', st['recall']) for t, st in zip(thrs, at))
+            ks = list(cfg.get('k', ()))
+            if len(ks):
+                rk = self._recall(emb, classes, ks)
+                metrics.update({f'Recall@K={k}': (x / y if y else float('nan')) for k, (x, y) in rk.items()})
+            for far, (tar, th) in ps.far_points(cfg.get('far_thr', ())).items():
+                metrics[f'TAR@FAR={far}'] = tar
+                metrics[f'TH@FAR={far}'] = th
+            for frr, (trr, th) in ps.frr_points(cfg.get('frr_thr', ())).items():
+                metrics[f'TRR@FRR={frr}'] = trr
+                metrics[f'TH@FRR={frr}'] = th
             all_metrics[name] = metrics
-            print('', *[f'{name} {k}\t{v}' for k, v in metrics.items()], sep='\n')
+            self.last_confmat[name] = confmat
+            print(*[f'{name} {k}\t{v}' for k, v in metrics.items()], sep='\n')
+            self._plot_confmat(name, cm)
             self._log(name, metrics)
             rocs.append((fpr.numpy(), tpr.numpy(), metrics['ROC AUC'], name))
-            self._plot_confmat(name, cm)
         self._plot_rocs(rocs)
         self.last_metrics = all_metrics
         return all_metrics

@@ -108,6 +108,14 @@ class FlatDDP:
         self._extra_done = set()
         self._hooks = [p.register_post_accumulate_grad_hook(self._reduce_param) for p in self.extra if p.requires_grad]
 
+    def broadcast_parameters(self):
+        """rank 0's parameters / BN statistics / head weights → every rank (construction, and after a checkpoint was loaded)"""
+        dist.broadcast(self.eng.master, 0, group=self.group)
+        if hasattr(self.eng, "stats"):
+            dist.broadcast(self.eng.stats, 0, group=self.group)
+        for p in self.extra:
+            dist.broadcast(p.data, 0, group=self.group)
+
     def detach(self):
         """unhook from the model (the trainer builds a new FlatDDP when the model got a new engine)"""
         for h in self._hooks:
@@ -155,13 +163,17 @@ class GenericDDP:
     ordinary parameter tensors (used by the CPU plumbing configs and the gloo tests)."""
 
     def __init__(self, module, group=None):
+        self.module = module      # identity of what this reducer is bound to (Trainer._setup rebinds when the model changes)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.group = group
-        for p in self.params:
-            dist.broadcast(p.data, 0, group=group)
         self.buffers = [b for b in module.buffers() if b.dtype.is_floating_point]
+        self.broadcast_parameters()
+
+    def broadcast_parameters(self):
+        for p in self.params:
+            dist.broadcast(p.data, 0, group=self.group)
         for b in self.buffers:
-            dist.broadcast(b.data, 0, group=group)
+            dist.broadcast(b.data, 0, group=self.group)
 
     def finish_backward(self):
         world = dist.get_world_size(self.group)

@@ -6,7 +6,9 @@ reference: per batch zero_grad → training_step → backward → optimizer.step
 trainer.py:403-413); validation at the end of every epoch, then a barrier when distributed, then the LR-scheduler
 step (loops/train_loop.py:13-38); evaluation outputs are handed over as List[dataloader][batch]
 (loops/eval_loop.py:30-51); no sanity-validation steps, no sampler replacement, private BN statistics per rank
-(trainer.py:105,110,118); one checkpoint (bare state_dict, reference key names) per epoch.
+(trainer.py:105,110,118); one checkpoint (bare state_dict, reference key names) per epoch plus a `.trainer` sidecar
+(epoch, global_step, optimizer_states, lr_schedulers — PL's checkpoint keys) that `resume_from_checkpoint=` /
+`fit(ckpt_path=)` restart from (trainer.py:111,399; a PL-format checkpoint holding the same keys is read too).
 
 Distributed = one process per GPU started by torchrun (RANK / LOCAL_RANK / WORLD_SIZE), RCCL all-reduce of the flat
 gradient buffer in buckets overlapped with backward (engine/ddp.py)."""
@@ -41,7 +43,7 @@ class Trainer:
     def __init__(self, gpus=0, default_root_dir=None, strategy=None, max_epochs=1, logger=False, enable_checkpointing=False,
                  callbacks=None, num_sanity_val_steps=0, limit_train_batches=None, limit_val_batches=None,
                  check_val_every_n_epoch=1, log_every_n_steps=50, benchmark=None, fast_dev_run=False, prefetch_batches=2,
-                 **_ignored):
+                 resume_from_checkpoint=None, **_ignored):
         self.gpus, self.root, self.strategy = gpus, default_root_dir, strategy
         self.max_epochs = 1 if fast_dev_run else max_epochs
         self.logger = logger if logger else None
@@ -56,6 +58,7 @@ class Trainer:
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.global_step = 0
         self.ddp = None
+        self.resume_from_checkpoint = resume_from_checkpoint
         # batches copied to the device ahead of the step on a copy stream (data_loading/prefetch.py); 0: plain .to() per batch
         self.prefetch_batches = int(os.environ.get('PFR_PREFETCH', prefetch_batches))
         self.train_img_s = None      # end-to-end images/s of the last fit() (loader + copy + step), first 5 steps excluded
@@ -93,20 +96,61 @@ class Trainer:
                     if self.ddp is not None:
                         self.ddp.detach()
                     self.ddp = FlatDDP(controller.model_loss, bucket_mb=self.strategy.get('bucket_mb', 25))
-            elif self.ddp is None:
+            elif self.ddp is None or self.ddp.module is not controller.model_loss:
+                # (re)bind: main.py builds a fresh Controller after the batch-size / lr finders — a reducer kept from the discarded
+                # one would neither broadcast rank 0's new parameters nor all-reduce the new model's gradients
                 from .ddp import GenericDDP
                 self.ddp = GenericDDP(controller.model_loss)
         return device
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def _save_checkpoint(self, controller, optims, scheds, epoch):
+        root = Path(self.root)
+        root.mkdir(parents=True, exist_ok=True)
+        torch.save(controller.state_dict(), root / f'epoch={epoch}.ckpt')
+        torch.save({'epoch': epoch + 1, 'global_step': self.global_step,
+                    'optimizer_states': [o.state_dict() for o in optims],
+                    'lr_schedulers': [s.state_dict() for s in scheds]}, root / f'epoch={epoch}.ckpt.trainer')
+
+    def _resume(self, controller, optims, scheds, path, device):
+        """→ first epoch to run.  `path`: an `epoch=N.ckpt` of this trainer (state dict; loop state in its `.trainer` sidecar) or a
+        pytorch-lightning checkpoint ({'state_dict', 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers'}).  Like PL
+        (trainer.py:306-308) a missing file raises, and training continues at the beginning of the next epoch."""
+        path = Path(path)
+        if not path.is_file():
+            raise FileNotFoundError(f"resume_from_checkpoint: no checkpoint at {path}")
+        ckpt = torch.load(str(path), map_location='cpu')
+        if isinstance(ckpt, dict) and 'state_dict' in ckpt:
+            sd, loop = ckpt['state_dict'], ckpt
+        else:
+            sd = ckpt
+            side = Path(str(path) + '.trainer')
+            loop = torch.load(str(side), map_location='cpu') if side.is_file() else {}
+        controller.load_state_dict(sd, strict=True)
+        for o, st in zip(optims, loop.get('optimizer_states', [])):
+            o.load_state_dict(st)
+        for s_, st in zip(scheds, loop.get('lr_schedulers', [])):
+            s_.load_state_dict(st)
+        self.global_step = int(loop.get('global_step', 0))
+        if 'epoch' not in loop:
+            print(f'resume_from_checkpoint: {path.name} carries no loop state — weights only, starting at epoch 0')
+        return int(loop.get('epoch', 0))
+
     # ------------------------------------------------------------------
-    def fit(self, controller):
+    def fit(self, controller, ckpt_path=None):
         device = self._setup(controller)
         opt = controller.configure_optimizers()
         optims, scheds = (opt if isinstance(opt, (tuple, list)) and len(opt) == 2 and isinstance(opt[0], (list, tuple))
                           else ([opt], []))
         optim = optims[0]
         history = []
-        for epoch in range(self.max_epochs):
+        first_epoch = 0
+        ckpt_path = ckpt_path or self.resume_from_checkpoint
+        if ckpt_path is not None:
+            first_epoch = self._resume(controller, optims, scheds, ckpt_path, device)
+            if self.ddp is not None and hasattr(self.ddp, 'broadcast_parameters'):
+                self.ddp.broadcast_parameters()
+        for epoch in range(first_epoch, self.max_epochs):
             controller.current_epoch = epoch
             controller.train()
             loader = controller.train_dataloader()
@@ -149,8 +193,7 @@ class Trainer:
             for s in scheds:
                 s.step()
             if self.enable_checkpointing and self.root is not None and self.rank == 0:
-                Path(self.root).mkdir(parents=True, exist_ok=True)
-                torch.save(controller.state_dict(), Path(self.root) / f'epoch={epoch}.ckpt')
+                self._save_checkpoint(controller, optims, scheds, epoch)
         self.loss_history = history
         return controller
 

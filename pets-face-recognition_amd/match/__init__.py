@@ -140,8 +140,8 @@ def pair_similarity(emb, idx_a, idx_b, eps=1e-8):
     ia = torch.as_tensor(idx_a, dtype=torch.int64, device=emb.device).contiguous()
     ib = torch.as_tensor(idx_b, dtype=torch.int64, device=emb.device).contiguous()
     if not emb.is_cuda:
-        a, b = emb[ia], emb[ib]
-        return ((a * b).sum(1) / (a.norm(dim=1).clamp_min(eps) * b.norm(dim=1).clamp_min(eps)) + 1) / 2
+        # CPU tensors: the reference's own call (fe_dogs_config.py:93), bit for bit
+        return (torch.nn.functional.cosine_similarity(emb[ia], emb[ib], eps=eps) + 1) / 2
     if ia.numel() and (int(torch.stack([ia.min(), ib.min()]).min()) < 0 or int(torch.stack([ia.max(), ib.max()]).max()) >= emb.shape[0]):
         # the torch indexing of the reference raises here; a device gather would read outside the embedding matrix
         raise IndexError(f"pair index out of range for {emb.shape[0]} embeddings (evaluation truncated by limit_val_batches?)")

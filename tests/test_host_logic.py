@@ -296,3 +296,106 @@ def test_lr_finder_suggestion_is_the_steepest_descent():
     loss[18] -= 0.6
     s = LRFinderResult(lrs, loss).suggestion()
     assert s in (lrs[17], lrs[18]) and LRFinderResult(lrs[:5], loss[:5]).suggestion() is None
+
+
+def _tiny_config(lr_milestones=(1, 2)):
+    """a config object with the reference's contract on a tiny CPU model (deterministic loaders)"""
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    from pets_face_recognition_amd.utils import get_dict_wrapper  # noqa: F401
+    g = torch.Generator().manual_seed(0)
+    xs = torch.rand(24, 3, 8, 8, generator=g)
+    ys = torch.randint(0, 6, (24,), generator=g)
+    data = [{"x": xs[i:i + 8], "label": ys[i:i + 8], "index": torch.arange(i, i + 8)} for i in range(0, 24, 8)]
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+
+    cfg = Cfg()
+
+    def model():
+        return torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(192, 512))
+
+    def loss(config, m):
+        return SoftmaxBasedMetricLearning(m, 6, 512, is_focal=True, arc_margin=True)
+
+    def optimizer(ml):
+        o = torch.optim.SGD([{"params": list(ml.module.parameters()), "lr": 0.05},
+                             {"params": list(ml.add_margin.parameters()), "lr": 0.1, "weight_decay": 1e-4}], 0.01, momentum=0.9)
+        return [o], [torch.optim.lr_scheduler.MultiStepLR(o, milestones=list(lr_milestones), gamma=0.1)]
+
+    cfg.update(model=model, loss=loss, optimizer=optimizer, train_dataloader=lambda: data, val_dataloader=lambda: data, n_epochs=3)
+    return cfg
+
+
+def test_resume_from_checkpoint_continues_the_run(tmp_path):
+    """reference engine/trainer.py:111,399 (`resume_from_checkpoint` → CheckpointConnector): a run restarted from the epoch-0
+    checkpoint ends with the weights, momentum buffers, scheduler state and step counter of the uninterrupted 3-epoch run; a
+    missing file raises like PL's; a pytorch-lightning-format checkpoint is read too."""
+    from pets_face_recognition_amd.engine import Trainer
+    from pets_face_recognition_amd.engine.controller import Controller
+    kw = dict(gpus=0, max_epochs=3, enable_checkpointing=True, check_val_every_n_epoch=100, prefetch_batches=0)
+    torch.manual_seed(1)
+    a = Controller(_tiny_config())
+    ta = Trainer(default_root_dir=tmp_path / "a", **kw)
+    ta.fit(a)
+    assert ta.global_step == 9 and (tmp_path / "a" / "epoch=0.ckpt.trainer").exists()
+    sd0 = torch.load(tmp_path / "a" / "epoch=0.ckpt")
+    assert "model_loss.add_margin.weight" in sd0                  # the weights file stays a bare reference-named state dict
+    torch.manual_seed(2)                                           # a different initialisation: everything must come from the file
+    b = Controller(_tiny_config())
+    tb = Trainer(default_root_dir=tmp_path / "b", resume_from_checkpoint=tmp_path / "a" / "epoch=0.ckpt", **kw)
+    tb.fit(b)
+    assert tb.global_step == 9
+    assert not (tmp_path / "b" / "epoch=0.ckpt").exists() and (tmp_path / "b" / "epoch=2.ckpt").exists()   # epochs 1, 2 ran
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va, vb), k
+    sa = torch.load(tmp_path / "a" / "epoch=2.ckpt.trainer"); sb = torch.load(tmp_path / "b" / "epoch=2.ckpt.trainer")
+    assert sa["epoch"] == sb["epoch"] == 3 and sa["lr_schedulers"] == sb["lr_schedulers"]
+    for x, y in zip(sa["optimizer_states"][0]["state"].values(), sb["optimizer_states"][0]["state"].values()):
+        assert torch.equal(x["momentum_buffer"], y["momentum_buffer"])
+    # pytorch-lightning layout: one file with state_dict + loop state; fit(ckpt_path=) form
+    st = torch.load(tmp_path / "a" / "epoch=1.ckpt.trainer")
+    torch.save(dict(st, state_dict=torch.load(tmp_path / "a" / "epoch=1.ckpt")), tmp_path / "pl.ckpt")
+    c = Controller(_tiny_config())
+    tc = Trainer(default_root_dir=tmp_path / "c", **kw)
+    tc.fit(c, ckpt_path=tmp_path / "pl.ckpt")
+    for (k, va), (_, vc) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(va, vc), k
+    with pytest.raises(FileNotFoundError):
+        Trainer(default_root_dir=tmp_path / "d", resume_from_checkpoint=tmp_path / "nope.ckpt", **kw).fit(Controller(_tiny_config()))
+
+
+_REBIND_SCRIPT = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+    from test_host_logic import _tiny_config
+    from pets_face_recognition_amd.engine import Trainer
+    from pets_face_recognition_amd.engine.controller import Controller
+    rank = int(os.environ['RANK'])
+    tr = Trainer(gpus=0, max_epochs=1, strategy=dict(kind='ddp'), check_val_every_n_epoch=100, prefetch_batches=0)
+    torch.manual_seed(10 + rank)
+    old = Controller(_tiny_config())
+    tr._setup(old)                                   # what the batch-size / lr finders do (utils/tuner.py) ...
+    first = tr.ddp
+    torch.manual_seed(20 + rank)                     # ... then main.py builds a FRESH controller (different init per rank here)
+    new = Controller(_tiny_config())
+    tr.fit(new)
+    assert tr.ddp is not first and tr.ddp.module is new.model_loss
+    for k, v in new.state_dict().items():
+        both = [torch.zeros_like(v) for _ in range(2)]
+        dist.all_gather(both, v)
+        assert torch.equal(both[0], both[1]), k      # rank 0's parameters were broadcast and the gradients averaged
+    dist.destroy_process_group()
+    print('rank', rank, 'ok')
+""")
+
+
+def test_generic_ddp_rebinds_to_the_controller_built_after_the_tuners_gloo_world2(tmp_path):
+    """ADVICE r3 (main.py:59): after find_max_batch_size / find_optimal_init_lr main.py builds a fresh Controller; on the torch / gloo
+    path the trainer must bind its reducer to THAT module (broadcast + all-reduce), not keep the one of the discarded controller."""
+    script = tmp_path / "rebind_check.py"
+    script.write_text(_REBIND_SCRIPT.format(root=ROOT))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29641", str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("ok") == 2

@@ -342,3 +342,25 @@ def test_first_chunk_topk_pivot_paths_are_exact(dist, K):
         return
     assert torch.equal(idx.long(), order), dist
     assert torch.equal(sc, torch.gather(s, 1, order))
+
+
+@pytest.mark.parametrize("name", ["n256", "n400", "ties", "edge"])
+def test_controller_evaluate_on_gpu_equals_reference_evaluate(name):
+    """Controller._evaluate on CUDA embeddings (fused pair-score kernel, pfr_pair_curve sort + scan, GPU candR@K) → the metrics
+    dict equals, key for key, what the REFERENCE's own Controller._evaluate printed for the same embeddings / pairs / thrs / k /
+    far_thr / frr_thr (tests/golden/evaluate.npz, engine/controller.py:95-183).  "edge" has impostor pairs of identical rows and
+    genuine pairs of opposite rows: whether torch-CPU's cosine returns exactly 1 / 0 there is rounding luck the reference's skip
+    rule (`thr not in (0, 1)`) depends on, so that set feeds the reference's pair scores through config.similarity_f (a custom
+    similarity is honoured on CUDA) and pins the device sort / scan / index rules on them."""
+    from test_oracle_golden import _evaluate_case, check_evaluate_against_reference
+    sim = None
+    if name == "edge":
+        sc = torch.tensor(np.load(os.path.join(GOLD, "evaluate.npz"))["edge_pair_scores"]).to(DEV)
+        sim = lambda pairs: sc       # noqa: E731
+    m, cm, gold, gold_cm = _evaluate_case(name, device=DEV, match_dtype=torch.float32, similarity_f=sim)
+    check_evaluate_against_reference(m, cm, gold, gold_cm, name)
+    # bf16 candidates + fp32 re-score: the same Recall@K
+    m2, _, _, _ = _evaluate_case(name, device=DEV, match_dtype=torch.bfloat16, similarity_f=sim)
+    for k in m:
+        if k.startswith("Recall@K="):
+            assert m2[k] == m[k], (name, k)

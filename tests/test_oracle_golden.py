@@ -278,3 +278,72 @@ def test_calc_scores_restatement_equals_reference_rows():
         assert r[4] == ans[ans >= 0].tolist()
     # the fixture exercises every branch of the rule
     assert any((a >= 0).sum() < 100 for a in z["answer"]) and any((a >= 0).sum() == 100 for a in z["answer"])
+
+
+def _evaluate_case(name, device="cpu", match_dtype=torch.float32, similarity_f=None):
+    """run the product Controller._evaluate on one set of tests/golden/evaluate.npz → (metrics dict, confusion matrix, golden)"""
+    import tempfile
+    from pets_face_recognition_amd.engine.controller import Controller
+    E = np.load(os.path.join(GOLD, "evaluate.npz"))
+    src = E if name == "edge" else np.load(os.path.join(GOLD, "recall.npz"))
+    emb = torch.tensor(src[f"{name}_emb"])
+    classes = torch.tensor(src[f"{name}_classes"])
+    pairs = [tuple(p) for p in src[f"{name}_pairs"].tolist()]
+    plabels = src[f"{name}_plabels"].tolist()
+
+    class PG:
+        corrected_indices = pairs
+        labels = plabels
+
+    def default_sim(ps):
+        t1 = torch.stack([p[0] for p in ps]); t2 = torch.stack([p[1] for p in ps])
+        return (torch.nn.functional.cosine_similarity(t1, t2) + 1) / 2
+    default_sim._is_default_cosine = True
+
+    class Cfg(dict):
+        def pair_generator(self, i):
+            return "Val", PG
+
+    N = emb.shape[0]
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1))
+    batches = [{"emb": emb[perm][i:i + 20].to(device), "label": classes[perm][i:i + 20].to(device), "index": perm[i:i + 20].to(device)}
+               for i in range(0, N, 20)]
+    with tempfile.TemporaryDirectory() as td:
+        cfg = Cfg(thrs=E["thrs"], k=E["k"].tolist(), far_thr=E["far_thr"].tolist(), frr_thr=E["frr_thr"].tolist(), img_dir=td)
+        cfg.similarity_f = similarity_f or default_sim
+        cfg.match_dtype = match_dtype
+        c = Controller.__new__(Controller)
+        torch.nn.Module.__init__(c)
+        c.logger, c.current_epoch, c.last_metrics, c.config = None, 0, {}, cfg
+        m = c._evaluate([batches])["Val"]
+    gold = dict(zip(E[f"{name}_keys"].tolist(), E[f"{name}_values"].tolist()))
+    return m, c.last_confmat["Val"], gold, E[f"{name}_confmat"].tolist()
+
+
+def check_evaluate_against_reference(m, cm, gold, gold_cm, name):
+    """key for key (same keys, same order — incl. the TAR@FAR / TRR@FRR keys the reference SKIPS when the threshold is 0 or 1);
+    ratios of Python ints to 1e-12, the values the reference prints from float32 tensors to 1e-6.  Recall@K under exact score ties is
+    undefined in the reference (unstable argsort, controller.py:155): the "ties" set still reproduces the golden for every K, the
+    "edge" set (ties across identities at the cut) is checked against the oracle's documented tie rule."""
+    assert list(m.keys()) == list(gold.keys()), (list(m.keys()), list(gold.keys()))
+    for k, v in gold.items():
+        if name == "edge" and k.startswith("Recall@K="):
+            # four identical rows of four identities: which of them the reference's unstable argsort ranks first is arbitrary;
+            # the product's documented rule (lower index first) is pinned by the oracle instead
+            from oracle import match_ref
+            E = np.load(os.path.join(GOLD, "evaluate.npz"))
+            kk = int(k.split("=")[1])
+            x, y = match_ref.recall_at_k_matrix(torch.tensor(E["edge_emb"]), torch.tensor(E["edge_classes"]), (kk,))[kk]
+            assert m[k] == x / y, (name, k, m[k], x / y)
+            continue
+        f32 = k in ("ROC AUC", "AveragePrecision", "Opt thr") or k.startswith("TH@") or " thr=" in k   # float32 tensors' .item()
+        tol = 1e-6 if f32 else 1e-12
+        assert abs(m[k] - v) <= tol, (name, k, m[k], v)
+    assert cm == gold_cm, (name, cm, gold_cm)
+
+
+@pytest.mark.parametrize("name", ["n256", "n400", "ties", "edge"])
+def test_evaluate_metrics_dict_equals_reference_evaluate(name):
+    """Controller._evaluate (CPU tensors) vs the metrics the REFERENCE's own Controller._evaluate printed for the same embeddings,
+    pairs, thrs / k / far_thr / frr_thr (engine/controller.py:95-183 run by oracle/make_golden.py gen_evaluate)."""
+    check_evaluate_against_reference(*_evaluate_case(name), name)
