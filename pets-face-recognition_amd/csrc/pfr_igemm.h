@@ -12,6 +12,8 @@ struct IgemmParams {
   int Cout, ldy;
   int M, K;
   float* stats_part;  // [tilesM][2][Cout] (tile mean, tile M2) or nullptr
+  int want_mtile = 0;  // rows per statistics partial the caller sized stats_part for (pfr_conv2d_mtile / pfr_gemm_act_mtile): a kernel
+                       // with another granularity must not take the launch (it would write a different number of partial rows)
   const float* bias;  // [Cout] or nullptr
   const void* residual;  // [M][ldy] of TO or nullptr: y = result (+bias) + residual   (transformer residual streams)
   int accumulate;
@@ -52,18 +54,13 @@ struct IgemmParams {
 int igemm_p_launch(IgemmParams& p, int dtype, int out_dtype, int bq, int bp, hipStream_t st);
 int igemm_p_enabled();
 int igemm_p_forced_tile();
-// wave-specialised kernel (pfr_igemm_ws.hip): PFR_IGEMM_WS / pfr_set_tuning("igemm_ws"): 0 off, 1 heuristic, 2 whenever eligible
-int igemm_ws_mode();
-void igemm_ws_set_mode(int v);
-bool igemm_ws_eligible(const IgemmParams& p, int dtype, int out_dtype);
-int igemm_ws_launch(IgemmParams& p, hipStream_t st);
 // weight-stationary streaming kernel for HBM-bound 1x1 convolutions (pfr_sconv.hip): PFR_SCONV / pfr_set_tuning("sconv"): 0 off,
 // 1 heuristic (default), 2 whenever eligible.  sconv_try_launch returns 1 when it does not take the launch; sconv_mtile the rows per
 // statistics partial of a post-op-free 1x1 launch it WOULD take (0: not its geometry) — both decide on geometry alone.
 int sconv_mode();
 void sconv_set_mode(int v);
 int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
-int sconv_mtile(int M, int N, int K, int dtype, int out_dtype);
+int sconv_mtile(int M, int N, int K, long in_rows, int dtype, int out_dtype);
 // halo-staged weight-stationary 3x3 kernel for 64 -> 64 channels (pfr_sconv3.hip); same conventions as sconv_*
 bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int dtype,
                  int out_dtype, int* bpw);

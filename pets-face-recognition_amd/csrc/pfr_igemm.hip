@@ -743,14 +743,6 @@ static int pick_persistent(int M, int Cout, int K, int C, int dtype, int out_dty
   return pclass ? 1 : 0;
 }
 
-// wave-specialised kernel: geometry-only part of the decision (what pfr_conv2d_mtile can see too)
-static int pick_ws(int M, int Cout, int K, int C, int dtype, int out_dtype, int has_pro) {
-  const int mode = igemm_ws_mode();
-  if (mode == 0 || dtype != PFR_BF16 || out_dtype != PFR_BF16 || has_pro) return 0;
-  if (C % 32 != 0 || M % 256 != 0 || Cout % 64 != 0 || K < 64 || (size_t)M * Cout * 2 >= ((size_t)1 << 31)) return 0;
-  return 1;
-}
-
 template <typename T, typename TO>
 static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   int bq, bp;
@@ -769,15 +761,20 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
     pfr_set_error("pfr_conv2d_dgrad_bn_sub: geometry not taken by the streaming kernel");
     return PFR_ERR_UNSUPPORTED;
   }
-  if (!stats_postop && igemm_ws_mode() && igemm_ws_eligible(p, dtype, out_dtype) &&
-      (igemm_pclass_ok(p) || pick_ws(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr)))
-    return igemm_ws_launch(p, st);
+  // a statistics launch goes only to a kernel whose partial granularity is the one the caller sized stats_part for
+  const auto mtile_ok = [&](int mt) { return !p.stats_part || !p.want_mtile || p.want_mtile == mt; };
   const int pcl = igemm_pclass_ok(p) ? 1 : 0;
-  if (!stats_postop && !p.bnb_part[0] && pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp)) {
+  if (!stats_postop && !p.bnb_part[0] && pick_persistent(p.M, p.Cout, p.K, p.C, dtype, out_dtype, p.pro_scale != nullptr, p.act, pcl, &bq, &bp) &&
+      mtile_ok(bq / 2)) {
     const int rc = igemm_p_launch(p, dtype, out_dtype, bq, bp, st);
     if (rc != 1) return rc;
   }
   const int v = pick_tile(p.M, p.Cout, p.K, dtype, out_dtype, &bq);
+  if (!mtile_ok(bq)) {
+    pfr_set_error("conv / gemm statistics launch: stats_part was sized for %d-row partials (pfr_conv2d_mtile / pfr_gemm_act_mtile) but this "
+                  "launch (ldy, bias / residual / ReLU / accumulate post-ops) can only take the %d-row tile kernel", p.want_mtile, bq);
+    return PFR_ERR_ARG;
+  }
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
     if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 8, 8, 2>(p, st);
     if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 8, 8, 2>(p, st);
@@ -801,11 +798,10 @@ extern "C" int pfr_conv2d_mtile(int N, int H, int W, int C, int Cout, int R, int
     if (sconv3_geom(N, H, W, C, Cout, R, S, stride, pad, 0, OH, OW, dtype, out_dtype, &bpw)) return bpw * 32;
     if (R == 1 && S == 1 && pad == 0 && (stride == 1 || (H == OH * stride && W == OW * stride))) {
       // 1x1: the streaming kernel publishes one partial per workgroup row range
-      const int mt = sconv_mtile(M, Cout, K, dtype, out_dtype);
+      const int mt = sconv_mtile(M, Cout, K, (long)N * H * W, dtype, out_dtype);
       if (mt) return mt;
     }
   }
-  if (pick_ws(M, Cout, K, C, dtype, out_dtype, fused_prologue)) return 64;   // one partial per memory wave (64 rows)
   // (statistics and the parity-class mode exclude each other, so the heuristic never picks the persistent kernel for a
   //  launch that publishes statistics; PFR_IGEMM_P=2 does)
   if (pick_persistent(M, Cout, K, C, dtype, out_dtype, fused_prologue, 0, 0, &bq, &bp)) return bq / 2;
@@ -937,6 +933,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int
   for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
   if (bnb) { p.res_sub = bnb->res_sub; p.bnb_mask = bnb->mask; for (int q = 0; q < 2; ++q) { p.bnb_x[q] = bnb->x[q]; p.bnb_coef[q] = bnb->coef[q]; p.bnb_part[q] = bnb->part[q]; } }
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
+  if (stats_part) p.want_mtile = pfr_conv2d_mtile(N, H, W, C, Cout, R, S, stride, pad, OH, OW, dtype, out_dtype, pro_scale != nullptr);
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
 #ifdef PFR_IGEMM_TRACE
@@ -991,6 +988,7 @@ static int gemm_act_impl(const void* x, const void* w, void* y, int dtype, long 
   p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = nullptr; p.res_sub = 0;
   p.bnb_mask = nullptr;
   for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
+  if (stats_part) p.want_mtile = pfr_gemm_act_mtile(M, K, N, dtype);
   p.div_ohow = make_fastdiv(1u);
   p.div_ow = make_fastdiv(1u);
 #ifdef PFR_IGEMM_TRACE

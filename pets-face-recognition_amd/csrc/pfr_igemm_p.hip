@@ -734,7 +734,6 @@ extern "C" int pfr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "igemm_ptile")) { g_p_tile = value; return PFR_OK; }
   if (!strcmp(key, "igemm_pkch")) { g_p_kch = value; return PFR_OK; }
   if (!strcmp(key, "igemm_ppf")) { g_p_pf = value; return PFR_OK; }
-  if (!strcmp(key, "igemm_ws")) { igemm_ws_set_mode(value); return PFR_OK; }
   if (!strcmp(key, "sconv")) { sconv_set_mode(value); return PFR_OK; }
   if (!strcmp(key, "sconv3")) { sconv3_set_enabled(value); return PFR_OK; }
   if (!strcmp(key, "wgrad_big")) { wgrad_set_big(value); return PFR_OK; }

@@ -591,12 +591,13 @@ static int sconv_panel(int N, int K) {
 struct SconvPlan {
   int np, npanels, nranges, R, ns, tp;
 };
-// geometry-only eligibility (what pfr_conv2d_mtile can see as well): bf16, K in {64, 128, 256, 512}, panel fits, enough rows
-bool sconv_plan(int M, int N, int K, int dtype, int out_dtype, SconvPlan* sp) {
+// geometry-only eligibility — the ONE test shared by pfr_conv2d_mtile, pfr_conv2d_dgrad_bn_parts and the launch: bf16, K in {64, 128,
+// 256, 512}, panel fits, enough rows, output AND input extents (in_rows = N*H*W: 4x the output rows of a stride-2 1x1) below 2 GiB
+bool sconv_plan(int M, int N, int K, long in_rows, int dtype, int out_dtype, SconvPlan* sp) {
   const int mode = sconv_mode();
   if (mode == 0 || dtype != PFR_BF16 || out_dtype != PFR_BF16) return false;
   if (K != 64 && K != 128 && K != 256 && K != 512) return false;
-  if (N % 64 != 0 || (long)M * N * 2 >= ((long)1 << 31) || (long)M * K * 2 >= ((long)1 << 31)) return false;
+  if (N % 64 != 0 || (long)M * N * 2 >= ((long)1 << 31) || (long)M * K * 2 >= ((long)1 << 31) || in_rows * K * 2 >= ((long)1 << 31)) return false;
   const int np = sconv_panel(N, K);
   if (!np) return false;
   const int npanels = N / np;
@@ -665,9 +666,9 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (join && ((!p.res_mask && !bnb && !acc_inplace) || p.stats_part)) return 1;
   if (p.res_sub && (!bnb || p.res_mask || p.ostride != 1 || (p.OH & 1) || (p.OW & 1))) return 1;
   if (p.ostride != 1 && (p.H != p.OH * p.ostride || p.W != p.OW * p.ostride)) return 1;
-  if ((long)p.N * p.H * p.W * p.K * 2 >= ((long)1 << 31)) return 1;
   SconvPlan pl;
-  if (!sconv_plan(p.M, p.Cout, p.K, dtype, out_dtype, &pl)) return 1;
+  if (!sconv_plan(p.M, p.Cout, p.K, (long)p.N * p.H * p.W, dtype, out_dtype, &pl)) return 1;
+  if (p.stats_part && p.want_mtile && p.want_mtile != pl.R) return 1;   // the caller sized stats_part for another kernel's partials
   SconvParams sp;
   sp.x = p.x; sp.w = p.w; sp.y = p.y;
   sp.M = p.M; sp.K = p.K; sp.N = p.Cout;
@@ -708,13 +709,13 @@ void sconv_set_bnb_mode(int v) { g_bnb_mode = v; }
 // partial rows (= row ranges) the streaming kernel leaves for a 1x1 data gradient + BN sums of this geometry, 0 when it does not take it
 int sconv_bnb_parts(int M, int N, int K, int dtype) {
   SconvPlan pl;
-  if (sconv_bnb_mode() != 2 || !sconv_plan(M, N, K, dtype, dtype, &pl)) return 0;
+  if (sconv_bnb_mode() != 2 || !sconv_plan(M, N, K, M, dtype, dtype, &pl)) return 0;
   return pl.nranges;
 }
 
 // rows per statistics partial when this kernel takes a (post-op free) 1x1 launch of the geometry, 0 when it does not
-int sconv_mtile(int M, int N, int K, int dtype, int out_dtype) {
+int sconv_mtile(int M, int N, int K, long in_rows, int dtype, int out_dtype) {
   SconvPlan pl;
-  if (!sconv_plan(M, N, K, dtype, out_dtype, &pl)) return 0;
+  if (!sconv_plan(M, N, K, in_rows, dtype, out_dtype, &pl)) return 0;
   return pl.R;
 }

@@ -394,6 +394,7 @@ int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) 
   if (infer ? p.stats_part != nullptr : p.out_relu != 0) return 1;
   int bpw;
   if (!sconv3_geom(p.N, p.H, p.W, p.C, p.Cout, p.R, p.S, p.ostride, p.pad, p.idil_log2, p.OH, p.OW, dtype, out_dtype, &bpw)) return 1;
+  if (p.stats_part && p.want_mtile && p.want_mtile != bpw * 32) return 1;
   Sconv3Params sp;
   sp.x = p.x; sp.w = p.w; sp.y = p.y;
   sp.N = p.N; sp.H = p.H; sp.W = p.W;

@@ -404,7 +404,7 @@ def test_strided_dgrad_parity_classes(dtype, R, H, C, Cout, accumulate):
     ("fwd", 8, 32, 64, 128, 1, 1), ("fwd", 8, 32, 64, 64, 3, 1), ("fwd", 8, 16, 256, 256, 3, 1), ("fwd", 8, 32, 128, 128, 3, 2),
     ("dgrad", 8, 16, 128, 128, 3, 1), ("dgrad", 8, 32, 256, 64, 1, 0), ("fwd", 20, 16, 96, 192, 1, 1)])
 def test_alternative_gemm_kernels_bit_identical(case):
-    """The persistent (pfr_igemm_p.hip) and wave-specialised (pfr_igemm_ws.hip) kernels must reproduce the one-tile-per-
+    """The persistent kernel (pfr_igemm_p.hip) must reproduce the one-tile-per-
     workgroup kernel BIT FOR BIT (same MFMA accumulation order) and publish BatchNorm statistics that finalise to the same
     mean / invstd, whatever partial granularity pfr_conv2d_mtile reports for them.  pfr_set_tuning selects the kernel."""
     from pets_face_recognition_amd._hip import lib
@@ -420,8 +420,7 @@ def test_alternative_gemm_kernels_bit_identical(case):
         kw = dict(stride=1, pad=R - 1 - pad, idil_log2=sd, out_hw=(H << sd, H << sd), stats=False)
     outs = []
     try:
-        for knobs in ({"igemm_p": 0, "igemm_ws": 0}, {"igemm_p": 2, "igemm_ws": 0, "igemm_ppf": 0}, {"igemm_p": 2, "igemm_ws": 0, "igemm_ppf": 1},
-                      {"igemm_p": 2, "igemm_ws": 0, "igemm_ppf": 3}, {"igemm_p": 0, "igemm_ws": 2}):
+        for knobs in ({"igemm_p": 0}, {"igemm_p": 2, "igemm_ppf": 0}, {"igemm_p": 2, "igemm_ppf": 1}, {"igemm_p": 2, "igemm_ppf": 3}):
             for k, v in knobs.items():
                 lib.pfr_set_tuning(k.encode(), v)
             y, part = o.conv2d_fwd(x, w, **kw)
@@ -434,7 +433,7 @@ def test_alternative_gemm_kernels_bit_identical(case):
             torch.cuda.synchronize()
             outs.append((y.clone(), st))
     finally:
-        for k, v in (("igemm_p", 1), ("igemm_ws", 0), ("igemm_ppf", 0)):
+        for k, v in (("igemm_p", 1), ("igemm_ppf", 0)):
             lib.pfr_set_tuning(k.encode(), v)
     for y, st in outs[1:]:
         assert torch.equal(y, outs[0][0])
@@ -902,3 +901,40 @@ def test_streaming_1x1_accumulate_bit_identical(case):
     assert torch.equal(outs[0], outs[1])
     ref = (x.float().reshape(-1, C) @ w.float().reshape(Co, C).t()).bfloat16().float().reshape(N, H, H, Co) + y0.float()
     assert (outs[1].float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+def test_statistics_partials_agree_with_the_query_at_the_2gib_input_boundary():
+    """ADVICE r3 (pfr_igemm.hip:804): a stride-2 1x1 conv whose OUTPUT-side extents pass the streaming kernel's 2 GiB test while its
+    INPUT extent (4x the rows) does not — layer2.0.downsample at a per-GPU batch of ≈ 1.4 k.  pfr_conv2d_mtile and the launch must
+    agree on the kernel (one shared geometry test): the partial rows the query promises are the rows the launch writes (canary row
+    behind them untouched) and they finalise to the statistics of the output.  And a statistics launch with post-ops that only the
+    tile kernel can take fails with PFR_ERR_ARG instead of writing a different number of partial rows."""
+    from pets_face_recognition_amd._hip import lib, PfrError
+    o = ops()
+    N, H, C, Co = 1340, 56, 256, 512                      # N*H*H*C*2 = 2.15e9 >= 2^31;  M*C*2 = 5.4e8
+    assert N * H * H * C * 2 >= 2 ** 31 and N * (H // 2) ** 2 * max(C, Co) * 2 < 2 ** 31
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(N, H, H, C, generator=g, device=DEV, dtype=torch.bfloat16)
+    w = (torch.randn(Co, 1, 1, C, generator=g, device=DEV) / C ** 0.5).bfloat16()
+    M = N * (H // 2) ** 2
+    mt = lib.pfr_conv2d_mtile(N, H, H, C, Co, 1, 1, 2, 0, H // 2, H // 2, 1, 1, 0)
+    nt = (M + mt - 1) // mt
+    buf = torch.full((nt + 1, 2, Co), 12345.0, dtype=torch.float32, device=DEV)
+    y, part = o.conv2d_fwd(x, w, stride=2, pad=0, stats=True, stats_buf=buf)
+    torch.cuda.synchronize()
+    assert torch.all(buf[nt] == 12345.0), "the launch wrote more partial rows than pfr_conv2d_mtile promised"
+    assert not torch.any(buf[:nt] == 12345.0), "the launch wrote fewer partial rows than pfr_conv2d_mtile promised"
+    st = o.bn_finalize(buf[:nt], mt, M, None, None, 1e-5, 0.1, None, None)
+    yf = y.float().reshape(M, Co)
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    assert torch.allclose(st[0], mean, rtol=1e-3, atol=2e-3)
+    assert torch.allclose(st[1], (var + 1e-5).rsqrt(), rtol=2e-3)
+    # just below the boundary the streaming kernel takes the same layer (its row range is the granularity)
+    mt_small = lib.pfr_conv2d_mtile(256, H, H, C, Co, 1, 1, 2, 0, H // 2, H // 2, 1, 1, 0)
+    assert mt_small != mt or mt in (64, 128, 256)
+    # statistics + ReLU post-op on a geometry whose query answers the streaming granularity: loud error, nothing written
+    xs = x[:8]
+    mts = lib.pfr_conv2d_mtile(8, H, H, C, Co, 1, 1, 1, 0, H, H, 1, 1, 0)
+    if mts not in (64, 128, 256):
+        with pytest.raises(PfrError):
+            o.conv2d_fwd(xs, w, stride=1, pad=0, stats=True, out_relu=True)

@@ -41,11 +41,10 @@ for kind, H, C, Co, R, s, dil, n in cases:
     by = (x.numel() + B * OH * OH * Co + w.numel()) * 2
     res = {}
     ref = None
-    variants = [("old", 0, -1, 4, 0), ("p128x128", 2, 0, 8, 0), ("ws2", 0, -1, 4, 0)]
+    variants = [("old", 0, -1, 4, 0), ("p128x128", 2, 0, 8, 0)]   # (the wave-specialised variant was retired in round 4: profiles/r02_gemm_ab*.json)
     for name, mode, tile, kch, pf in variants:
         if pf == 2 and C % 64:
             continue
-        lib.pfr_set_tuning(b"igemm_ws", 2 if name == "ws2" else 0)
         lib.pfr_set_tuning(b"igemm_p", mode)
         lib.pfr_set_tuning(b"igemm_ptile", tile)
         lib.pfr_set_tuning(b"igemm_pkch", kch)
