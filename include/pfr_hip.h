@@ -113,6 +113,34 @@ int pfr_conv2d_dgrad_bn_sub(const void* dy, const void* wt, void* dx, int dtype,
                             const void* res_compact, const void* bn_x, const float* bn_coef, const unsigned char* bn_mask,
                             float* bn_part, pfr_stream_t stream);
 
+/* The two launches above with `flags` (streaming form with a bit mask only): 1 = dx is stored THROUGH bn_mask (dx = g*mask: every consumer
+ * of a block-output gradient — the BN backward of the block's last BN, its projection BN, the residual join — reads it through that mask,
+ * so they may then read it plainly); 2 = the first BN's input is not read: only sum g*mask is produced (row 1 of bn_part = 0; bn_x and
+ * bn_coef may be NULL) — sum g*mask*xhat then comes out of pfr_bn3_bwd_coef. */
+int pfr_conv2d_dgrad_bn_ex(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int R, int S,
+                           int pad, int idil_log2, int OH, int OW, const void* res, const unsigned char* res_mask, int accumulate,
+                           const void* bn_x, const float* bn_coef, const unsigned char* bn_mask, float* bn_part, const void* bn2_x,
+                           const float* bn2_coef, float* bn2_part, int flags, pfr_stream_t stream);
+int pfr_conv2d_dgrad_bn_sub_ex(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int OH, int OW,
+                               const void* res_compact, const void* bn_x, const float* bn_coef, const unsigned char* bn_mask,
+                               float* bn_part, int flags, pfr_stream_t stream);
+
+/* Backward of a bottleneck's last 1x1 convolution + BatchNorm (autograd of `relu(bn3(conv3(z)) + shortcut)`, torchvision
+ * Bottleneck.forward) WITHOUT the BatchNorm's input x = conv3(z) and without its gradient dx (csrc/pfr_bnfree.hip): BN backward is
+ * linear, dx = A*G + B*(x - mean) + C0 per channel, and x - mean = (Z - zbar) W^T, so with G1 = G^T Z (pfr_conv2d_wgrad of the masked
+ * gradient G [M][C] against Z [M][K]), G2 = Z^T Z, zsum = column sums of Z:
+ *   pfr_bn3_bwd_coef:    dbeta = sum of part[t][0][:] (the partials pfr_conv2d_dgrad_bn[_ex] left), dgamma_c = invstd_c * sum_k W[c][k]
+ *                        (G1[c][k] - dbeta_c zbar_k); coef [3][C] = A = gamma invstd, B = -gamma invstd^2 dgamma / M, C0 = -gamma invstd dbeta / M
+ *   pfr_bn3_bwd_weights: dW = A*G1 + B*(W (G2 - M zbar zbar^T)) + C0 (x) (M zbar)   (fp32, += if accumulate);
+ *                        wa_t [K][C] bf16 = A_c W[c][k] (data-gradient weight layout), S [K][K] bf16 = W^T diag(B) W, bias [K] = C0^T W - zbar S
+ * and the data gradient is dZ = G wa_t^T + Z S + bias: pfr_conv2d_fwd(Z, S, bias) then pfr_conv2d_dgrad_bn(G, wa_t, res = that, no masks).
+ * W = the fp32 master weights [C][K]; count = M rows. */
+int pfr_bn3_bwd_coef(const float* part, int nparts, const float* G1, const float* zsum, const float* W, const float* gamma,
+                     const float* invstd, int C, int K, float count, float* dgamma, float* dbeta, float* coef, int accumulate,
+                     pfr_stream_t stream);
+int pfr_bn3_bwd_weights(const float* coef, const float* G1, const float* G2, const float* zsum, const float* W, int C, int K, float count,
+                        float* dW, void* wa_t, void* S, float* bias, int accumulate, pfr_stream_t stream);
+
 /* pfr_conv2d_wgrad replaces the autograd weight gradient of nn.Conv2d / nn.Linear / F.linear:
  *   dw[co][r][s][c] (fp32) = scale * sum_m dy[m][co] * act(x)[...]  (+ dw if accumulate)
  * workspace: fp32 [pfr_conv2d_wgrad_splits(M,Cout,R*S*C)][Cout][R*S*C] (may be NULL when splits == 1). */

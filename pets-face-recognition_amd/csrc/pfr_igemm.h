@@ -40,6 +40,7 @@ struct IgemmParams {
   // of its projection shortcut), x = that BN's input [M][ldy] of TO, coef = its [4][Cout] (mean, invstd, scale, shift),
   // part = [tilesM][2][Cout]: Σ g·mask and Σ g·mask·x̂ over the tile's rows.  mask: bit mask bnb_mask ([M][ldy / KPACK]) when
   // given, else scale·x + shift > 0 of set 0.
+  int bnb_flags = 0;   // bit 0: store the gradient THROUGH bnb_mask (g*mask); bit 1: no input / coefficients for BN 0 (only sum g*mask)
   const void* bnb_x[2];
   const float* bnb_coef[2];
   float* bnb_part[2];

@@ -814,6 +814,7 @@ struct BnbArgs {
   const float* coef[2];
   float* part[2];
   const unsigned char* mask;
+  int flags = 0;      // pfr_conv2d_dgrad_bn_ex: 1 = store through the mask, 2 = BN 0 without input / coefficients
   int res_sub = 0;    // the residual is the compact gradient of a stride-2 projection shortcut (streaming join only)
 };
 static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
@@ -865,25 +866,47 @@ extern "C" int pfr_conv2d_dgrad_bn_parts(int dtype, int N, int H, int W, int C, 
 // mask = bit mask `bn_mask` ([M][Cout/KPACK] bytes, pfr_bn_act_mask) when given, else scale·x + shift > 0 (coef rows 2, 3).
 // bn_x / bn_coef ([4][Cout]: mean, invstd, scale, shift) / bn_part describe the first BN, bn2_* an optional second one that
 // consumes the same gradient through the same mask (projection shortcut).  Replaces pfr_bn_bwd_reduce's pass over (g, x).
-extern "C" int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout,
-                                   int R, int S, int pad, int idil_log2, int OH, int OW, const void* res,
-                                   const unsigned char* res_mask, int accumulate, const void* bn_x, const float* bn_coef,
-                                   const unsigned char* bn_mask, float* bn_part, const void* bn2_x, const float* bn2_coef,
-                                   float* bn2_part, hipStream_t stream) {
-  PFR_CHECK_ARG(bn_x && bn_coef && bn_part, "pfr_conv2d_dgrad_bn: null pointer");
+static int dgrad_bn_impl(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int R, int S, int pad,
+                         int idil_log2, int OH, int OW, const void* res, const unsigned char* res_mask, int accumulate, const void* bn_x,
+                         const float* bn_coef, const unsigned char* bn_mask, float* bn_part, const void* bn2_x, const float* bn2_coef,
+                         float* bn2_part, int flags, hipStream_t stream) {
+  const bool nox = (flags & 2) != 0;
+  PFR_CHECK_ARG(bn_part && (nox || (bn_x && bn_coef)), "pfr_conv2d_dgrad_bn: null pointer");
+  PFR_CHECK_ARG(!(flags & 3) || (bn_mask && sconv_bnb_mode() == 2), "pfr_conv2d_dgrad_bn_ex: flags need the bit mask and the streaming form");
+  PFR_CHECK_ARG(!nox || (res && res_mask), "pfr_conv2d_dgrad_bn_ex: flag 2 (no BN input) goes with the block join (res + res_mask)");
   PFR_CHECK_ARG(!bn2_part || (bn2_x && bn2_coef && bn_mask), "pfr_conv2d_dgrad_bn: the second BN needs x, coef and the shared bit mask");
   PFR_CHECK_ARG(sconv_bnb_mode() == 2 ? (res != nullptr || res_mask == nullptr) : ((res == nullptr) == (res_mask == nullptr)),
                 "pfr_conv2d_dgrad_bn: res and res_mask go together (streaming form: res without a mask = plain add, res may be dx)");
   PFR_CHECK_ARG(pfr_conv2d_dgrad_bn_parts(dtype, N, H, W, C, Cout, R, S, idil_log2, OH, OW) > 0,
                 "pfr_conv2d_dgrad_bn: geometry not supported by the fused form (see pfr_conv2d_dgrad_bn_parts)");
-  PFR_CHECK_ARG(sconv_bnb_mode() != 2 || (!accumulate && (!res || bn_mask) && (!bn2_part || res)),
-                "pfr_conv2d_dgrad_bn: the streaming form (bnb mode 2) takes no accumulation, a bit mask with the join, a second BN only with the join");
+  PFR_CHECK_ARG(sconv_bnb_mode() != 2 || (!accumulate && (!res || !res_mask || bn_mask) && (!bn2_part || res)),
+                "pfr_conv2d_dgrad_bn: the streaming form (bnb mode 2) takes no accumulation, a bit mask with the masked join, a second BN only with the join");
   BnbArgs b;
   b.x[0] = bn_x; b.coef[0] = bn_coef; b.part[0] = bn_part;
   b.x[1] = bn2_x; b.coef[1] = bn2_coef; b.part[1] = bn2_part;
   b.mask = bn_mask;
+  b.flags = flags;
   return conv2d_fwd_impl(dy, wt, dx, dtype, dtype, N, H, W, C, Cout, R, S, 1, pad, idil_log2, OH, OW, Cout, nullptr, res, accumulate,
                          0, nullptr, nullptr, 0, nullptr, res_mask, stream, &b);
+}
+extern "C" int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout,
+                                   int R, int S, int pad, int idil_log2, int OH, int OW, const void* res,
+                                   const unsigned char* res_mask, int accumulate, const void* bn_x, const float* bn_coef,
+                                   const unsigned char* bn_mask, float* bn_part, const void* bn2_x, const float* bn2_coef,
+                                   float* bn2_part, hipStream_t stream) {
+  return dgrad_bn_impl(dy, wt, dx, dtype, N, H, W, C, Cout, R, S, pad, idil_log2, OH, OW, res, res_mask, accumulate, bn_x, bn_coef, bn_mask,
+                       bn_part, bn2_x, bn2_coef, bn2_part, 0, stream);
+}
+// the same with `flags` (streaming form + bit mask only): 1 = dx is stored THROUGH bn_mask (dx = g*mask: every consumer of a block-output
+// gradient reads it through that mask, so they may then read it plainly); 2 = the first BN's input is not read: only sum g*mask is
+// produced (row 1 of bn_part = 0; bn_x / bn_coef may be NULL) — for the BN-input-free backward of pfr_bn3_bwd_coef
+extern "C" int pfr_conv2d_dgrad_bn_ex(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout,
+                                      int R, int S, int pad, int idil_log2, int OH, int OW, const void* res,
+                                      const unsigned char* res_mask, int accumulate, const void* bn_x, const float* bn_coef,
+                                      const unsigned char* bn_mask, float* bn_part, const void* bn2_x, const float* bn2_coef,
+                                      float* bn2_part, int flags, hipStream_t stream) {
+  return dgrad_bn_impl(dy, wt, dx, dtype, N, H, W, C, Cout, R, S, pad, idil_log2, OH, OW, res, res_mask, accumulate, bn_x, bn_coef, bn_mask,
+                       bn_part, bn2_x, bn2_coef, bn2_part, flags, stream);
 }
 
 // dx = dgrad(dy) + up2(res_compact) + BN sums: the main-branch data gradient of a block whose projection shortcut is a 1x1 / stride-2
@@ -891,10 +914,11 @@ extern "C" int pfr_conv2d_dgrad_bn(const void* dy, const void* wt, void* dx, int
 // [N][OH/2][OW/2][Cout] and added here at the pixels with even (oh, ow) — instead of a scattered accumulate pass over dx — and the
 // launch leaves the BatchNorm-backward sums of the BN whose output gradient dx is (bit mask), as pfr_conv2d_dgrad_bn.  Streaming
 // kernels only: pfr_conv2d_dgrad_bn_parts (with pfr_set_tuning("bnb", 2)) > 0 and even OH, OW are required.
-extern "C" int pfr_conv2d_dgrad_bn_sub(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int OH,
-                                       int OW, const void* res_compact, const void* bn_x, const float* bn_coef,
-                                       const unsigned char* bn_mask, float* bn_part, hipStream_t stream) {
-  PFR_CHECK_ARG(dy && wt && dx && res_compact && bn_x && bn_coef && bn_mask && bn_part, "pfr_conv2d_dgrad_bn_sub: null pointer");
+static int dgrad_bn_sub_impl(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int OH, int OW,
+                             const void* res_compact, const void* bn_x, const float* bn_coef, const unsigned char* bn_mask,
+                             float* bn_part, int flags, hipStream_t stream) {
+  const bool nox = (flags & 2) != 0;
+  PFR_CHECK_ARG(dy && wt && dx && res_compact && bn_mask && bn_part && (nox || (bn_x && bn_coef)), "pfr_conv2d_dgrad_bn_sub: null pointer");
   PFR_CHECK_ARG(sconv_bnb_mode() == 2 && OH == H && OW == W && !(OH & 1) && !(OW & 1) &&
                     pfr_conv2d_dgrad_bn_parts(dtype, N, H, W, C, Cout, 1, 1, 0, OH, OW) > 0,
                 "pfr_conv2d_dgrad_bn_sub: needs the streaming form (bnb mode 2, an eligible 1x1 geometry, even extents)");
@@ -903,8 +927,20 @@ extern "C" int pfr_conv2d_dgrad_bn_sub(const void* dy, const void* wt, void* dx,
   b.x[1] = nullptr; b.coef[1] = nullptr; b.part[1] = nullptr;
   b.mask = bn_mask;
   b.res_sub = 1;
+  b.flags = flags;
   return conv2d_fwd_impl(dy, wt, dx, dtype, dtype, N, H, W, C, Cout, 1, 1, 1, 0, 0, OH, OW, Cout, nullptr, res_compact, 0, 0, nullptr,
                          nullptr, 0, nullptr, nullptr, stream, &b);
+}
+extern "C" int pfr_conv2d_dgrad_bn_sub(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int OH,
+                                       int OW, const void* res_compact, const void* bn_x, const float* bn_coef,
+                                       const unsigned char* bn_mask, float* bn_part, hipStream_t stream) {
+  return dgrad_bn_sub_impl(dy, wt, dx, dtype, N, H, W, C, Cout, OH, OW, res_compact, bn_x, bn_coef, bn_mask, bn_part, 0, stream);
+}
+// with the flags of pfr_conv2d_dgrad_bn_ex
+extern "C" int pfr_conv2d_dgrad_bn_sub_ex(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int C, int Cout, int OH,
+                                          int OW, const void* res_compact, const void* bn_x, const float* bn_coef,
+                                          const unsigned char* bn_mask, float* bn_part, int flags, hipStream_t stream) {
+  return dgrad_bn_sub_impl(dy, wt, dx, dtype, N, H, W, C, Cout, OH, OW, res_compact, bn_x, bn_coef, bn_mask, bn_part, flags, stream);
 }
 
 static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int out_dtype, int N, int H, int W,
@@ -931,7 +967,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, void* y, int dtype, int
   p.act = 0; p.y2 = nullptr; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = res_mask; p.res_sub = 0;
   p.bnb_mask = nullptr;
   for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
-  if (bnb) { p.res_sub = bnb->res_sub; p.bnb_mask = bnb->mask; for (int q = 0; q < 2; ++q) { p.bnb_x[q] = bnb->x[q]; p.bnb_coef[q] = bnb->coef[q]; p.bnb_part[q] = bnb->part[q]; } }
+  if (bnb) { p.res_sub = bnb->res_sub; p.bnb_flags = bnb->flags; p.bnb_mask = bnb->mask; for (int q = 0; q < 2; ++q) { p.bnb_x[q] = bnb->x[q]; p.bnb_coef[q] = bnb->coef[q]; p.bnb_part[q] = bnb->part[q]; } }
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   if (stats_part) p.want_mtile = pfr_conv2d_mtile(N, H, W, C, Cout, R, S, stride, pad, OH, OW, dtype, out_dtype, pro_scale != nullptr);
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));

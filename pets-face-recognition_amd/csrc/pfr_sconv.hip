@@ -50,6 +50,8 @@ struct SconvParams {
   const void* bnx2;
   const float* bn_coef2;
   float* bn_part2;
+  int store_masked;       // BNB with a bit mask: y is stored THROUGH the mask (g*mask; every consumer of a block-output gradient
+                          // reads it through that mask anyway, so they may then skip it: pfr_conv2d_dgrad_bn_ex)
   int npanels, nranges, R;    // R: rows per range (multiple of the 32-row block height)
   int npw;                    // couts of a workgroup's weight panel (64, 128 or 256)
   int interleave;             // 1: block-interleaved row assignment (needs M % 32 == 0 and M / 32 divisible by nranges)
@@ -64,12 +66,15 @@ struct SconvParams {
 // holds bf16), i.e. one more bf16 rounding of the pre-activation than the tile kernel's fp32 epilogue.
 // EP 4: plain data gradient + the BatchNorm-backward sums of the BN it feeds (mask recomputed or bit mask); EP 5: the join + those
 // sums (bit mask) — pfr_bn_bwd_reduce's pass over (gradient, BN input, mask) becomes one extra row read in this epilogue.
+// EP 7 / 8 = EP 5 / 6 WITHOUT the first BN's input: only sum g*mask is produced for it (row 1 of its partials = 0) — the
+// BN-input-free backward of pfr_bnfree.hip gets sum g*mask*xhat from the weight-gradient GEMM instead; no x row read, no coefficients.
 template <int TP, int NS, bool STATS, int EP = 0>
 __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
-  constexpr bool JOIN = EP == 1 || EP == 5 || EP == 6;
-  constexpr bool HASRES = EP == 1 || EP == 3 || EP == 5 || EP == 6;
-  constexpr bool BNB = EP == 4 || EP == 5 || EP == 6;
-  constexpr bool BNB2 = EP == 6;     // + the projection-shortcut BN of the previous block (same g, same mask, its own x)
+  constexpr bool JOIN = EP == 1 || EP == 5 || EP == 6 || EP == 7 || EP == 8;
+  constexpr bool HASRES = EP == 1 || EP == 3 || EP == 5 || EP == 6 || EP == 7 || EP == 8;
+  constexpr bool BNB = EP == 4 || EP == 5 || EP == 6 || EP == 7 || EP == 8;
+  constexpr bool BNB2 = EP == 6 || EP == 8;     // + the projection-shortcut BN of the previous block (same g, same mask, its own x)
+  constexpr bool NOX = EP == 7 || EP == 8;      // the first BN's input is not read (bit mask required)
   constexpr bool INFER = EP == 2 || EP == 3;
   static_assert(!(STATS && EP != 0), "only the plain variant publishes statistics");
   constexpr int NPV = TP * 32;           // couts per wave
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   constexpr int SB = NPV / 16;           // store instructions per block (32 rows x NPV couts x 2 B / 1 KiB)
   // residual (+ mask) and BN-input (+ mask) load instructions per block (BNB always issues its mask-byte load: with a recomputed
   // mask it reads one dummy byte, the count per block stays a compile-time constant)
-  constexpr int RL = (JOIN ? 2 * SB : (HASRES ? SB : 0)) + (BNB ? 2 * SB : 0) + (BNB2 ? SB : 0);
+  constexpr int RL = (JOIN ? 2 * SB : (HASRES ? SB : 0)) + (BNB ? (NOX ? SB : 2 * SB) : 0) + (BNB2 ? SB : 0);
   extern __shared__ __attribute__((aligned(128))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -146,11 +151,15 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = n0 + g * 64 + e_ch0 * 8 + e;
-        const float mu = p.bn_coef[c], is = p.bn_coef[p.N + c];
-        bca[g][e] = is;
-        bcb[g][e] = -mu * is;
-        bsc[g][e] = bn_bits ? 0.f : p.bn_coef[2 * p.N + c];
-        bsh[g][e] = bn_bits ? 1.f : p.bn_coef[3 * p.N + c];
+        if constexpr (NOX) {
+          bca[g][e] = 0.f; bcb[g][e] = 0.f; bsc[g][e] = 0.f; bsh[g][e] = 1.f;
+        } else {
+          const float mu = p.bn_coef[c], is = p.bn_coef[p.N + c];
+          bca[g][e] = is;
+          bcb[g][e] = -mu * is;
+          bsc[g][e] = bn_bits ? 0.f : p.bn_coef[2 * p.N + c];
+          bsh[g][e] = bn_bits ? 1.f : p.bn_coef[3 * p.N + c];
+        }
       }
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
@@ -329,10 +338,11 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
       for (int g = 0; g < NCG; ++g)
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
-                       : "=v"(bxr[g][ps])
-                       : "v"(y_lane + (uint32_t)(g * 128)), "s"(bxrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
-                       : "memory");
+          if constexpr (!NOX)
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+                         : "=v"(bxr[g][ps])
+                         : "v"(y_lane + (uint32_t)(g * 128)), "s"(bxrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
+                         : "memory");
           // (recomputed mask: the descriptor covers 16 bytes of y, every lane reads byte 0 or gets the out-of-range zero)
           asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen"
                        : "=v"(bmk[g][ps])
@@ -434,11 +444,16 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
               if (p.relu) f[e] = fmaxf(f[e], 0.f);
             }
           }
-          const u32x4 o = Chunk<bf16_t>::pack(f);
+          u32x4 o = Chunk<bf16_t>::pack(f);
           if constexpr (BNB) {
             // sums over the value AS STORED (what pfr_bn_bwd_reduce would read back) through the BN's own ReLU mask
             float xv[8];
-            Chunk<bf16_t>::unpack(bxr[g][ps], xv);
+            if constexpr (NOX) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) xv[e] = 0.f;
+            } else {
+              Chunk<bf16_t>::unpack(bxr[g][ps], xv);
+            }
             const uint32_t bits = bmk[g][ps];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -450,9 +465,12 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
                 const bool keep = bn_bits ? ((bits >> q) & 1u) != 0 : fmaf(xv[q], bsc[g][q], bsh[g][q]) > 0.f;
                 gm[h] = keep ? gs[h] : 0.f;
               }
-              const f32x2 xh = {fmaf(xv[2 * e], bca[g][2 * e], bcb[g][2 * e]), fmaf(xv[2 * e + 1], bca[g][2 * e + 1], bcb[g][2 * e + 1])};
+              if (p.store_masked) o[e] = (__float_as_uint(gm[0]) >> 16) | (__float_as_uint(gm[1]) & 0xffff0000u);
               b1[g][e] += gm;
-              b2[g][e] = __builtin_elementwise_fma(gm, xh, b2[g][e]);
+              if constexpr (!NOX) {
+                const f32x2 xh = {fmaf(xv[2 * e], bca[g][2 * e], bcb[g][2 * e]), fmaf(xv[2 * e + 1], bca[g][2 * e + 1], bcb[g][2 * e + 1])};
+                b2[g][e] = __builtin_elementwise_fma(gm, xh, b2[g][e]);
+              }
               if constexpr (BNB2) {
                 const float x0 = __uint_as_float(cxr[g][ps][e] << 16), x1 = __uint_as_float(cxr[g][ps][e] & 0xffff0000u);
                 const f32x2 yh = {fmaf(x0, cca[g][2 * e], ccb[g][2 * e]), fmaf(x1, cca[g][2 * e + 1], ccb[g][2 * e + 1])};
@@ -654,8 +672,11 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   if (p.accumulate && !acc_inplace) return 1;
   // BatchNorm-backward sums in the epilogue (pfr_conv2d_dgrad_bn): one BN, no statistics / bias; with the join its bit mask is required
   const bool bnb = p.bnb_part[0] != nullptr;
-  if (bnb && (sconv_bnb_mode() != 2 || p.bias || p.stats_part || p.out_relu || (p.residual && !p.bnb_mask) ||
-              (p.bnb_part[1] && !(p.residual && p.bnb_mask))))
+  // (a residual WITHOUT its mask is a plain add and goes with either kind of BN mask; a masked residual = the block join = bit mask)
+  const bool nox = bnb && (p.bnb_flags & 2);
+  if (bnb && (sconv_bnb_mode() != 2 || p.bias || p.stats_part || p.out_relu || (p.residual && p.res_mask && !p.bnb_mask) ||
+              (p.bnb_part[1] && !(p.residual && p.bnb_mask)) || (nox && !(p.residual && p.bnb_mask)) ||
+              ((p.bnb_flags & 1) && !p.bnb_mask)))
     return 1;
   // inference form: bias (+ plain residual add) (+ ReLU), no statistics; training forms: no bias / ReLU, residual only as the join
   const bool infer = p.bias != nullptr;
@@ -679,6 +700,7 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.bias = p.bias; sp.relu = p.out_relu;
   sp.bnx = p.bnb_x[0]; sp.bn_coef = p.bnb_coef[0]; sp.bn_mask = p.bnb_mask; sp.bn_part = p.bnb_part[0];
   sp.bnx2 = p.bnb_x[1]; sp.bn_coef2 = p.bnb_coef[1]; sp.bn_part2 = p.bnb_part[1];
+  sp.store_masked = bnb ? (p.bnb_flags & 1) : 0;
   sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
   static const bool il_on = !(getenv("PFR_SCONV_INTERLEAVE") && getenv("PFR_SCONV_INTERLEAVE")[0] == '0');
   sp.interleave = (il_on && p.M % 32 == 0 && (p.M / 32) % pl.nranges == 0 && (long)pl.R * pl.nranges == p.M) ? 1 : 0;
@@ -686,7 +708,8 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.div_ohow = p.div_ohow; sp.div_ow = p.div_ow;
   if (bnb) {   // 64-cout column slices keep the residual / BN-input rows and both sums inside the register budget
     pl.tp = 2;
-    if (p.bnb_part[1]) return sconv_launch_ns<2, false, 6>(sp, pl, st);
+    if (p.bnb_part[1]) return nox ? sconv_launch_ns<2, false, 8>(sp, pl, st) : sconv_launch_ns<2, false, 6>(sp, pl, st);
+    if (nox) return sconv_launch_ns<2, false, 7>(sp, pl, st);
     return p.residual ? sconv_launch_ns<2, false, 5>(sp, pl, st) : sconv_launch_ns<2, false, 4>(sp, pl, st);
   }
   if (infer) {

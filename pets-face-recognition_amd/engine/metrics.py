@@ -57,7 +57,8 @@ class PairStats:
         z = torch.zeros(1, dtype=torch.long)
         tps, fps = torch.cat([z, tps]), torch.cat([z, fps])
         thr = torch.cat([self.s[self.ends][:1] + 1, self.s[self.ends]])
-        return fps / fps[-1], tps / tps[-1], thr
+        # (a set without impostor / without genuine pairs: rates 0 instead of torchmetrics' 0/0 = nan)
+        return fps / fps[-1].clamp_min(1), tps / tps[-1].clamp_min(1), thr
 
     def auroc(self):
         tps, fps = self._counts()

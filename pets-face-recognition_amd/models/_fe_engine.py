@@ -189,6 +189,12 @@ class FEEngine:
         # stem tail backward without the max-pool gradient tensor (-1.1 GB of HBM traffic per step at bs 256): measured neutral
         # (0.57 vs 0.62 ms; the gather is vector-ALU bound), bit-identical, opt-in like PFR_FUSE_BNB
         self.fuse_pool = os.environ.get("PFR_FUSE_POOL", "0") == "1"
+        # BN-input-free backward of a bottleneck's conv3 + bn3 (csrc/pfr_bnfree.hip; round 4): the gradient that reaches the block
+        # output is stored THROUGH the block's ReLU mask by its producer, bn3's backward sums come out of the weight-gradient GEMM, and
+        # conv3's data gradient is G·(A∘W) + z2·S + bias — bn3's input and its gradient are never read / written in the backward pass.
+        # bf16 streaming geometries only (layer1-2 of ResNet-50 at bs 256); PFR_BNFREE=0 keeps the materialised form everywhere.
+        self.bnfree = os.environ.get("PFR_BNFREE", "1") != "0" and self.dtype == torch.bfloat16 and self.fuse_bnb == 2
+        self.ws_main = None             # split-K workspace of weight-gradient launches on the MAIN stream (self.ws belongs to the side stream)
         self.grad_ready_hook = None     # callable(lo, hi): flat-grad range [lo, hi) is final (DDP bucket hook)
         self.hook_syncs_side = False    # True: the hook makes ITS stream wait for self.side (the main stream then never waits at a mark)
         self.bucket_elems = 6 * 1024 * 1024
@@ -694,6 +700,27 @@ class FEEngine:
             ops.append(("srec", (k,)))
             pending[dy.data_ptr()] = k
 
+        ws_main_need = [0]
+
+        def wgrad_main(x, xshape, dy, dyshape, c, out):
+            """a weight-gradient GEMM on the MAIN stream (its result feeds the next launches), into `out`, own split-K workspace"""
+            Nq, Hq, Wq, Cq = xshape
+            _, OH, OW, Co = dyshape
+            KK = c.R * c.S * Cq
+            splits = lib.pfr_conv2d_wgrad_splits(Nq * OH * OW, Co, KK)
+            ws_main_need[0] = max(ws_main_need[0], splits * Co * KK)
+            ops.append(("wgrad_main", (x.data_ptr(), dy.data_ptr(), out.data_ptr(), None, self.did, Nq, Hq, Wq, Cq, Co, c.R, c.S,
+                                       c.stride, c.pad, OH, OW, Co, 0, 0, 0, 1.0, 0)))
+
+        def side_op(fn, args):
+            """any launch on the side stream (fork / record like a weight gradient) → its index for a later ("wait", k)"""
+            k = nside[0]
+            nside[0] += 1
+            ops.append(("fork", (k,)))
+            ops.append(("sideop", (fn, args)))
+            ops.append(("srec", (k,)))
+            return k
+
         def dgrad(dy, dyshape, c, dx, dxshape, accumulate=0):
             log2 = {1: 0, 2: 1}[c.stride]
             self._conv_fwd(ops, dy, dyshape, c.wt, dx, c, 1, c.R - 1 - c.pad, dxshape[1], dxshape[2], idil=log2,
@@ -738,17 +765,22 @@ class FEEngine:
             return lib.pfr_conv2d_dgrad_bn_parts(self.did, dyshape[0], dyshape[1], dyshape[2], dyshape[3], c.Cin, c.R, c.S,
                                                  {1: 0, 2: 1}[c.stride], dxshape[1], dxshape[2])
 
-        def dgrad_bn(dy, dyshape, c, dx, dxshape, bn1, bn2=None, res=None, res_mask=None, accumulate=0):
-            """data gradient + BN-backward partial sums; bn1 = (x, bn record, bit mask or None, part), bn2 = (x, bn record, part)"""
+        def dgrad_bn(dy, dyshape, c, dx, dxshape, bn1, bn2=None, res=None, res_mask=None, accumulate=0, flags=0, wt=None):
+            """data gradient + BN-backward partial sums; bn1 = (x, bn record, bit mask or None, part), bn2 = (x, bn record, part);
+            flags: pfr_conv2d_dgrad_bn_ex (1 = store through the bit mask, 2 = no input for bn1)"""
             x1, b1, mk, p1 = bn1
             x2p = c2p = p2p = 0
             if bn2 is not None:
                 x2p, c2p, p2p = bn2[0].data_ptr(), bn2[1].coef.data_ptr(), bn2[2].data_ptr()
-            ops.append((lib.pfr_conv2d_dgrad_bn, (dy.data_ptr(), c.wt.data_ptr(), dx.data_ptr(), self.did, dyshape[0], dyshape[1],
-                                                  dyshape[2], dyshape[3], c.Cin, c.R, c.S, c.R - 1 - c.pad, {1: 0, 2: 1}[c.stride],
-                                                  dxshape[1], dxshape[2], 0 if res is None else res.data_ptr(),
-                                                  0 if res_mask is None else res_mask.data_ptr(), accumulate, x1.data_ptr(),
-                                                  b1.coef.data_ptr(), 0 if mk is None else mk.data_ptr(), p1.data_ptr(), x2p, c2p, p2p)))
+            args = (dy.data_ptr(), (c.wt if wt is None else wt).data_ptr(), dx.data_ptr(), self.did, dyshape[0], dyshape[1],
+                    dyshape[2], dyshape[3], c.Cin, c.R, c.S, c.R - 1 - c.pad, {1: 0, 2: 1}[c.stride],
+                    dxshape[1], dxshape[2], 0 if res is None else res.data_ptr(),
+                    0 if res_mask is None else res_mask.data_ptr(), accumulate, 0 if x1 is None else x1.data_ptr(),
+                    b1.coef.data_ptr(), 0 if mk is None else mk.data_ptr(), p1.data_ptr(), x2p, c2p, p2p)
+            if flags:
+                ops.append((lib.pfr_conv2d_dgrad_bn_ex, args + (flags,)))
+            else:
+                ops.append((lib.pfr_conv2d_dgrad_bn, args))
 
         acc = 0  # placeholder: _finalize_plan emits an overwrite (0) and an accumulate (1) variant of every grad write
         # fc
@@ -766,6 +798,38 @@ class FEEngine:
         # blocks in reverse
         nblk = len(self.blocks)
         pre3 = {}     # block index -> partial sums of its last BN / projection BN left by the producer of its output gradient
+        # BN-input-free backward (pfr_bnfree.hip): geometry test per block, and — on the side stream, ahead of their use — the two
+        # quantities that depend on forward values only: G2 = z2ᵀz2 and the column sums of z2
+        bnf = {}        # block index -> dict(G2, zsum, side index, npart of conv3's streaming data gradient)
+        premasked = {}  # block index -> True: the gradient at its output was stored through the block's ReLU mask by its producer
+        if self.bnfree:
+            for k in range(nblk - 1):
+                convs, _ = self.blocks[k]
+                _, _, raws, _, _, oshape, acts = bsaved[k]
+                if len(convs) != 3 or acts[1] is None:
+                    continue
+                c3 = convs[2][0]
+                zs = raws[1][1]
+                if c3.R != 1 or c3.stride != 1 or c3.Cin not in (64, 128, 256) or c3.Cout % 64:
+                    continue
+                npart = dgrad_parts(oshape, c3, zs)
+                if npart <= 0:
+                    continue
+                rows = zs[0] * zs[1] * zs[2]
+                G2 = self._A(plan, (c3.Cin, c3.Cin), torch.float32)
+                zsum = self._A(plan, (c3.Cin,), torch.float32)
+                cws = self._A(plan, (max(1, lib.pfr_colsum_ws_floats(rows, c3.Cin)),), torch.float32)
+                wgrad(acts[1], zs, acts[1], zs, c3, out=G2)
+                kk = side_op(lib.pfr_colsum, (acts[1].data_ptr(), self.did, rows, c3.Cin, zsum.data_ptr(), 0, cws.data_ptr()))
+                bnf[k] = dict(G2=G2, zsum=zsum, side=kk, npart=npart)
+            if bnf:
+                cmax = max(self.blocks[k][0][2][0].Cout for k in bnf)
+                kmax = max(self.blocks[k][0][2][0].Cin for k in bnf)
+                bnf_G1 = self._A(plan, (cmax * kmax,), torch.float32)
+                bnf_coef = self._A(plan, (3 * cmax,), torch.float32)
+                bnf_wat = self._A(plan, (cmax * kmax,))
+                bnf_S = self._A(plan, (kmax * kmax,))
+                bnf_bias = self._A(plan, (kmax,), torch.float32)
         for k in range(nblk - 1, -1, -1):
             convs, down = self.blocks[k]
             xin, xshape, raws, cd, out, oshape, acts = bsaved[k]
@@ -773,12 +837,41 @@ class FEEngine:
             ylast, _ = raws[-1]
             # BN(last) + residual + ReLU backward.  `out` is the block's ReLU bit mask; dcur (the gradient that arrived at
             # the block output) is KEPT: the residual branch consumes it through the same mask (no masked copy is written)
-            dz3 = G(oshape)
             p3 = pre3.get(k)
-            bn_bwd(dcur, out, ylast, oshape, lastbn, 3, dz3, None, acc, pre=None if p3 is None else p3[0])
             rmask = out
-            dy, dyshape = dz3, oshape
-            for i in range(len(convs) - 1, 0, -1):
+            free3 = k in bnf and premasked.get(k, False) and p3 is not None
+            if free3:
+                # conv3 + bn3 without bn3's input (pfr_bnfree.hip).  dcur holds G = g∘mask already.
+                c3, bn3 = convs[2]
+                _, bn2 = convs[1]
+                z2, (c2raw, zs) = acts[1], raws[1]
+                f = bnf[k]
+                C3, K3, rows3 = c3.Cout, c3.Cin, float(oshape[0] * oshape[1] * oshape[2])
+                wgrad_main(z2, zs, dcur, oshape, c3, bnf_G1)                                   # G1 = Gᵀ z2
+                ops.append(("wait", (f["side"],)))                                              # G2, zsum (side stream, issued long ago)
+                part3, np3 = p3[0]
+                Wm = self.master.data_ptr() + 4 * c3.off
+                ops.append((lib.pfr_bn3_bwd_coef, (part3.data_ptr(), np3, bnf_G1.data_ptr(), f["zsum"].data_ptr(), Wm, bn3.gamma.data_ptr(),
+                                                   bn3.coef[1].data_ptr(), C3, K3, rows3, bn3.dgamma.data_ptr(), bn3.dbeta.data_ptr(),
+                                                   bnf_coef.data_ptr(), acc)))
+                ops.append((lib.pfr_bn3_bwd_weights, (bnf_coef.data_ptr(), bnf_G1.data_ptr(), f["G2"].data_ptr(), f["zsum"].data_ptr(), Wm,
+                                                      C3, K3, rows3, c3.g.data_ptr(), bnf_wat.data_ptr(), bnf_S.data_ptr(),
+                                                      bnf_bias.data_ptr(), acc)))
+                release(part3)
+                y1 = G(zs)
+                ops.append((lib.pfr_conv2d_fwd, (z2.data_ptr(), bnf_S.data_ptr(), y1.data_ptr(), self.did, self.did, zs[0], zs[1], zs[2], K3, K3,
+                                                 1, 1, 1, 0, 0, zs[1], zs[2], K3, bnf_bias.data_ptr(), 0, 0, 0, 0, 0, 0, 0)))
+                dz2 = G(zs)
+                part2 = G((f["npart"], 2, K3), torch.float32)
+                dgrad_bn(dcur, oshape, c3, dz2, zs, (c2raw, bn2, None, part2), res=y1, wt=bnf_wat)
+                release(y1)
+                bn_bwd(dz2, None, c2raw, zs, bn2, 2, dz2, None, acc, pre=(part2, f["npart"]))
+                dy, dyshape = dz2, zs
+            else:
+                dz3 = G(oshape)
+                bn_bwd(dcur, out, ylast, oshape, lastbn, 3, dz3, None, acc, pre=None if p3 is None else p3[0])
+                dy, dyshape = dz3, oshape
+            for i in range(len(convs) - 1 - (1 if free3 else 0), 0, -1):
                 c, bn = convs[i]
                 pc, pbn = convs[i - 1]
                 xraw, xrs = raws[i - 1]
@@ -830,9 +923,14 @@ class FEEngine:
                     comp = G((xshape[0], oshape[1], oshape[2], xshape[3]))
                     self._conv_fwd(ops, dgd, oshape, dc.wt, comp, dc, 1, 0, oshape[1], oshape[2], idil=0, Cout=dc.Cin)
                     part = G((npart3, 2, xshape[3]), torch.float32)
-                    ops.append((lib.pfr_conv2d_dgrad_bn_sub, (dy.data_ptr(), c0.wt.data_ptr(), dxin.data_ptr(), self.did, dyshape[0], dyshape[1],
-                                                              dyshape[2], dyshape[3], c0.Cin, xshape[1], xshape[2], comp.data_ptr(),
-                                                              nxt[0].data_ptr(), nxt[1].coef.data_ptr(), nxt[2].data_ptr(), part.data_ptr())))
+                    sub_args = (dy.data_ptr(), c0.wt.data_ptr(), dxin.data_ptr(), self.did, dyshape[0], dyshape[1], dyshape[2], dyshape[3],
+                                c0.Cin, xshape[1], xshape[2], comp.data_ptr(), nxt[0].data_ptr(), nxt[1].coef.data_ptr(),
+                                nxt[2].data_ptr(), part.data_ptr())
+                    if (k - 1) in bnf:      # the previous block takes the BN-input-free backward: its output gradient leaves masked
+                        ops.append((lib.pfr_conv2d_dgrad_bn_sub_ex, sub_args + (1,)))
+                        premasked[k - 1] = True
+                    else:
+                        ops.append((lib.pfr_conv2d_dgrad_bn_sub, sub_args))
                     pre3[k - 1] = ((part, npart3), None)
                     release(comp)
                     npart = -1
@@ -868,7 +966,10 @@ class FEEngine:
                     part = G((npart, 2, xshape[3]), torch.float32)
                     part2 = G((npart, 2, xshape[3]), torch.float32) if nxt[3] is not None else None
                     dgrad_bn(dy, dyshape, c0, dxin, xshape, (nxt[0], nxt[1], nxt[2], part),
-                             None if part2 is None else (nxt[3], nxt[4], part2), res=dcur, res_mask=rmask)
+                             None if part2 is None else (nxt[3], nxt[4], part2), res=dcur, res_mask=rmask,
+                             flags=1 if (k - 1) in bnf else 0)
+                    if (k - 1) in bnf:
+                        premasked[k - 1] = True
                     pre3[k - 1] = ((part, npart), None if part2 is None else (part2, npart))
                 else:
                     ops.append((lib.pfr_conv2d_dgrad_join, (dy.data_ptr(), c0.wt.data_ptr(), dxin.data_ptr(), self.did, dyshape[0],
@@ -918,6 +1019,9 @@ class FEEngine:
         if self.ws is None or self.ws.numel() < ws_need[0]:
             self.ws = torch.empty(ws_need[0], dtype=torch.float32, device=self.device)
         plan.meta["ws_need"] = ws_need[0]
+        if ws_main_need[0] and (self.ws_main is None or self.ws_main.numel() < ws_main_need[0]):
+            self.ws_main = torch.empty(ws_main_need[0], dtype=torch.float32, device=self.device)
+        plan.meta["bnfree_blocks"] = sorted(k for k in bnf if premasked.get(k))
         return plan
 
     def _mark(self, ops, off):
@@ -981,6 +1085,12 @@ class FEEngine:
                     a[3] = self.ws.data_ptr()
                     a[-1] = acc if fn == "wgrad" else 0
                     res.append((_SIDE, (lib.pfr_conv2d_wgrad, tuple(a))))
+                elif fn == "wgrad_main":
+                    a = list(args)
+                    a[3] = self.ws_main.data_ptr() if self.ws_main is not None else 0
+                    res.append((lib.pfr_conv2d_wgrad, tuple(a)))
+                elif fn == "sideop":
+                    res.append((_SIDE, (args[0], tuple(args[1]))))
                 elif fn == "fork":
                     res.append((_FORK, args[0]))
                 elif fn == "srec":
@@ -995,13 +1105,18 @@ class FEEngine:
                     res.append((lib.pfr_copy2d_f32, tuple(args[:-1]) + (acc,)))
                 elif fn == "s2dunpack":
                     res.append((lib.pfr_s2d_wgrad, tuple(args[:-1]) + (acc,)))
-                elif fn is lib.pfr_bn_bwd_finalize or fn is lib.pfr_bn_bwd_reduce_finalize:
+                elif fn is lib.pfr_bn_bwd_finalize or fn is lib.pfr_bn_bwd_reduce_finalize or fn is lib.pfr_bn3_bwd_coef \
+                        or fn is lib.pfr_bn3_bwd_weights:
                     res.append((fn, tuple(args[:-1]) + (acc,)))
                 else:
                     res.append((fn, args))
             plan.meta["bwd%d" % acc] = res
             plan.meta.pop("c_bwd%d" % acc, None)
-        plan.meta["ws_ptr"] = self.ws.data_ptr() if self.ws is not None else 0
+        plan.meta["ws_ptr"] = self._ws_key()
+
+    def _ws_key(self):
+        """the split-K workspaces a resolved plan has baked in (side stream, main stream)"""
+        return (self.ws.data_ptr() if self.ws is not None else 0, self.ws_main.data_ptr() if self.ws_main is not None else 0)
 
     def forward(self, x, train, with_backward, ticket=None):
         if x.dim() != 4 or x.shape[1] != self.stem[0].Cin:
@@ -1011,7 +1126,7 @@ class FEEngine:
         x = x.contiguous()
         N, _, H, W = x.shape
         plan = self.acquire_plan(N, H, W, train, with_backward, ticket if with_backward else None)
-        if with_backward and plan.meta.get("ws_ptr", 0) != (self.ws.data_ptr() if self.ws is not None else 0):
+        if with_backward and plan.meta.get("ws_ptr", 0) != self._ws_key():
             self._finalize_plan(plan)
         if plan.meta.get("folded") and self.graph_eval and _TRACER[0] is None:
             return self._forward_graphed(plan, x)
@@ -1153,7 +1268,7 @@ class FEEngine:
         if demb.numel() != plan.meta["demb"].numel():
             raise PfrError(f"backward: gradient of {tuple(demb.shape)} does not match the plan's embedding buffer "
                            f"{tuple(plan.meta['demb'].shape)}")
-        if plan.meta.get("ws_ptr", 0) != (self.ws.data_ptr() if self.ws is not None else 0):
+        if plan.meta.get("ws_ptr", 0) != self._ws_key():
             self._finalize_plan(plan)   # the shared weight-gradient workspace grew after this plan was resolved
         lib.pfr_cast(demb.data_ptr(), dtype_id(demb.dtype), plan.meta["demb"].data_ptr(), self.did, demb.numel(), stream)
         acc = 1 if self.first_param.grad is not None else 0

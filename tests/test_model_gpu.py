@@ -458,7 +458,8 @@ def test_streaming_bn_backward_sums_in_the_train_step(monkeypatch):
             grads.append(torch.cat([p.grad.flatten() for p in m.parameters()]).double().cpu())
             names = [f.__name__ for f, _ in m.hip_engine()._last_plan.meta["bwd0"] if hasattr(f, "__name__")]
             if flag == "2":
-                assert names.count("pfr_conv2d_dgrad_bn") >= 12, names.count("pfr_conv2d_dgrad_bn")
+                nfused = names.count("pfr_conv2d_dgrad_bn") + names.count("pfr_conv2d_dgrad_bn_ex")
+                assert nfused >= 12, nfused
             else:
                 assert names.count("pfr_conv2d_dgrad_bn") == 0
     finally:
@@ -467,3 +468,57 @@ def test_streaming_bn_backward_sums_in_the_train_step(monkeypatch):
     assert torch.isfinite(grads[1]).all()
     e = ((grads[0] - grads[1]).norm() / grads[0].norm()).item()
     assert e < 2e-2, e
+
+
+def test_bn_input_free_backward_of_conv3_bn3(monkeypatch):
+    """csrc/pfr_bnfree.hip (round 4): in layer1-2 of ResNet-50 the backward pass of conv3 + bn3 reads neither bn3's input nor
+    writes its gradient — the producer stores the block-output gradient through the ReLU mask, bn3's sums come out of the
+    weight-gradient GEMM, conv3's data gradient is G·(A∘W) + z2·S + bias.  Same mathematics, other rounding points: against the
+    fp64 oracle gradient the new path must be at least as close as the materialised one (whole gradient, and per tensor within
+    the bf16 noise of the old path), and the 7 eligible blocks must actually take it."""
+    from oracle import resnet_ref
+    from pets_face_recognition_amd._hip import lib
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = resnet_ref.init_state_dict("resnet50", 512, seed=11)
+    for k in sd:       # damped residual branches: see test_backbone_fwd_bwd_vs_oracle
+        if k.startswith("layer") and k.endswith(".bn3.weight"):
+            sd[k] = torch.full_like(sd[k], 0.2)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(8, 3, 128, 128, generator=g)
+    demb = torch.randn(8, 512, generator=g) * 0.05
+    names = resnet_ref.param_names(sd)
+    p64 = {k: (v.double().requires_grad_(True) if k in names else (v.double() if v.dtype.is_floating_point else v.clone()))
+           for k, v in sd.items()}
+    resnet_ref.forward(p64, x.double(), "resnet50", train=True).backward(demb.double())
+    res = {}
+    try:
+        lib.pfr_set_tuning(b"sconv", 2)      # small test batch: take every eligible geometry
+        for flag in ("0", "1"):
+            monkeypatch.setenv("PFR_BNFREE", flag)
+            m = build("resnet50", torch.bfloat16, sd).train()
+            emb = m(x.to(DEV))
+            emb.backward(demb.to(DEV))
+            torch.cuda.synchronize()
+            eng = m.hip_engine()
+            blocks = eng._last_plan.meta["bnfree_blocks"]
+            assert blocks == ([] if flag == "0" else [0, 1, 2, 3, 4, 5, 6]), blocks
+            res[flag] = ({n: p.grad.double().cpu() for n, p in m.named_parameters()}, emb.double().cpu())
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+        lib.pfr_set_tuning(b"bnb", 0)
+    assert torch.equal(res["0"][1], res["1"][1])          # the forward pass is the same launches
+    f64 = torch.cat([p64[n].grad.flatten() for n in res["0"][0]])
+    err = {}
+    for flag in ("0", "1"):
+        fl = torch.cat([res[flag][0][n].flatten() for n in res["0"][0]])
+        assert torch.isfinite(fl).all()
+        err[flag] = ((fl - f64).norm() / f64.norm()).item()
+    assert err["1"] <= 1.05 * err["0"] + 1e-3, err
+    worst = max(((res["1"][0][n] - p64[n].grad).norm() / (p64[n].grad.norm() + 1e-30)).item()
+                - 1.5 * ((res["0"][0][n] - p64[n].grad).norm() / (p64[n].grad.norm() + 1e-30)).item() for n in res["0"][0])
+    assert worst < 2e-2, worst
+    # the tensors the new path computes itself (bn3 / conv3 of layer1-2) against fp64: not worse than the materialised form
+    for n in ("layer1.1.bn3.weight", "layer1.1.bn3.bias", "layer1.1.conv3.weight", "layer2.2.bn3.weight", "layer2.2.conv3.weight"):
+        e1 = ((res["1"][0][n] - p64[n].grad).norm() / p64[n].grad.norm()).item()
+        e0 = ((res["0"][0][n] - p64[n].grad).norm() / p64[n].grad.norm()).item()
+        assert e1 <= 1.2 * e0 + 2e-3, (n, e1, e0)
