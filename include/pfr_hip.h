@@ -113,6 +113,17 @@ int pfr_conv2d_dgrad_bn_sub(const void* dy, const void* wt, void* dx, int dtype,
                             const void* res_compact, const void* bn_x, const float* bn_coef, const unsigned char* bn_mask,
                             float* bn_part, pfr_stream_t stream);
 
+/* Recompute form of a bottleneck's last convolution (1x1, stride 1; torchvision Bottleneck.forward `out = relu(bn3(conv3(z)) + identity)`)
+ * on the bf16 streaming kernel — the convolution output never reaches HBM: pfr_conv1x1_stats leaves only the BatchNorm partials (tile
+ * height pfr_conv1x1_tail_mtile = pfr_conv2d_mtile of the geometry; 0: not taken, use pfr_conv2d_fwd + pfr_bn_act_mask), and after
+ * pfr_bn_finalize pfr_conv1x1_bn_tail recomputes it and stores y = relu(a1*conv + b1 + (a2 ? a2*res + b2 : res)) with the ReLU bit mask
+ * of pfr_bn_act_mask; bit-identical to the stored form (both round the convolution to bf16 first). */
+int pfr_conv1x1_tail_mtile(int dtype, int N, int H, int W, int C, int Cout);
+int pfr_conv1x1_stats(const void* x, const void* w, int dtype, int N, int H, int W, int C, int Cout, float* stats_part,
+                      pfr_stream_t stream);
+int pfr_conv1x1_bn_tail(const void* x, const void* w, void* y, unsigned char* mask, int dtype, int N, int H, int W, int C, int Cout,
+                        const float* a1, const float* b1, const void* res, const float* a2, const float* b2, pfr_stream_t stream);
+
 /* The two launches above with `flags` (streaming form with a bit mask only): 1 = dx is stored THROUGH bn_mask (dx = g*mask: every consumer
  * of a block-output gradient — the BN backward of the block's last BN, its projection BN, the residual join — reads it through that mask,
  * so they may then read it plainly); 2 = the first BN's input is not read: only sum g*mask is produced (row 1 of bn_part = 0; bn_x and

@@ -69,6 +69,11 @@ __device__ __forceinline__ void buffer_store_b128_sync(u32x4 v, __amdgpu_buffer_
   asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_waitcnt expcnt(0)" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// one byte per lane, same discipline (the block tail's ReLU bit masks)
+__device__ __forceinline__ void buffer_store_byte_sync(uint32_t v, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  asm volatile("s_nop 4\n\tbuffer_store_byte %0, %1, %2, %3 offen\n\ts_waitcnt expcnt(0)" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ------------------------------------------------------------------------------------------------

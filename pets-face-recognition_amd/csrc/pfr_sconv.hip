@@ -25,6 +25,7 @@
 // rows are grouped.
 #include "pfr_igemm.h"
 #include <stdlib.h>
+#include <string.h>
 
 struct SconvParams {
   const void* x;
@@ -50,6 +51,10 @@ struct SconvParams {
   const void* bnx2;
   const float* bn_coef2;
   float* bn_part2;
+  // EP 10 / 11 (block tail): y = relu(a1*conv + b1 + (EP 10: res | EP 11: a2*res + b2)) on the bf16-rounded convolution value, and the
+  // sign of the pre-ReLU value as one bit per element (mask_out [M][N/8]) — pfr_bn_act_mask's arithmetic in this epilogue
+  const float* tail_a1; const float* tail_b1; const float* tail_a2; const float* tail_b2;
+  unsigned char* mask_out;
   int store_masked;       // BNB with a bit mask: y is stored THROUGH the mask (g*mask; every consumer of a block-output gradient
                           // reads it through that mask anyway, so they may then skip it: pfr_conv2d_dgrad_bn_ex)
   int npanels, nranges, R;    // R: rows per range (multiple of the 32-row block height)
@@ -68,20 +73,27 @@ struct SconvParams {
 // sums (bit mask) — pfr_bn_bwd_reduce's pass over (gradient, BN input, mask) becomes one extra row read in this epilogue.
 // EP 7 / 8 = EP 5 / 6 WITHOUT the first BN's input: only sum g*mask is produced for it (row 1 of its partials = 0) — the
 // BN-input-free backward of pfr_bnfree.hip gets sum g*mask*xhat from the weight-gradient GEMM instead; no x row read, no coefficients.
+// EP 9 (with STATS): statistics ONLY — the convolution is computed, rounded to bf16 and enters the BatchNorm partials exactly as in the
+// plain variant, but nothing is stored (first pass of the recompute form of a bottleneck's last convolution, pfr_conv1x1_stats).
+// EP 10 / 11: the second pass (pfr_conv1x1_bn_tail): the convolution again, then the block tail relu(bn3(.) + shortcut) and its ReLU
+// bit mask in the epilogue — the convolution output itself never reaches HBM.
 template <int TP, int NS, bool STATS, int EP = 0>
 __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   constexpr bool JOIN = EP == 1 || EP == 5 || EP == 6 || EP == 7 || EP == 8;
-  constexpr bool HASRES = EP == 1 || EP == 3 || EP == 5 || EP == 6 || EP == 7 || EP == 8;
+  constexpr bool HASRES = EP == 1 || EP == 3 || EP == 5 || EP == 6 || EP == 7 || EP == 8 || EP == 10 || EP == 11;
   constexpr bool BNB = EP == 4 || EP == 5 || EP == 6 || EP == 7 || EP == 8;
   constexpr bool BNB2 = EP == 6 || EP == 8;     // + the projection-shortcut BN of the previous block (same g, same mask, its own x)
   constexpr bool NOX = EP == 7 || EP == 8;      // the first BN's input is not read (bit mask required)
   constexpr bool INFER = EP == 2 || EP == 3;
-  static_assert(!(STATS && EP != 0), "only the plain variant publishes statistics");
+  constexpr bool NOSTORE = EP == 9;
+  constexpr bool TAIL = EP == 10 || EP == 11;
+  static_assert(!(STATS && EP != 0 && EP != 9) && !(EP == 9 && !STATS), "only the plain / statistics-only variants publish statistics");
   constexpr int NPV = TP * 32;           // couts per wave
   constexpr int GB = 4096;               // granule bytes: [32 rows][64 k] bf16
   constexpr int GI = 4;                  // DMA instructions per granule
   constexpr int NCG = NPV / 64;          // 64-cout column groups of the epilogue
-  constexpr int SB = NPV / 16;           // store instructions per block (32 rows x NPV couts x 2 B / 1 KiB)
+  constexpr int SB = NPV / 16;           // data store instructions per block (32 rows x NPV couts x 2 B / 1 KiB)
+  constexpr int SBT = NOSTORE ? 0 : (TAIL ? 2 * SB : SB);   // vector-memory STORE instructions a block's epilogue really issues (+ mask bytes)
   // residual (+ mask) and BN-input (+ mask) load instructions per block (BNB always issues its mask-byte load: with a recomputed
   // mask it reads one dummy byte, the count per block stays a compile-time constant)
   constexpr int RL = (JOIN ? 2 * SB : (HASRES ? SB : 0)) + (BNB ? (NOX ? SB : 2 * SB) : 0) + (BNB2 ? SB : 0);
@@ -132,6 +144,20 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
       for (int e = 0; e < 8; ++e) bias8[g][e] = p.bias[n0 + g * 64 + e_ch0 * 8 + e];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  float ta1[NCG][8], tb1[NCG][8], ta2[NCG][8], tb2[NCG][8];
+  __amdgpu_buffer_rsrc_t korsrc = __builtin_amdgcn_make_buffer_rsrc(TAIL ? (void*)p.mask_out : p.y, 0, TAIL ? p.M * (p.N >> 3) : 16, 0x00020000);
+  if constexpr (TAIL) {
+    const int e_ch0 = lane & 7;
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = n0 + g * 64 + e_ch0 * 8 + e;
+        ta1[g][e] = p.tail_a1[c]; tb1[g][e] = p.tail_b1[c];
+        ta2[g][e] = EP == 11 ? p.tail_a2[c] : 1.f; tb2[g][e] = EP == 11 ? p.tail_b2[c] : 0.f;
+      }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // BN-backward coefficients of this lane's 8 couts per column group (read-back layout): xhat = ca*x + cb, mask = sc*x + sh > 0
@@ -273,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
     // (join: the RL residual / mask loads of a block are issued at its start, which follows an epilogue: every epilogue in the
     //  window stands for SB stores + RL loads younger than the granule.  The first block's loads follow no epilogue and go
     //  uncounted: a smaller count than the true one only waits longer.)
-    constexpr int EV = SB + RL;
+    constexpr int EV = SBT + RL;
     if (ne == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI) : "memory");
     else if (ne == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + EV > 63 ? 63 : (NS - 1) * GI + EV) : "memory");
     else if (ne == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * GI + 2 * EV > 63 ? 63 : (NS - 1) * GI + 2 * EV) : "memory");
@@ -428,11 +454,22 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
             s2[g][e] = __builtin_elementwise_fma(d, d, s2[g][e]);
           }
         }
+        if constexpr (NOSTORE) continue;
         if constexpr (EP != 0) {
           float f[8], rr8[8];
           Chunk<bf16_t>::unpack(v, f);
           if constexpr (HASRES) Chunk<bf16_t>::unpack(rres[g][ps], rr8);
-          if constexpr (JOIN) {
+          if constexpr (TAIL) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float z = fmaf(f[e], ta1[g][e], tb1[g][e]);
+              z += fmaf(rr8[e], ta2[g][e], tb2[g][e]);
+              bits |= (z > 0.f ? 1u : 0u) << e;
+              f[e] = fmaxf(z, 0.f);
+            }
+            buffer_store_byte_sync(bits, korsrc, k_lane + (uint32_t)(g * 8), (uint32_t)(m0 * (p.N >> 3) + (n0 >> 3)) + (uint32_t)(ps * p.N));
+          } else if constexpr (JOIN) {
             const uint32_t bits = has_rmask ? rmk[g][ps] : 0xffu;
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += ((bits >> e) & 1u) ? rr8[e] : 0.f;
@@ -741,4 +778,62 @@ int sconv_mtile(int M, int N, int K, long in_rows, int dtype, int out_dtype) {
   SconvPlan pl;
   if (!sconv_plan(M, N, K, in_rows, dtype, out_dtype, &pl)) return 0;
   return pl.R;
+}
+
+// ------------------------------------------------------------------------------------------------ recompute form of a block's last conv
+// A bottleneck's last convolution (1x1, Cout = 4 x Cin) is HBM-bound on its OUTPUT: writing c3 and reading it back for the block tail
+// moves 8x the bytes of its input.  Since the backward pass no longer needs c3 (pfr_bnfree.hip), the forward pass computes it twice
+// instead: pfr_conv1x1_stats leaves only the BatchNorm partials, and — after pfr_bn_finalize — pfr_conv1x1_bn_tail recomputes the tile
+// and applies relu(a1*c3 + b1 + shortcut) (+ ReLU bit mask) in its epilogue, on the same bf16-rounded values the stored tensor held:
+// results are bit-identical to pfr_conv2d_fwd + pfr_bn_act_mask.
+static bool tail_geom(int dtype, int N, int H, int W, int C, int Cout, SconvPlan* pl) {
+  if (dtype != PFR_BF16 || (long)N * H * W >= ((long)1 << 31)) return false;
+  return sconv_plan(N * H * W, Cout, C, (long)N * H * W, dtype, dtype, pl);
+}
+// rows per statistics partial of pfr_conv1x1_stats (= pfr_conv2d_mtile of the same geometry), 0: geometry not taken by the streaming kernel
+extern "C" int pfr_conv1x1_tail_mtile(int dtype, int N, int H, int W, int C, int Cout) {
+  SconvPlan pl;
+  return tail_geom(dtype, N, H, W, C, Cout, &pl) ? pl.R : 0;
+}
+static void tail_params(SconvParams& sp, const SconvPlan& pl, const void* x, const void* w, int N, int H, int W, int C, int Cout) {
+  memset(&sp, 0, sizeof(sp));
+  sp.x = x; sp.w = w;
+  sp.M = N * H * W; sp.K = C; sp.N = Cout;
+  sp.H = H; sp.W = W; sp.OH = H; sp.OW = W; sp.ostride = 1;
+  sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
+  static const bool il_on = !(getenv("PFR_SCONV_INTERLEAVE") && getenv("PFR_SCONV_INTERLEAVE")[0] == '0');
+  sp.interleave = (il_on && sp.M % 32 == 0 && (sp.M / 32) % pl.nranges == 0 && (long)pl.R * pl.nranges == sp.M) ? 1 : 0;
+  sp.xbytes = (int)((long)sp.M * C * 2);
+  sp.div_ohow = make_fastdiv((uint32_t)(H * W)); sp.div_ow = make_fastdiv((uint32_t)W);
+}
+extern "C" int pfr_conv1x1_stats(const void* x, const void* w, int dtype, int N, int H, int W, int C, int Cout, float* stats_part,
+                                 hipStream_t st) {
+  PFR_CHECK_ARG(x && w && stats_part, "pfr_conv1x1_stats: null pointer");
+  SconvPlan pl;
+  if (!tail_geom(dtype, N, H, W, C, Cout, &pl)) {
+    pfr_set_error("pfr_conv1x1_stats: geometry not taken by the streaming kernel (pfr_conv1x1_tail_mtile == 0)");
+    return PFR_ERR_UNSUPPORTED;
+  }
+  SconvParams sp;
+  tail_params(sp, pl, x, w, N, H, W, C, Cout);
+  sp.y = stats_part;     // (descriptor base of dummy loads only: nothing is stored)
+  sp.stats_part = stats_part;
+  return pl.tp == 2 ? sconv_launch_ns<2, true, 9>(sp, pl, st) : sconv_launch_ns<4, true, 9>(sp, pl, st);
+}
+extern "C" int pfr_conv1x1_bn_tail(const void* x, const void* w, void* y, unsigned char* mask, int dtype, int N, int H, int W, int C,
+                                   int Cout, const float* a1, const float* b1, const void* res, const float* a2, const float* b2,
+                                   hipStream_t st) {
+  PFR_CHECK_ARG(x && w && y && mask && a1 && b1 && res, "pfr_conv1x1_bn_tail: null pointer");
+  PFR_CHECK_ARG((a2 == nullptr) == (b2 == nullptr), "pfr_conv1x1_bn_tail: a2 and b2 go together");
+  SconvPlan pl;
+  if (!tail_geom(dtype, N, H, W, C, Cout, &pl)) {
+    pfr_set_error("pfr_conv1x1_bn_tail: geometry not taken by the streaming kernel (pfr_conv1x1_tail_mtile == 0)");
+    return PFR_ERR_UNSUPPORTED;
+  }
+  SconvParams sp;
+  tail_params(sp, pl, x, w, N, H, W, C, Cout);
+  sp.y = y; sp.res = res; sp.mask_out = mask;
+  sp.tail_a1 = a1; sp.tail_b1 = b1; sp.tail_a2 = a2; sp.tail_b2 = b2;
+  if (a2) { pl.tp = 2; return sconv_launch_ns<2, false, 11>(sp, pl, st); }   // (64-cout slices: four coefficient sets in registers)
+  return pl.tp == 2 ? sconv_launch_ns<2, false, 10>(sp, pl, st) : sconv_launch_ns<4, false, 10>(sp, pl, st);
 }

@@ -561,6 +561,60 @@ class FEEngine:
         self._bn_fwd(ops, bn, part, nt, N * OH * OW, train, mt)
         return y, (N, OH, OW, c.Cout)
 
+    def _dgrad_parts(self, dyshape, c, dxshape, two_bns=False, accumulates=False):
+        """partial rows per BN of a data-gradient launch that also leaves BatchNorm-backward sums (0: separate reduce pass)"""
+        if not self.fuse_bnb or (self.fuse_bnb == 2 and (two_bns or accumulates)):
+            return 0
+        if self.fuse_bnb == 2 and dxshape[0] * dxshape[1] * dxshape[2] < self._bnb_min_rows:
+            return 0
+        return lib.pfr_conv2d_dgrad_bn_parts(self.did, dyshape[0], dyshape[1], dyshape[2], dyshape[3], c.Cin, c.R, c.S,
+                                             {1: 0, 2: 1}[c.stride], dxshape[1], dxshape[2])
+
+    def _bnfree_set(self, cshape):
+        """Blocks whose conv3 + bn3 take the BN-input-free form (pfr_bnfree.hip) for a network input that reaches layer1 with shape
+        `cshape`: {block index: partial rows of conv3's streaming data gradient}.  Geometry only — the forward pass (which then does
+        not store conv3's output) and the backward pass (which then never asks for it) both decide with this one function:
+          * conv3 is 1x1 / stride 1 with 64 | 128 | 256 inputs and its data gradient is a streaming-kernel geometry;
+          * the gradient at the block's output is produced by a streaming join of the NEXT block (conv1's data gradient of an
+            identity block, or the compact-shortcut form of a projection block): those store it through this block's ReLU mask."""
+        out = {}
+        if not self.bnfree:
+            return out
+        shapes = []
+        cur = cshape
+        for convs, down in self.blocks:
+            xs = cur
+            zs = []
+            for c, _ in convs:
+                oh, ow = conv_out_hw(cur[1], cur[2], c.R, c.S, c.stride, c.pad)
+                cur = (cur[0], oh, ow, c.Cout)
+                zs.append(cur)
+            shapes.append((xs, zs, cur))
+        for k in range(len(self.blocks) - 1):
+            convs, down = self.blocks[k]
+            xs, zs, oshape = shapes[k]
+            if len(convs) != 3:
+                continue
+            c3 = convs[2][0]
+            if c3.R != 1 or c3.stride != 1 or c3.Cin not in (64, 128, 256) or c3.Cout % 64:
+                continue
+            npart = self._dgrad_parts(oshape, c3, zs[1])
+            if npart <= 0 or lib.pfr_conv1x1_tail_mtile(self.did, zs[1][0], zs[1][1], zs[1][2], c3.Cin, c3.Cout) <= 0:
+                continue
+            # producer of this block's output gradient = the next block's first data gradient
+            nconvs, ndown = self.blocks[k + 1]
+            nxs, nzs, _ = shapes[k + 1]
+            c0 = nconvs[0][0]
+            if c0.stride != 1 or self._dgrad_parts(nzs[0], c0, nxs) <= 0:
+                continue
+            if ndown is not None:
+                dc = ndown[0]
+                if (down is not None or dc.R != 1 or dc.stride != 2 or nxs[1] % 2 or nxs[2] % 2
+                        or os.environ.get("PFR_BNB_SUB", "1") == "0" or os.environ.get("PFR_BNB_INPLACE") == "1"):
+                    continue
+            out[k] = npart
+        return out
+
     def build_plan(self, N, H, W, train, with_backward):
         plan = _Plan()
         ops = plan.ops
@@ -597,13 +651,27 @@ class FEEngine:
         cur, cshape = pooled, (N, PH, PW, st.Cout)
         # ---- residual blocks
         bsaved = []
-        for convs, down in self.blocks:
+        free_set = self._bnfree_set(cshape) if train else {}
+        plan.meta["free_set"] = free_set
+        for bk, (convs, down) in enumerate(self.blocks):
             xin, xshape = cur, cshape
             raws = []
             acts = []      # materialised relu(BN(c)) of the inner convs (None when fused into the consumer's prologue)
             pro = None
             src, sshape = xin, xshape
             for ci, (c, bn) in enumerate(convs):
+                if bk in free_set and ci == 2:
+                    # recompute form: this pass leaves only bn3's statistics; the tail launch below computes conv3 again
+                    OH3, OW3 = conv_out_hw(sshape[1], sshape[2], c.R, c.S, c.stride, c.pad)
+                    part3, nt3, mt3 = self._stats_buf(plan, sshape, c, OH3, OW3)
+                    ops.append((lib.pfr_conv1x1_stats, (src.data_ptr(), c.w.data_ptr(), self.did, sshape[0], sshape[1], sshape[2], c.Cin,
+                                                        c.Cout, part3.data_ptr())))
+                    self._bn_fwd(ops, bn, part3, nt3, sshape[0] * OH3 * OW3, train, mt3)
+                    z2_in = (src, sshape)
+                    raws.append((None, (sshape[0], OH3, OW3, c.Cout)))
+                    acts.append(None)
+                    sshape = raws[-1][1]
+                    continue
                 y, yshape = self._conv_bn(plan, ops, src, sshape, c, bn, train, pro=pro)
                 raws.append((y, yshape))
                 if ci + 1 < len(convs) and not self.fuse_prologue:
@@ -625,7 +693,19 @@ class FEEngine:
             # sign of the pre-ReLU block output as a bit mask (1 bit instead of a 16-bit re-read, twice, in backward)
             rmask = self._A(plan, (rows, sshape[3] // self.kp), torch.uint8) if with_backward else None
             mptr = 0 if rmask is None else rmask.data_ptr()
-            if down is not None:
+            if bk in free_set:
+                if rmask is None:     # (a training forward without a backward pass: the kernel still writes the mask)
+                    rmask = self._A(plan, (rows, sshape[3] // self.kp), torch.uint8)
+                res, a2, b2 = xin, 0, 0
+                if down is not None:
+                    dc, dbn = down
+                    cd, _ = self._conv_bn(plan, ops, xin, xshape, dc, dbn, train)
+                    res, a2, b2 = cd, dbn.coef[2].data_ptr(), dbn.coef[3].data_ptr()
+                zt, zts = z2_in
+                ops.append((lib.pfr_conv1x1_bn_tail, (zt.data_ptr(), lastc.w.data_ptr(), out.data_ptr(), rmask.data_ptr(), self.did, zts[0],
+                                                      zts[1], zts[2], lastc.Cin, lastc.Cout, lastbn.coef[2].data_ptr(),
+                                                      lastbn.coef[3].data_ptr(), res.data_ptr(), a2, b2)))
+            elif down is not None:
                 dc, dbn = down
                 cd, _ = self._conv_bn(plan, ops, xin, xshape, dc, dbn, train)
                 ops.append((lib.pfr_bn_act_mask, (src.data_ptr(), lastbn.coef[2].data_ptr(), lastbn.coef[3].data_ptr(),
@@ -757,13 +837,7 @@ class FEEngine:
                                                0 if gres is None else gres.data_ptr(), self.did, rows, C)))
             release(part)
 
-        def dgrad_parts(dyshape, c, dxshape, two_bns=False, accumulates=False):
-            if not self.fuse_bnb or (self.fuse_bnb == 2 and (two_bns or accumulates)):
-                return 0
-            if self.fuse_bnb == 2 and dxshape[0] * dxshape[1] * dxshape[2] < self._bnb_min_rows:
-                return 0
-            return lib.pfr_conv2d_dgrad_bn_parts(self.did, dyshape[0], dyshape[1], dyshape[2], dyshape[3], c.Cin, c.R, c.S,
-                                                 {1: 0, 2: 1}[c.stride], dxshape[1], dxshape[2])
+        dgrad_parts = self._dgrad_parts
 
         def dgrad_bn(dy, dyshape, c, dx, dxshape, bn1, bn2=None, res=None, res_mask=None, accumulate=0, flags=0, wt=None):
             """data gradient + BN-backward partial sums; bn1 = (x, bn record, bit mask or None, part), bn2 = (x, bn record, part);
@@ -802,19 +876,12 @@ class FEEngine:
         # quantities that depend on forward values only: G2 = z2ᵀz2 and the column sums of z2
         bnf = {}        # block index -> dict(G2, zsum, side index, npart of conv3's streaming data gradient)
         premasked = {}  # block index -> True: the gradient at its output was stored through the block's ReLU mask by its producer
-        if self.bnfree:
-            for k in range(nblk - 1):
+        if free_set:
+            for k, npart in free_set.items():
                 convs, _ = self.blocks[k]
                 _, _, raws, _, _, oshape, acts = bsaved[k]
-                if len(convs) != 3 or acts[1] is None:
-                    continue
                 c3 = convs[2][0]
                 zs = raws[1][1]
-                if c3.R != 1 or c3.stride != 1 or c3.Cin not in (64, 128, 256) or c3.Cout % 64:
-                    continue
-                npart = dgrad_parts(oshape, c3, zs)
-                if npart <= 0:
-                    continue
                 rows = zs[0] * zs[1] * zs[2]
                 G2 = self._A(plan, (c3.Cin, c3.Cin), torch.float32)
                 zsum = self._A(plan, (c3.Cin,), torch.float32)
@@ -839,7 +906,9 @@ class FEEngine:
             # the block output) is KEPT: the residual branch consumes it through the same mask (no masked copy is written)
             p3 = pre3.get(k)
             rmask = out
-            free3 = k in bnf and premasked.get(k, False) and p3 is not None
+            free3 = k in bnf
+            if free3 and not (premasked.get(k, False) and p3 is not None):
+                raise PfrError(f"block {k}: the forward pass dropped conv3's output but its output gradient was not produced masked")
             if free3:
                 # conv3 + bn3 without bn3's input (pfr_bnfree.hip).  dcur holds G = g∘mask already.
                 c3, bn3 = convs[2]
@@ -924,10 +993,10 @@ class FEEngine:
                     self._conv_fwd(ops, dgd, oshape, dc.wt, comp, dc, 1, 0, oshape[1], oshape[2], idil=0, Cout=dc.Cin)
                     part = G((npart3, 2, xshape[3]), torch.float32)
                     sub_args = (dy.data_ptr(), c0.wt.data_ptr(), dxin.data_ptr(), self.did, dyshape[0], dyshape[1], dyshape[2], dyshape[3],
-                                c0.Cin, xshape[1], xshape[2], comp.data_ptr(), nxt[0].data_ptr(), nxt[1].coef.data_ptr(),
+                                c0.Cin, xshape[1], xshape[2], comp.data_ptr(), 0 if nxt[0] is None else nxt[0].data_ptr(), nxt[1].coef.data_ptr(),
                                 nxt[2].data_ptr(), part.data_ptr())
-                    if (k - 1) in bnf:      # the previous block takes the BN-input-free backward: its output gradient leaves masked
-                        ops.append((lib.pfr_conv2d_dgrad_bn_sub_ex, sub_args + (1,)))
+                    if (k - 1) in bnf:      # the previous block takes the BN-input-free backward: its output gradient leaves masked,
+                        ops.append((lib.pfr_conv2d_dgrad_bn_sub_ex, sub_args + (3,)))     # and only sum g*mask is asked of this launch
                         premasked[k - 1] = True
                     else:
                         ops.append((lib.pfr_conv2d_dgrad_bn_sub, sub_args))
@@ -967,7 +1036,7 @@ class FEEngine:
                     part2 = G((npart, 2, xshape[3]), torch.float32) if nxt[3] is not None else None
                     dgrad_bn(dy, dyshape, c0, dxin, xshape, (nxt[0], nxt[1], nxt[2], part),
                              None if part2 is None else (nxt[3], nxt[4], part2), res=dcur, res_mask=rmask,
-                             flags=1 if (k - 1) in bnf else 0)
+                             flags=3 if (k - 1) in bnf else 0)
                     if (k - 1) in bnf:
                         premasked[k - 1] = True
                     pre3[k - 1] = ((part, npart), None if part2 is None else (part2, npart))
@@ -1022,6 +1091,7 @@ class FEEngine:
         if ws_main_need[0] and (self.ws_main is None or self.ws_main.numel() < ws_main_need[0]):
             self.ws_main = torch.empty(ws_main_need[0], dtype=torch.float32, device=self.device)
         plan.meta["bnfree_blocks"] = sorted(k for k in bnf if premasked.get(k))
+        assert plan.meta["bnfree_blocks"] == sorted(free_set), (plan.meta["bnfree_blocks"], sorted(free_set))
         return plan
 
     def _mark(self, ops, off):

@@ -938,3 +938,52 @@ def test_statistics_partials_agree_with_the_query_at_the_2gib_input_boundary():
     if mts not in (64, 128, 256):
         with pytest.raises(PfrError):
             o.conv2d_fwd(xs, w, stride=1, pad=0, stats=True, out_relu=True)
+
+
+@pytest.mark.parametrize("case", [(2, 56, 64, 256, False), (3, 28, 128, 512, True), (2, 56, 64, 256, True), (1, 9, 64, 256, False),
+                                  (5, 14, 256, 1024, False), (7, 9, 128, 512, True)])
+def test_recompute_form_of_the_last_conv_is_bit_identical(case):
+    """pfr_conv1x1_stats + pfr_conv1x1_bn_tail (csrc/pfr_sconv.hip EP 9 / 10 / 11): the block tail relu(bn3(conv3(z)) + shortcut) with
+    conv3's output never stored must give the BITS of pfr_conv2d_fwd (statistics) + pfr_bn_act_mask: same output, same ReLU bit mask,
+    statistics partials that finalise to the same coefficients — identity and projection (second BN on the shortcut) forms, ragged
+    row counts."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, C, Co, proj = case
+    g = torch.Generator().manual_seed(H * C + Co + proj)
+    z = torch.relu(torch.randn(N, H, H, C, generator=g)).to(DEV).bfloat16()
+    w = (torch.randn(Co, 1, 1, C, generator=g) / C ** 0.5).to(DEV).bfloat16()
+    res = torch.randn(N, H, H, Co, generator=g).to(DEV).bfloat16()
+    a2 = (1 + 0.1 * torch.randn(Co, generator=g)).to(DEV) if proj else None
+    b2 = (0.1 * torch.randn(Co, generator=g)).to(DEV) if proj else None
+    gamma = (1 + 0.1 * torch.randn(Co, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(Co, generator=g)).to(DEV)
+    M = N * H * H
+    try:
+        lib.pfr_set_tuning(b"sconv", 2)
+        mt = lib.pfr_conv1x1_tail_mtile(1, N, H, H, C, Co)
+        assert mt > 0 and mt == lib.pfr_conv2d_mtile(N, H, H, C, Co, 1, 1, 1, 0, H, H, 1, 1, 0)
+        st = torch.cuda.current_stream().cuda_stream
+        # stored form
+        y, part = o.conv2d_fwd(z, w, stats=True)
+        coef = o.bn_finalize(part, mt, M, gamma, beta, 1e-5, 0.1, None, None).clone()
+        out_ref = torch.empty_like(y)
+        mask_ref = torch.zeros(M, Co // 8, dtype=torch.uint8, device=DEV)
+        lib.pfr_bn_act_mask(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), res.data_ptr(), a2.data_ptr() if proj else 0,
+                            b2.data_ptr() if proj else 0, out_ref.data_ptr(), mask_ref.data_ptr(), 1, M, Co, 1, st)
+        # recompute form
+        nt = (M + mt - 1) // mt
+        part2 = torch.full((nt + 1, 2, Co), 777.0, dtype=torch.float32, device=DEV)
+        lib.pfr_conv1x1_stats(z.data_ptr(), w.data_ptr(), 1, N, H, H, C, Co, part2.data_ptr(), st)
+        coef2 = o.bn_finalize(part2[:nt], mt, M, gamma, beta, 1e-5, 0.1, None, None).clone()
+        out = torch.empty_like(y)
+        mask = torch.zeros(M, Co // 8, dtype=torch.uint8, device=DEV)
+        lib.pfr_conv1x1_bn_tail(z.data_ptr(), w.data_ptr(), out.data_ptr(), mask.data_ptr(), 1, N, H, H, C, Co, coef2[2].data_ptr(),
+                                coef2[3].data_ptr(), res.data_ptr(), a2.data_ptr() if proj else 0, b2.data_ptr() if proj else 0, st)
+        torch.cuda.synchronize()
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+    assert torch.all(part2[nt] == 777.0)
+    assert torch.equal(part2[:nt], part) and torch.equal(coef2, coef)
+    assert torch.equal(out, out_ref) and torch.equal(mask, mask_ref)
+    assert out.float().abs().sum() > 0 and mask.sum() > 0
