@@ -35,7 +35,8 @@ PEAK_HBM_GBS = 8000.0
 
 # every C-ABI entry point whose launches execute the FLOPs counted by conv_flops_per_img (conv / Linear forward, data and
 # weight gradients incl. the fused-epilogue variants, windowed attention)
-CONV_FAMILY = ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_conv2d_dgrad_join", "pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub", "pfr_gemm_act",
+CONV_FAMILY = ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_conv2d_dgrad_join", "pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub",
+               "pfr_conv2d_dgrad_bn_ex", "pfr_conv2d_dgrad_bn_sub_ex", "pfr_conv1x1_stats", "pfr_conv1x1_bn_tail", "pfr_gemm_act",
                "pfr_window_attn_fwd", "pfr_window_attn_bwd")
 
 
@@ -513,13 +514,21 @@ def main():
                 key = "dgrad_join N%d H%d W%d C%d Co%d R%d dil%d OH%d" % (a[4], a[5], a[6], a[7], a[8], a[9], a[12], a[13])
                 fl = 2.0 * a[4] * a[13] * a[14] * a[8] * a[9] * a[10] * a[7] / (4 ** a[12])
                 by = esz * (a[4] * a[5] * a[6] * a[7] + 2 * a[4] * a[13] * a[14] * a[8] + a[8] * a[9] * a[10] * a[7])
-            elif name == "pfr_conv2d_dgrad_bn":
+            elif name in ("pfr_conv1x1_stats", "pfr_conv1x1_bn_tail"):
+                # recompute form of a block's last 1x1 conv: (x, w, dtype, N, H, W, C, Cout, part) / (x, w, y, mask, dtype, N, H, W, C, Cout, ...).
+                # The algorithmic FLOPs of the convolution are counted ONCE (on the tail launch); the statistics pass is extra work.
+                o = 2 if name == "pfr_conv1x1_stats" else 4
+                Nn, Hh, Ww, Cc, Co = a[o + 1], a[o + 2], a[o + 3], a[o + 4], a[o + 5]
+                key = "%s N%d H%d W%d C%d Co%d" % (name[4:], Nn, Hh, Ww, Cc, Co)
+                fl = 0.0 if name == "pfr_conv1x1_stats" else 2.0 * Nn * Hh * Ww * Cc * Co
+                by = esz * Nn * Hh * Ww * Cc + (0 if name == "pfr_conv1x1_stats" else esz * 2 * Nn * Hh * Ww * Co + Nn * Hh * Ww * Co // 8)
+            elif name in ("pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_ex"):
                 # (dy, wt, dx, dtype, N, H, W, C, Cout, R, S, pad, idil, OH, OW, res, mask, acc, bn_x, ...): the data gradient (+ join)
                 # that also reads the BN input for the BatchNorm-backward sums (what pfr_bn_bwd_reduce read in a separate pass)
                 key = "dgrad_bn%s N%d H%d W%d C%d Co%d R%d dil%d OH%d" % ("_join" if a[15] else "", a[4], a[5], a[6], a[7], a[8], a[9], a[12], a[13])
                 fl = 2.0 * a[4] * a[13] * a[14] * a[8] * a[9] * a[10] * a[7] / (4 ** a[12])
                 by = esz * (a[4] * a[5] * a[6] * a[7] + (3 if a[15] else 2) * a[4] * a[13] * a[14] * a[8] + a[8] * a[9] * a[10] * a[7])
-            elif name == "pfr_conv2d_dgrad_bn_sub":
+            elif name in ("pfr_conv2d_dgrad_bn_sub", "pfr_conv2d_dgrad_bn_sub_ex"):
                 # (dy, wt, dx, dtype, N, H, W, C, Cout, OH, OW, res_compact, bn_x, ...): 1x1 data gradient + compact shortcut gradient + BN sums
                 key = "dgrad_bn_sub N%d H%d W%d C%d Co%d" % (a[4], a[5], a[6], a[7], a[8])
                 fl = 2.0 * a[4] * a[9] * a[10] * a[8] * a[7]
@@ -552,7 +561,7 @@ def main():
         # roofline.frac = ALL conv / linear FLOPs of the step / the time of ALL conv-family launches / peak.  The data-gradient
         # launches that also do the BatchNorm-backward reduction in their epilogue (pfr_conv2d_dgrad_bn[_sub]) are conv launches: their
         # FLOPs and their time both count.  The ratio without them is kept under its own key (`frac_excl_bn_sum_launches`).
-        fused_ms = sum(summ[k][1] for k in ("pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub") if k in summ) / nprof
+        fused_ms = sum(summ[k][1] for k in ("pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub", "pfr_conv2d_dgrad_bn_ex", "pfr_conv2d_dgrad_bn_sub_ex") if k in summ) / nprof
         fused_flops = sum(v[0] / nprof * v[2] for k, v in det.items() if k.startswith("dgrad_bn"))
         conv_ms = conv_ms_all
         ach = flops / (conv_ms_all * 1e-3) / 1e12

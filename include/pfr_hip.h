@@ -152,6 +152,12 @@ int pfr_bn3_bwd_coef(const float* part, int nparts, const float* G1, const float
 int pfr_bn3_bwd_weights(const float* coef, const float* G1, const float* G2, const float* zsum, const float* W, int C, int K, float count,
                         float* dW, void* wa_t, void* S, float* bias, int accumulate, pfr_stream_t stream);
 
+/* G2 = X^T X [Q][Q] and the column sums of X [Q] in ONE streaming pass over X [M][Q] (bf16, Q = 64 | 128): the two forward-only inputs
+ * of pfr_bn3_bwd_coef / pfr_bn3_bwd_weights.  out = Q*Q floats then Q floats; workspace = pfr_gram_ws_floats(M, Q) floats (0: geometry
+ * not supported — pfr_conv2d_wgrad(x, x) + pfr_colsum give the same). */
+long pfr_gram_ws_floats(long M, int Q);
+int pfr_gram_colsum(const void* x, int dtype, long M, int Q, float* out, float* workspace, pfr_stream_t stream);
+
 /* pfr_conv2d_wgrad replaces the autograd weight gradient of nn.Conv2d / nn.Linear / F.linear:
  *   dw[co][r][s][c] (fp32) = scale * sum_m dy[m][co] * act(x)[...]  (+ dw if accumulate)
  * workspace: fp32 [pfr_conv2d_wgrad_splits(M,Cout,R*S*C)][Cout][R*S*C] (may be NULL when splits == 1). */

@@ -901,6 +901,166 @@ static int swgrad_launch(const WgradParams& p, const SwgradPlan& pl, float* slab
   return PFR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gram matrix + column sums of an activation tensor in ONE streaming pass: G2 = XᵀX [Q][Q] and s = column sums of X [Q]
+// (X [M][Q] bf16, Q = 64 or 128) — the two forward-only quantities of the BN-input-free backward (pfr_bnfree.hip).  The structure
+// of swgrad_kernel with a single operand: 256 persistent workgroups, every wave a private LDS-DMA ring of [16 rows][64 channels]
+// blocks, no barrier in the loop; a wave owns 64 rows of G2 (its column block, WA = Q/64 of them) and ALL Q columns, the WM = 8/WA
+// wave groups take different 16-row steps.  The transposing reads of a block serve as A and as B operand; the column sums are
+// one more MFMA against a fragment of ones.  One fp32 slab [Q*Q + Q] per workgroup, summed by wgrad_reduce_kernel.
+struct GramParams {
+  const void* x;
+  float* slabs;     // [nsplit][Q*Q + Q]
+  int M, Q, nsplit, nit;
+};
+template <int GQ, int NS>
+__global__ __launch_bounds__(512, 1) void gram_kernel(GramParams p) {
+  constexpr int SLOT = GQ * 2048, IPS = GQ * 2, TQ = 2 * GQ, WA = GQ, WM = 8 / GQ;
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WA, wa = wave % WA;
+  const int split = blockIdx.x;
+  if (split >= p.nsplit) return;
+  const int drow = lane >> 3, pc = lane & 7;
+  uint32_t voff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * h + drow;
+    const int lc = ((((pc >> 1) ^ (((row >> 1) & 1) << 1)) << 1) | (pc & 1));
+    voff[h] = (uint32_t)((row * p.Q + lc * 8) * 2);
+  }
+  const char* xb = reinterpret_cast<const char*>(p.x);
+  char* const ring = smem + wave * (NS * SLOT);
+  const long nb = ((long)p.M + 15) >> 4;
+  auto issue = [&](int slot, long it) __attribute__((always_inline)) {
+    const long blk = (it * p.nsplit + split) * WM + wm;
+    const long m0 = blk << 4;
+    const long left = blk < nb ? (long)p.M - m0 : 0;
+    const long rows = left > 16 ? 16 : left;
+    const long mb = blk < nb ? m0 : 0;
+    __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb + mb * p.Q * 2), 0, (int)(rows * p.Q * 2), 0x00020000);
+    char* base = ring + slot * SLOT;
+#pragma unroll
+    for (int j = 0; j < GQ; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (__attribute__((address_space(3))) void*)(base + j * 2048 + h * 1024), 16,
+                                                 (int)voff[h], j * 128, 0, 0);
+  };
+  f32x16 acc[2][TQ], accz[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accz[i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
+  const int g = lane >> 4, s4 = lane & 15;
+  const int r0 = (g >> 1) * 8 + (s4 >> 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)(wave * (NS * SLOT));
+  uint32_t laneT[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int gran = 2 * t + (g & 1);
+    laneT[t] = lds0 + r0 * 128 + ((gran ^ (((r0 >> 1) & 1) << 1)) << 5) + (s4 & 3) * 8;
+  }
+  const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s, s);
+  auto step = [&](auto slot_c, long it) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    issue((S + NS - 1) % NS, it + NS - 1);
+    wg_wait_vm<(NS - 1) * IPS>();
+    u32x2 hq[TQ][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) hq[j][q] = lds_read_tr16(laneT[j & 1], S * SLOT + (j >> 1) * 2048 + q * 512);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(hq[j][q]));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // this wave's 64 rows of G2: the 32-channel halves 2*wa + i of the block are the A operand (wa is wave-uniform)
+      u32x4 ua;
+      if (GQ == 1 || wa == 0) ua = (u32x4){hq[i][0][0], hq[i][0][1], hq[i][1][0], hq[i][1][1]};
+      else ua = (u32x4){hq[(TQ > 2 ? 2 : 0) + i][0][0], hq[(TQ > 2 ? 2 : 0) + i][0][1], hq[(TQ > 2 ? 2 : 0) + i][1][0], hq[(TQ > 2 ? 2 : 0) + i][1][1]};
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        const u32x4 ub = {hq[j][0][0], hq[j][0][1], hq[j][1][0], hq[j][1][1]};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), acc[i][j], 0, 0, 0);
+      }
+      accz[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ones), accz[i], 0, 0, 0);
+    }
+  };
+  for (long it = 0; it < p.nit; it += NS) {
+    step(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < p.nit) step(std::integral_constant<int, 1>{}, it + 1);
+    if constexpr (NS > 2) { if (it + 2 < p.nit) step(std::integral_constant<int, 2>{}, it + 2); }
+    if constexpr (NS > 3) { if (it + 3 < p.nit) step(std::integral_constant<int, 3>{}, it + 3); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    asm volatile("s_nop 15" : "+v"(accz[i]));
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) asm volatile("s_nop 15" : "+v"(acc[i][j]));
+  }
+  __syncthreads();
+  // ---- sum the WM wave groups (tree over LDS, fixed order)
+  float* red = reinterpret_cast<float*>(smem);
+  constexpr int NT = 2 * TQ + 2;     // accumulator tiles per wave
+  for (int stride = WM >> 1; stride >= 1; stride >>= 1) {
+    if (wm >= stride && wm < 2 * stride) {
+      float* dst = red + (size_t)((wm - stride) * WA + wa) * (NT * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) dst[((i * TQ + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[((2 * TQ + i) * 16 + e) * 64 + lane] = accz[i][e];
+      }
+    }
+    __syncthreads();
+    if (wm < stride) {
+      const float* src = red + (size_t)(wm * WA + wa) * (NT * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += src[((i * TQ + j) * 16 + e) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accz[i][e] += src[((2 * TQ + i) * 16 + e) * 64 + lane];
+      }
+    }
+    __syncthreads();
+  }
+  if (wm == 0) {
+    float* out = p.slabs + (size_t)split * ((size_t)p.Q * p.Q + p.Q);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        const int col = j * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[(size_t)(wa * 64 + i * 32 + acc_row(e, lane)) * p.Q + col] = acc[i][j][e];
+      }
+      if ((lane & 31) == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[(size_t)p.Q * p.Q + wa * 64 + i * 32 + acc_row(e, lane)] = accz[i][e];
+      }
+    }
+  }
+}
+
 // sums the split slabs: block = 64 columns (of 4 floats) x 4 split-lanes; every lane keeps 4 independent loads in flight
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4,
                                                            int splits, float scale, int accumulate) {
@@ -1078,5 +1238,35 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, n4, p.splits, scale, accumulate);
     PFR_CHECK_LAUNCH();
   }
+  return PFR_OK;
+}
+
+// G2 = XᵀX and the column sums of X in one pass (csrc/pfr_bnfree.hip's forward-only quantities).  out: [Q*Q] then [Q] floats;
+// workspace: pfr_gram_ws_floats floats (0: geometry not supported — use pfr_conv2d_wgrad(x, x) + pfr_colsum)
+extern "C" long pfr_gram_ws_floats(long M, int Q) {
+  if ((Q != 64 && Q != 128) || M < 16 * 256 || M * Q * 2 >= (1L << 31)) return 0;
+  return 256L * ((long)Q * Q + Q);
+}
+extern "C" int pfr_gram_colsum(const void* x, int dtype, long M, int Q, float* out, float* workspace, hipStream_t st) {
+  PFR_CHECK_ARG(x && out && workspace, "pfr_gram_colsum: null pointer");
+  PFR_CHECK_ARG(dtype == PFR_BF16 && pfr_gram_ws_floats(M, Q) > 0, "pfr_gram_colsum: bf16, Q = 64 | 128, M >= 4096 only");
+  GramParams gp;
+  gp.x = x; gp.slabs = workspace; gp.M = (int)M; gp.Q = Q; gp.nsplit = 256;
+  const int wm = Q == 64 ? 8 : 4;
+  const long nb = (M + 15) / 16, per = 256L * wm;
+  gp.nit = (int)((nb + per - 1) / per);
+  if (Q == 64) {
+    static bool attr = false;   // (LDS: the rings, then — reused — the wave-group sums: 4 waves x 6 tiles / 4 waves x 10 tiles of 4 KiB)
+    if (!attr) { hipFuncSetAttribute((const void*)gram_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((gram_kernel<1, 4>), dim3(256), dim3(512), 160 * 1024, st, gp);
+  } else {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)gram_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((gram_kernel<2, 3>), dim3(256), dim3(512), 160 * 1024, st, gp);
+  }
+  PFR_CHECK_LAUNCH();
+  const size_t n4 = ((size_t)Q * Q + Q) / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, workspace, out, n4, 256, 1.0f, 0);
+  PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

@@ -681,6 +681,17 @@ class FEEngine:
                     acts.append(z)
                     pro = None
                     src, sshape = z, yshape
+                    if bk in free_set and ci == 1 and with_backward:
+                        # z2ᵀz2 and the column sums of z2 for the BN-input-free backward, while z2 is fresh in the Infinity Cache
+                        rows2 = yshape[0] * yshape[1] * yshape[2]
+                        nws = lib.pfr_gram_ws_floats(rows2, yshape[3])
+                        if nws > 0:
+                            gram = self._A(plan, (yshape[3] * yshape[3] + yshape[3],), torch.float32)
+                            gws = plan.meta.get("gram_ws")
+                            if gws is None or gws.numel() < nws:
+                                gws = plan.meta["gram_ws"] = self._A(plan, (nws,), torch.float32)
+                            ops.append((lib.pfr_gram_colsum, (z.data_ptr(), self.did, rows2, yshape[3], gram.data_ptr(), gws.data_ptr())))
+                            plan.meta.setdefault("gram", {})[bk] = gram
                 else:
                     acts.append(None)
                     pro = (bn.coef[2], bn.coef[3])
@@ -883,6 +894,10 @@ class FEEngine:
                 c3 = convs[2][0]
                 zs = raws[1][1]
                 rows = zs[0] * zs[1] * zs[2]
+                gram = plan.meta.get("gram", {}).get(k)
+                if gram is not None:      # computed by the forward pass (pfr_gram_colsum)
+                    bnf[k] = dict(G2=gram[:c3.Cin * c3.Cin], zsum=gram[c3.Cin * c3.Cin:], side=None, npart=npart)
+                    continue
                 G2 = self._A(plan, (c3.Cin, c3.Cin), torch.float32)
                 zsum = self._A(plan, (c3.Cin,), torch.float32)
                 cws = self._A(plan, (max(1, lib.pfr_colsum_ws_floats(rows, c3.Cin)),), torch.float32)
@@ -917,7 +932,8 @@ class FEEngine:
                 f = bnf[k]
                 C3, K3, rows3 = c3.Cout, c3.Cin, float(oshape[0] * oshape[1] * oshape[2])
                 wgrad_main(z2, zs, dcur, oshape, c3, bnf_G1)                                   # G1 = Gᵀ z2
-                ops.append(("wait", (f["side"],)))                                              # G2, zsum (side stream, issued long ago)
+                if f["side"] is not None:
+                    ops.append(("wait", (f["side"],)))                                          # G2, zsum (side stream, issued long ago)
                 part3, np3 = p3[0]
                 Wm = self.master.data_ptr() + 4 * c3.off
                 ops.append((lib.pfr_bn3_bwd_coef, (part3.data_ptr(), np3, bnf_G1.data_ptr(), f["zsum"].data_ptr(), Wm, bn3.gamma.data_ptr(),

@@ -987,3 +987,29 @@ def test_recompute_form_of_the_last_conv_is_bit_identical(case):
     assert torch.equal(part2[:nt], part) and torch.equal(coef2, coef)
     assert torch.equal(out, out_ref) and torch.equal(mask, mask_ref)
     assert out.float().abs().sum() > 0 and mask.sum() > 0
+
+
+@pytest.mark.parametrize("M,Q", [(8192, 64), (100357, 64), (4099, 128), (25088, 128), (200704, 128)])
+def test_gram_matrix_and_column_sums_in_one_pass(M, Q):
+    """pfr_gram_colsum (csrc/pfr_wgrad.hip gram_kernel): G2 = XᵀX and the column sums of X [M][Q] (bf16) from ONE streaming pass,
+    against fp64 torch on the same bf16 values; deterministic (two launches give the same bits); ragged row counts."""
+    from pets_face_recognition_amd._hip import lib
+    g = torch.Generator().manual_seed(M + Q)
+    x = torch.relu(torch.randn(M, Q, generator=g)).bfloat16().to(DEV)
+    nws = lib.pfr_gram_ws_floats(M, Q)
+    assert nws > 0 and lib.pfr_gram_ws_floats(M, 96) == 0
+    ws = torch.empty(nws, dtype=torch.float32, device=DEV)
+    outs = []
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        out = torch.full((Q * Q + Q + 8,), -3.0, dtype=torch.float32, device=DEV)
+        lib.pfr_gram_colsum(x.data_ptr(), 1, M, Q, out.data_ptr(), ws.data_ptr(), st)
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.all(outs[0][Q * Q + Q:] == -3.0)
+    xd = x.double()
+    G2 = (xd.t() @ xd).cpu()
+    zs = xd.sum(0).cpu()
+    got = outs[0].double().cpu()
+    assert torch.allclose(got[:Q * Q].view(Q, Q), G2, rtol=2e-5, atol=1e-3)
+    assert torch.allclose(got[Q * Q:Q * Q + Q], zs, rtol=2e-5, atol=1e-3)
