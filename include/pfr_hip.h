@@ -42,6 +42,9 @@ int pfr_device_arch(char* buf, int buflen);
  * whenever the geometry is eligible; "igemm_ptile" -1 heuristic / 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64 (rows x couts).
  * Results do not depend on the knobs (same accumulation order); statistics-partial granularity follows pfr_conv2d_mtile. */
 int pfr_set_tuning(const char* key, int value);
+/* bumped by every pfr_set_tuning call that CHANGES a knob: launch plans that baked a kernel choice in (statistics-partial granularity,
+ * partial-row counts) are rebuilt by their owners when the epoch they were built under is over */
+int pfr_tuning_epoch(void);
 
 /* C-side executor of a pre-built launch plan (csrc/pfr_plan.hip): the host keeps a step's fixed list of C-ABI calls (fixed device
  * pointers) in a plan and replays it with ONE call instead of one interpreter round trip per launch.  An entry is appended with
@@ -227,14 +230,6 @@ int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* x, const fl
                       pfr_stream_t stream);
 int pfr_bn_bwd_finalize(const float* part, int nparts, int C, float count, const float* gamma, const float* mean,
                         const float* invstd, float* dgamma, float* dbeta, float* coef, int accumulate, pfr_stream_t stream);
-/* reduce and finalize in ONE launch (the last workgroups to arrive sum the partial rows in index order: deterministic, nothing
- * spins).  part: [pfr_bn_bwd_fused_part_rows(C, dtype, rows)][2][C] floats; counters: >= 64 zero-initialised 32-bit words owned by
- * the call site (left at zero); count = rows. */
-int pfr_bn_bwd_fused_part_rows(int C, int dtype, long rows);
-int pfr_bn_bwd_reduce_finalize(const void* dout, const void* out, const void* x, const float* mean, const float* invstd,
-                               const float* scale, const float* shift, int mask_mode, int dtype, long rows, int C, float* part,
-                               unsigned int* counters, const float* gamma, float* dgamma, float* dbeta, float* coef,
-                               int accumulate, pfr_stream_t stream);
 int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x, const float* coef, const float* scale,
                      const float* shift, int mask_mode, void* dx, void* gres, int dtype, long rows, int C,
                      pfr_stream_t stream);
@@ -243,16 +238,6 @@ int pfr_bn_bwd_apply(const void* dout, const void* out, const void* x, const flo
 int pfr_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int dtype, int N,
                             int H, int W, int C, int relu, pfr_stream_t stream);
 int pfr_maxpool_bwd(const void* dy, const uint8_t* idx, void* dz, int dtype, int N, int H, int W, int C, pfr_stream_t stream);
-/* The stem tail backward without the [N,H,W,C] max-pool gradient tensor (reference: torch autograd of
- * models/resnet.py maxpool(relu(bn1(conv1(x)))) — MaxPool2DWithIndicesBackward + ThresholdBackward + NativeBatchNormBackward):
- * g = maxpool_bwd(dpool, idx) where scale*x + shift > 0, gathered from the pooled gradient inside the BatchNorm-backward reduce
- * and apply passes.  part / coef exactly as pfr_bn_bwd_reduce / pfr_bn_bwd_apply (pfr_bn_bwd_finalize runs between the two);
- * results are bit-identical to pfr_maxpool_bwd + pfr_bn_bwd_reduce(mask_mode 2) + pfr_bn_bwd_apply(mask_mode 2). */
-int pfr_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* invstd,
-                           const float* scale, const float* shift, int dtype, int N, int H, int W, int C, float* part,
-                           pfr_stream_t stream);
-int pfr_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const float* coef, const float* scale,
-                          const float* shift, void* dx, int dtype, int N, int H, int W, int C, pfr_stream_t stream);
 int pfr_avgpool_fwd(const void* x, void* y, int dtype, int N, int HW, int C, pfr_stream_t stream);
 int pfr_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int HW, int C, pfr_stream_t stream);
 

@@ -208,9 +208,7 @@ extern "C" int pfr_colreduce_blocks(int C, int dtype, long rows) {
   return col_geom(C, dtype == PFR_BF16 ? 8 : 4, (size_t)rows).gx;
 }
 
-// COHERENT: the row is written with device-scope (write-through) stores — for launches whose last workgroups read the rows of
-// the others (bn_bwd_reduce_kernel<.., FIN>); a release fence instead costs an L2 write-back scan per workgroup.
-template <int NQ, int KP, bool COHERENT = false>
+template <int NQ, int KP>
 __device__ __forceinline__ void col_block_reduce(float (&v)[NQ][KP], float* lds, int cw, int rl, int col, int rlane,
                                                  int cglob, int cpr, float* out_row, int C) {
   // lds: [rl][cw][NQ*KP]
@@ -227,8 +225,7 @@ __device__ __forceinline__ void col_block_reduce(float (&v)[NQ][KP], float* lds,
       for (int e = 0; e < KP; ++e) {
         float a = 0.f;
         for (int r = 0; r < rl; ++r) a += lds[((size_t)r * cw + col) * (NQ * KP) + q * KP + e];
-        if (COHERENT) __hip_atomic_store(out_row + (size_t)q * C + cglob * KP + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else out_row[(size_t)q * C + cglob * KP + e] = a;
+        out_row[(size_t)q * C + cglob * KP + e] = a;
       }
   }
 }
@@ -701,31 +698,15 @@ extern "C" int pfr_bn_act_mask(const void* x1, const float* a1, const float* b1,
 // mask_mode 0: none; 1: out > 0 (materialised post-activation tensor); 2: scale·x + shift > 0 (recomputed)
 // MASK is a template parameter: with a run-time mode the optional loads (`if (mode == 3) bits = …`) sit in branches and hipcc drains
 // the memory queue (vmcnt(0)) behind the first row of every four-row batch — two round trips per batch instead of one
-// FIN: the launch also does pfr_bn_bwd_finalize's work (no second launch on the dependency chain).  Workgroups are grouped by
-// BNF_GROUP consecutive row blocks; the LAST workgroup of a group to arrive (device-scope counter) sums the group's partial rows in
-// index order into a group row, and the last GROUP to arrive sums the group rows in index order and writes dgamma / dbeta / coef:
-// the order of every sum is fixed by indices, not by arrival, so the result is deterministic.  Nothing spins; the counters are left
-// at zero for the next launch.
-#define BNF_GROUP 16
-struct BnBwdFin {
-  const float* gamma;
-  float* dgamma;
-  float* dbeta;
-  float* coef;
-  float* gpart;          // [ngroups][2][C]
-  unsigned int* counters;  // [gridDim.y][1 + ngroups], zero before the first launch
-  float count;
-  int accumulate;
-};
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <typename T, int MASK, bool FIN = false>
+// (round 4: the FIN variant — reduce + finalize in one launch through a last-workgroup hand-over — measured slower than the separate
+// 6.7 us finalize launch it removed, profiles/r03_finalize_fusion.txt, and was retired)
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             float* __restrict__ part, size_t rows, int C,
-                                                            int cw, int rl, int cpr, BnBwdFin fin = BnBwdFin()) {
+                                                            int cw, int rl, int cpr) {
   constexpr int mask_mode = MASK;
   constexpr int KP = DT<T>::KPACK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -788,66 +769,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       body(ld16(dout + off), ld16(x + off), vo, mask_mode == 3 ? mk[r * cpr + cglob] : 0u);
     }
   }
-  col_block_reduce<2, KP, FIN>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
-  if (!FIN) return;
-  __shared__ int last;
-  const int ngroups = (gridDim.x + BNF_GROUP - 1) / BNF_GROUP, grp = blockIdx.x / BNF_GROUP;
-  const int gbeg = grp * BNF_GROUP, gend = min((int)gridDim.x, gbeg + BNF_GROUP);
-  unsigned int* cnt = fin.counters + (size_t)blockIdx.y * (1 + ngroups);
-  const int c_lo = blockIdx.y * cw * KP, c_hi = min(C, c_lo + cw * KP);   // the channels this column of workgroups owns
-  // hand-over without fences: the partial row went out as device-scope stores (not left dirty in this XCD's L2), every wave waits
-  // for its stores to complete before the barrier, then ONE device-scope atomic counts the arrival; readers use device-scope loads
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&cnt[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(gend - gbeg - 1);
-  __syncthreads();
-  if (!last) return;
-  for (int c = c_lo + (int)threadIdx.x; c < c_hi; c += 256) {
-    float va[BNF_GROUP], vb[BNF_GROUP];
-#pragma unroll
-    for (int i = 0; i < BNF_GROUP; ++i) {
-      const int b = gbeg + i < gend ? gbeg + i : gbeg;
-      va[i] = ld_agent(part + ((size_t)b * 2 + 0) * C + c);
-      vb[i] = ld_agent(part + ((size_t)b * 2 + 1) * C + c);
-    }
-    float a = 0.f, b2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < BNF_GROUP; ++i)
-      if (gbeg + i < gend) { a += va[i]; b2 += vb[i]; }
-    __hip_atomic_store(fin.gpart + ((size_t)grp * 2 + 0) * C + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(fin.gpart + ((size_t)grp * 2 + 1) * C + c, b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ngroups - 1);
-  __syncthreads();
-  if (!last) return;
-  for (int c = c_lo + (int)threadIdx.x; c < c_hi; c += 256) {
-    const float g = fin.gamma ? fin.gamma[c] : 1.f, is = invstd[c], mu = mean[c];
-    const float dg0 = (fin.dgamma && fin.accumulate) ? fin.dgamma[c] : 0.f, db0 = (fin.dbeta && fin.accumulate) ? fin.dbeta[c] : 0.f;
-    float sg = 0.f, sgx = 0.f;
-    for (int g0 = 0; g0 < ngroups; g0 += 8) {
-      float va[8], vb[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int gg = g0 + i < ngroups ? g0 + i : 0;
-        va[i] = ld_agent(fin.gpart + ((size_t)gg * 2 + 0) * C + c);
-        vb[i] = ld_agent(fin.gpart + ((size_t)gg * 2 + 1) * C + c);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (g0 + i < ngroups) { sg += va[i]; sgx += vb[i]; }
-    }
-    if (fin.dgamma) fin.dgamma[c] = fin.accumulate ? dg0 + sgx : sgx;
-    if (fin.dbeta) fin.dbeta[c] = fin.accumulate ? db0 + sg : sg;
-    const float cg = g * is;
-    const float cx = -g * is * is * sgx / fin.count;
-    const float c0 = -g * is * sg / fin.count - cx * mu;
-    fin.coef[c] = cg;
-    fin.coef[C + c] = cx;
-    fin.coef[2 * C + c] = c0;
-  }
-  if ((int)threadIdx.x <= ngroups) __hip_atomic_store(&cnt[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream order separates the launches)
+  col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
 }
 
 extern "C" int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* x, const float* mean,
@@ -870,38 +792,6 @@ extern "C" int pfr_bn_bwd_reduce(const void* dout, const void* out, const void* 
   return PFR_OK;
 }
 
-// reduce + finalize in ONE launch (see bn_bwd_reduce_kernel<.., FIN>).  part: [pfr_bn_bwd_fused_part_rows][2][C] floats (the
-// row-block partials followed by the group rows); counters: >= 64 zero-initialised 32-bit words owned by this call site.
-extern "C" int pfr_bn_bwd_fused_part_rows(int C, int dtype, long rows) {
-  const ColGeom g = col_geom(C, dtype == PFR_BF16 ? 8 : 4, (size_t)rows);
-  return g.gx + (g.gx + BNF_GROUP - 1) / BNF_GROUP;
-}
-extern "C" int pfr_bn_bwd_reduce_finalize(const void* dout, const void* out, const void* x, const float* mean, const float* invstd,
-                                          const float* scale, const float* shift, int mask_mode, int dtype, long rows, int C,
-                                          float* part, unsigned int* counters, const float* gamma, float* dgamma, float* dbeta,
-                                          float* coef, int accumulate, hipStream_t st) {
-  PFR_CHECK_ARG(dout && x && mean && invstd && part && counters && coef, "pfr_bn_bwd_reduce_finalize: null pointer");
-  PFR_CHECK_ARG((mask_mode != 1 && mask_mode != 3) || out, "pfr_bn_bwd_reduce_finalize: mask_mode 1 / 3 needs out / the bit mask");
-  PFR_CHECK_ARG(mask_mode != 2 || (scale && shift), "pfr_bn_bwd_reduce_finalize: mask_mode 2 needs scale/shift");
-  PFR_CHECK_ARG(mask_mode >= 0 && mask_mode <= 3, "pfr_bn_bwd_reduce_finalize: bad mask_mode");
-  const int kp = dtype == PFR_BF16 ? 8 : 4;
-  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_reduce_finalize: C %% %d != 0", kp);
-  ColGeom g = col_geom(C, kp, (size_t)rows);
-  const int ngroups = (g.gx + BNF_GROUP - 1) / BNF_GROUP;
-  PFR_CHECK_ARG(g.gy * (1 + ngroups) <= 64, "pfr_bn_bwd_reduce_finalize: geometry needs %d counters", g.gy * (1 + ngroups));
-  BnBwdFin fin;
-  fin.gamma = gamma; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.coef = coef;
-  fin.gpart = part + (size_t)g.gx * 2 * C;
-  fin.counters = counters; fin.count = (float)rows; fin.accumulate = accumulate;
-  const size_t shb = (size_t)256 * 2 * kp * sizeof(float);
-#define PFR_BNR(TT, M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, M, true>), dim3(g.gx, g.gy), dim3(256), shb, st, (const TT*)dout, (const TT*)out, (const TT*)x, mean, invstd, scale, shift, part, (size_t)rows, C, g.cw, g.rl, g.cpr, fin)
-#define PFR_BNR4(TT) do { switch (mask_mode) { case 0: PFR_BNR(TT, 0); break; case 1: PFR_BNR(TT, 1); break; case 2: PFR_BNR(TT, 2); break; default: PFR_BNR(TT, 3); } } while (0)
-  if (dtype == PFR_BF16) PFR_BNR4(bf16_t); else PFR_BNR4(float);
-#undef PFR_BNR4
-#undef PFR_BNR
-  PFR_CHECK_LAUNCH();
-  return PFR_OK;
-}
 
 // ---- backward finalise: partials → dgamma, dbeta and the per-channel coefficients of
 //      dx = cg·g + cx·x + c0     (cg = γ·invstd, cx = −γ·invstd²·Σgx̂/M, c0 = −γ·invstd·Σg/M − cx·mean)
@@ -1328,217 +1218,8 @@ extern "C" int pfr_maxpool_bwd(const void* dy, const uint8_t* idx, void* dz, int
   return PFR_OK;
 }
 
-// ---- stem tail backward WITHOUT the max-pool gradient tensor: the gradient arriving at the stem BatchNorm is
-// g = maxpool_bwd(dpool, idx) ∘ [scale·x + shift > 0].  pfr_maxpool_bwd + pfr_bn_bwd_reduce + pfr_bn_bwd_apply write that
-// [N,H,W,C] tensor once and read it twice (1.2 GB at 256 x 112² x 64 bf16); the two kernels below gather it from the
-// quarter-size pooled gradient instead (the ≤ 4 covering windows of a pixel, all loads issued up front) and are otherwise the
-// reduce / apply kernels: same thread layout, same summation order, the gathered value rounded to T as the stored tensor
-// was — partial sums and dx are bit-identical to the three-launch path.
-template <typename T>
-struct PoolTaps {
-  u32x4 gv[4];
-  uint64_t pk[4];
-  int tap[4];
-  bool ok[4];
-};
-// (n, h, w) of a thread's rows are walked with carries (one division per thread, not per row)
-struct PixWalk {
-  int n, h, w, dn, dh, dw;
-  __device__ __forceinline__ void init(uint32_t r, uint32_t step, int H, int W) {
-    w = (int)(r % (uint32_t)W); const uint32_t q1 = r / (uint32_t)W; h = (int)(q1 % (uint32_t)H); n = (int)(q1 / (uint32_t)H);
-    dw = (int)(step % (uint32_t)W); const uint32_t q2 = step / (uint32_t)W; dh = (int)(q2 % (uint32_t)H); dn = (int)(q2 / (uint32_t)H);
-  }
-  __device__ __forceinline__ void advance(int H, int W) {
-    w += dw; h += dh; n += dn;
-    if (w >= W) { w -= W; ++h; }
-    if (h >= H) { h -= H; ++n; }
-  }
-};
-template <typename T>
-__device__ __forceinline__ void pool_issue(PoolTaps<T>& t, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const PixWalk& pw,
-                                           int cc, int cpr, int OH, int OW) {
-  constexpr int KP = DT<T>::KPACK;
-  const int n = pw.n, h = pw.h, w = pw.w;
-  const int oh0 = (h + 1) >> 1, r0 = h + 1 - 2 * oh0, ow0 = ((int)w + 1) >> 1, s0 = (int)w + 1 - 2 * ow0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int dh = q >> 1, dw = q & 1;
-    const int oh = oh0 - dh, ow = ow0 - dw;
-    const int rr = r0 + 2 * dh, sx = s0 + 2 * dw;
-    t.ok[q] = oh >= 0 && oh < OH && ow >= 0 && ow < OW && rr < 3 && sx < 3;
-    t.tap[q] = rr * 3 + sx;
-    const int ohc = min(max(oh, 0), OH - 1), owc = min(max(ow, 0), OW - 1);
-    const size_t o = (((size_t)n * OH + ohc) * OW + owc) * cpr + cc;
-    t.gv[q] = ld16(dpool + o * KP);
-    if constexpr (KP == 8) t.pk[q] = *reinterpret_cast<const uint64_t*>(idx + o * 8);
-    else t.pk[q] = *reinterpret_cast<const uint32_t*>(idx + o * 4);
-  }
-}
-template <typename T>
-__device__ __forceinline__ void pool_sum(const PoolTaps<T>& t, float (&acc)[DT<T>::KPACK]) {
-  constexpr int KP = DT<T>::KPACK;
-#pragma unroll
-  for (int e = 0; e < KP; ++e) acc[e] = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float g[KP];
-    Chunk<T>::unpack(t.gv[q], g);
-#pragma unroll
-    for (int e = 0; e < KP; ++e)
-      acc[e] += (t.ok[q] && (int)((t.pk[q] >> (8 * e)) & 0xff) == t.tap[q]) ? g[e] : 0.f;
-  }
-  Chunk<T>::unpack(Chunk<T>::pack(acc), acc);   // as pfr_maxpool_bwd stored it
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
-                                                                 const T* __restrict__ x, const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd, const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift, float* __restrict__ part,
-                                                                 uint32_t rows, int C, int H, int W, int OH, int OW, int cw, int rl,
-                                                                 int cpr) {
-  constexpr int KP = DT<T>::KPACK;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
-  const int cglob = blockIdx.y * cw + col;
-  float v[2][KP];
-#pragma unroll
-  for (int e = 0; e < KP; ++e) { v[0][e] = 0.f; v[1][e] = 0.f; }
-  if (cglob < cpr) {
-    float mu[KP], is[KP], sc[KP], sh[KP];
-#pragma unroll
-    for (int e = 0; e < KP; ++e) {
-      mu[e] = mean[cglob * KP + e];
-      is[e] = invstd[cglob * KP + e];
-      sc[e] = scale[cglob * KP + e];
-      sh[e] = shift[cglob * KP + e];
-    }
-    auto body = [&](const PoolTaps<T>& t, u32x4 vx) {
-      float g[KP], xv[KP];
-      pool_sum<T>(t, g);
-      Chunk<T>::unpack(vx, xv);
-#pragma unroll
-      for (int e = 0; e < KP; ++e) {
-        const float gg = fmaf(xv[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
-        v[0][e] += gg;
-        v[1][e] = fmaf(gg, (xv[e] - mu[e]) * is[e], v[1][e]);
-      }
-    };
-    const uint32_t step = gridDim.x * (uint32_t)rl;
-    uint32_t r = blockIdx.x * (uint32_t)rl + rlane;
-    PixWalk pw;
-    pw.init(r, step, H, W);
-    for (; r + step < rows; r += 2 * step) {   // two rows per thread in flight (nine loads each)
-      PoolTaps<T> t0, t1;
-      pool_issue<T>(t0, dpool, idx, pw, cglob, cpr, OH, OW);
-      pw.advance(H, W);
-      pool_issue<T>(t1, dpool, idx, pw, cglob, cpr, OH, OW);
-      pw.advance(H, W);
-      const u32x4 x0 = ld16_nt(x + (size_t)r * C + cglob * KP), x1 = ld16_nt(x + (size_t)(r + step) * C + cglob * KP);
-      body(t0, x0);
-      body(t1, x1);
-    }
-    for (; r < rows; r += step) {
-      PoolTaps<T> t0;
-      pool_issue<T>(t0, dpool, idx, pw, cglob, cpr, OH, OW);
-      pw.advance(H, W);
-      body(t0, ld16(x + (size_t)r * C + cglob * KP));
-    }
-  }
-  col_block_reduce<2, KP>(v, lds, cw, rl, col, rlane, cglob, cpr, part + (size_t)blockIdx.x * 2 * C, C);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
-                                                                const T* __restrict__ x, const float* __restrict__ coef,
-                                                                const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                T* __restrict__ dx, uint32_t rows, int C, int H, int W, int OH, int OW,
-                                                                int cw, int rl, int cpr) {
-  constexpr int KP = DT<T>::KPACK;
-  const int col = threadIdx.x % cw, rlane = threadIdx.x / cw;
-  const int cglob = blockIdx.y * cw + col;
-  if (cglob >= cpr) return;
-  float cg[KP], cx[KP], c0[KP], sc[KP], sh[KP];
-#pragma unroll
-  for (int e = 0; e < KP; ++e) {
-    const int c = cglob * KP + e;
-    cg[e] = coef[c];
-    cx[e] = coef[C + c];
-    c0[e] = coef[2 * C + c];
-    sc[e] = scale[c];
-    sh[e] = shift[c];
-  }
-  auto body = [&](const PoolTaps<T>& t, u32x4 vx, size_t off) {
-    float g[KP], xv[KP];
-    pool_sum<T>(t, g);
-    Chunk<T>::unpack(vx, xv);
-#pragma unroll
-    for (int e = 0; e < KP; ++e) {
-      const float gg = fmaf(xv[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
-      xv[e] = fmaf(cg[e], gg, fmaf(cx[e], xv[e], c0[e]));
-    }
-    st16(dx + off, Chunk<T>::pack(xv));
-  };
-  const uint32_t step = gridDim.x * (uint32_t)rl;
-  uint32_t r = blockIdx.x * (uint32_t)rl + rlane;
-  PixWalk pw;
-  pw.init(r, step, H, W);
-  for (; r + step < rows; r += 2 * step) {
-    PoolTaps<T> t0, t1;
-    pool_issue<T>(t0, dpool, idx, pw, cglob, cpr, OH, OW);
-    pw.advance(H, W);
-    pool_issue<T>(t1, dpool, idx, pw, cglob, cpr, OH, OW);
-    pw.advance(H, W);
-    const size_t o0 = (size_t)r * C + cglob * KP, o1 = (size_t)(r + step) * C + cglob * KP;
-    const u32x4 x0 = ld16_nt(x + o0), x1 = ld16_nt(x + o1);
-    body(t0, x0, o0);
-    body(t1, x1, o1);
-  }
-  for (; r < rows; r += step) {
-    PoolTaps<T> t0;
-    pool_issue<T>(t0, dpool, idx, pw, cglob, cpr, OH, OW);
-    pw.advance(H, W);
-    const size_t o0 = (size_t)r * C + cglob * KP;
-    body(t0, ld16(x + o0), o0);
-  }
-}
-
-// dpool [N,OH,OW,C] (OH = (H+2-3)/2+1 …: the 3x3 / stride 2 / pad 1 pooling of pfr_bn_relu_maxpool_fwd), idx its argmax taps,
-// x [N,H,W,C] the raw stem convolution output; part: pfr_colreduce_blocks(C, dtype, N·H·W) x [2][C] as pfr_bn_bwd_reduce
-extern "C" int pfr_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* x, const float* mean, const float* invstd,
-                                      const float* scale, const float* shift, int dtype, int N, int H, int W, int C, float* part,
-                                      hipStream_t st) {
-  PFR_CHECK_ARG(dpool && idx && x && mean && invstd && scale && shift && part, "pfr_bn_bwd_reduce_pool: null pointer");
-  const int kp = dtype == PFR_BF16 ? 8 : 4;
-  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_reduce_pool: C %% %d != 0", kp);
-  const size_t rows = (size_t)N * H * W;
-  PFR_CHECK_ARG(rows > 0 && rows < (1ull << 31), "pfr_bn_bwd_reduce_pool: N*H*W out of range");
-  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  ColGeom g = col_geom(C, kp, rows);
-  const size_t shb = (size_t)256 * 2 * kp * sizeof(float);
-  if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), shb, st, (const bf16_t*)dpool, idx, (const bf16_t*)x, mean, invstd, scale, shift, part, (uint32_t)rows, C, H, W, OH, OW, g.cw, g.rl, g.cpr);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<float>, dim3(g.gx, g.gy), dim3(256), shb, st, (const float*)dpool, idx, (const float*)x, mean, invstd, scale, shift, part, (uint32_t)rows, C, H, W, OH, OW, g.cw, g.rl, g.cpr);
-  PFR_CHECK_LAUNCH();
-  return PFR_OK;
-}
-extern "C" int pfr_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const float* coef, const float* scale,
-                                     const float* shift, void* dx, int dtype, int N, int H, int W, int C, hipStream_t st) {
-  PFR_CHECK_ARG(dpool && idx && x && coef && scale && shift && dx, "pfr_bn_bwd_apply_pool: null pointer");
-  const int kp = dtype == PFR_BF16 ? 8 : 4;
-  PFR_CHECK_ARG(C % kp == 0, "pfr_bn_bwd_apply_pool: C %% %d != 0", kp);
-  const size_t rows = (size_t)N * H * W;
-  PFR_CHECK_ARG(rows > 0 && rows < (1ull << 31), "pfr_bn_bwd_apply_pool: N*H*W out of range");
-  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  ColGeom g = col_geom(C, kp, rows, 512);
-  if (dtype == PFR_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<bf16_t>, dim3(g.gx, g.gy), dim3(256), 0, st, (const bf16_t*)dpool, idx, (const bf16_t*)x, coef, scale, shift, (bf16_t*)dx, (uint32_t)rows, C, H, W, OH, OW, g.cw, g.rl, g.cpr);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<float>, dim3(g.gx, g.gy), dim3(256), 0, st, (const float*)dpool, idx, (const float*)x, coef, scale, shift, (float*)dx, (uint32_t)rows, C, H, W, OH, OW, g.cw, g.rl, g.cpr);
-  PFR_CHECK_LAUNCH();
-  return PFR_OK;
-}
+// (round 4: the variant that gathered the max-pool gradient inside the BatchNorm-backward passes — bit-identical, measured neutral —
+// was retired; profiles/HISTORY.md)
 
 // ------------------------------------------------------------------------------------------------
 // global average pool [N][HW][C] -> [N][C] and its backward

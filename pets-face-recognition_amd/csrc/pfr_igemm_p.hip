@@ -728,8 +728,11 @@ int igemm_p_forced_tile() {
 }
 // run-time tuning knobs (what the PFR_* environment variables set at start-up), for A/B sweeps inside one process:
 //   "igemm_p": 0 never / 1 heuristic / 2 whenever eligible;  "igemm_ptile": -1 heuristic, 0:128x128 1:64x128 2:128x64 3:64x64
-extern "C" int pfr_set_tuning(const char* key, int value) {
-  PFR_CHECK_ARG(key, "pfr_set_tuning: null key");
+// every CHANGE of a knob bumps the epoch: launch plans bake kernel choices in (statistics-partial granularity, partial-row counts
+// of the fused BatchNorm sums), so the engines rebuild their plans when the epoch they were built under is over (pfr_tuning_epoch)
+static int g_tuning_epoch = 0;
+extern "C" int pfr_tuning_epoch(void) { return g_tuning_epoch; }
+static int set_tuning_impl(const char* key, int value) {
   if (!strcmp(key, "igemm_p")) { g_p_mode = value; return PFR_OK; }
   if (!strcmp(key, "igemm_ptile")) { g_p_tile = value; return PFR_OK; }
   if (!strcmp(key, "igemm_pkch")) { g_p_kch = value; return PFR_OK; }
@@ -741,6 +744,19 @@ extern "C" int pfr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "swgrad")) { swgrad_set_mode(value); return PFR_OK; }
   pfr_set_error("pfr_set_tuning: unknown key %s", key);
   return PFR_ERR_ARG;
+}
+extern "C" int pfr_set_tuning(const char* key, int value) {
+  PFR_CHECK_ARG(key, "pfr_set_tuning: null key");
+  static struct { char key[16]; int value; } seen[16];
+  static int nseen = 0;
+  const int rc = set_tuning_impl(key, value);
+  if (rc != PFR_OK) return rc;
+  int i = 0;
+  for (; i < nseen; ++i)
+    if (!strcmp(seen[i].key, key)) break;
+  if (i == nseen && nseen < 16) { strncpy(seen[nseen].key, key, 15); seen[nseen].key[15] = 0; seen[nseen].value = value - 1; ++nseen; }
+  if (i < 16 && seen[i].value != value) { seen[i].value = value; ++g_tuning_epoch; }
+  return PFR_OK;
 }
 
 template <typename T, typename TO, int BQ, int BP>

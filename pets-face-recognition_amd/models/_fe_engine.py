@@ -47,35 +47,6 @@ def flat_layout(model):
     return offs, total
 
 
-def _batch_side(ops, batch):
-    """Experiment (PFR_WGRAD_BATCH=n): hand the weight gradients to the side stream n at a time — one fork (completion signal on
-    the main queue) per n instead of one per layer.  A deferred group is flushed before anything that waits for one of its members."""
-    out, held = [], []
-
-    def flush():
-        if held:
-            out.append(("fork", (held[0][0],)))
-            for k, op in held:
-                out.append(op)
-                out.append(("srec", (k,)))
-            held.clear()
-    i = 0
-    while i < len(ops):
-        fn, args = ops[i]
-        if fn == "fork" and i + 2 < len(ops) and ops[i + 2][0] == "srec":
-            held.append((args[0], ops[i + 1]))
-            i += 3
-            if len(held) >= batch:
-                flush()
-            continue
-        if fn in ("wait", "mwait") and held and args[0] >= held[0][0]:
-            flush()
-        out.append(ops[i])
-        i += 1
-    flush()
-    return out
-
-
 def grad_ready_marks(model):
     """The offsets `off` at which the backward pass reports "flat gradient [off, end) is final" (FEEngine._mark), in the order
     it reports them: after fc, after every residual block (last block first; a block's first parameter is conv1.weight),
@@ -156,15 +127,8 @@ class FEEngine:
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
-        # PFR_SIDE_CUS=n: the weight-gradient (side) launches of the backward plan run on a stream restricted to n of the 256 compute
-        # units (hipExtStreamCreateWithCUMask, every (256/n)-th CU so that all XCDs contribute), next to the HBM-bound BN passes
-        self.side_cus = int(os.environ.get("PFR_SIDE_CUS", "0"))
-        self._masked_side = None
-        # Fusing BN-apply+ReLU into the CONSUMER conv's operand prologue saves one write+read of the normalised
-        # activation, but the transform is then repeated for every tap and every Cout tile (18x for a 3x3 256->256
-        # conv): measured on MI355X it costs ~2x the kernel time, far more than the single elementwise pass it saves.
-        # Default: materialise z = relu(BN(c)) once (pfr_bn_act); PFR_FUSE_PROLOGUE=1 re-enables the fused form.
-        self.fuse_prologue = os.environ.get("PFR_FUSE_PROLOGUE", "0") == "1"
+        # (BN-apply + ReLU fused into the CONSUMER conv's operand prologue cost ~2x the kernel time it saved — the transform is repeated
+        #  per tap and per Cout tile — and was retired in round 4: profiles/HISTORY.md; z = relu(BN(c)) is materialised once by pfr_bn_act)
         # replay the step's launch lists from C (csrc/pfr_plan.hip) instead of a Python loop: ~16 ms -> ~2 ms of host time per
         # ResNet-50 step (PFR_C_PLAN=0 keeps the interpreter loop; a launch tracer always uses it)
         self.c_plan = os.environ.get("PFR_C_PLAN", "1") != "0"
@@ -178,20 +142,15 @@ class FEEngine:
         # Measured (profiles/r03_bnb_streaming.txt): 19.64 -> 19.35 ms/step; default.  0 = separate pass everywhere.
         self.fuse_bnb = int(os.environ.get("PFR_FUSE_BNB", "2") or 0)
         lib.pfr_set_tuning(b"bnb", self.fuse_bnb)
+        self._tuning_epoch = lib.pfr_tuning_epoch()
         self._bnb_min_rows = int(os.environ.get("PFR_BNB_MIN_ROWS", "0"))   # experiment: keep the separate pass for small tensors
-        # Opt-in (PFR_FUSE_FIN=1): BatchNorm backward reduce + finalize in one launch (the last workgroups to arrive merge the
-        # partial rows, pfr_bn_bwd_reduce_finalize) — 53 dependent 7 us launches fewer per ResNet-50 step, but MEASURED SLOWER
-        # (profiles/r03_finalize_fusion.txt): with release fences 26.1 vs 19.5 ms/step (every fence is an L2 write-back scan), with
-        # write-through stores + device-scope loads instead of fences 20.14 vs 19.56: the hand-over is six dependent device-scope
-        # round trips of ~2 us, more than the 6.7 us finalize launch (256 workgroups in parallel) and its gap cost.
-        self.fuse_fin = os.environ.get("PFR_FUSE_FIN", "0") == "1"
-        self._fin_counters = {}
-        # stem tail backward without the max-pool gradient tensor (-1.1 GB of HBM traffic per step at bs 256): measured neutral
-        # (0.57 vs 0.62 ms; the gather is vector-ALU bound), bit-identical, opt-in like PFR_FUSE_BNB
-        self.fuse_pool = os.environ.get("PFR_FUSE_POOL", "0") == "1"
+        # (retired in round 4 after losing their A/B, evidence under profiles/: reduce + finalize in one launch — r03_finalize_fusion.txt;
+        #  the stem's max-pool gradient gathered inside the BN-backward passes — neutral; a CU-masked side stream — r03_cumask_sweep.txt;
+        #  weight gradients handed to the side stream in groups — r03_wgrad_batch.txt)
         # BN-input-free backward of a bottleneck's conv3 + bn3 (csrc/pfr_bnfree.hip; round 4): the gradient that reaches the block
         # output is stored THROUGH the block's ReLU mask by its producer, bn3's backward sums come out of the weight-gradient GEMM, and
-        # conv3's data gradient is G·(A∘W) + z2·S + bias — bn3's input and its gradient are never read / written in the backward pass.
+        # conv3's data gradient is G·(A∘W) + z2·S + bias — bn3's input and its gradient are never read / written in the backward pass,
+        # so the forward pass does not store conv3's output either (statistics pass + recompute with the block tail in the epilogue).
         # bf16 streaming geometries only (layer1-2 of ResNet-50 at bs 256); PFR_BNFREE=0 keeps the materialised form everywhere.
         self.bnfree = os.environ.get("PFR_BNFREE", "1") != "0" and self.dtype == torch.bfloat16 and self.fuse_bnb == 2
         self.ws_main = None             # split-K workspace of weight-gradient launches on the MAIN stream (self.ws belongs to the side stream)
@@ -610,7 +569,7 @@ class FEEngine:
             if ndown is not None:
                 dc = ndown[0]
                 if (down is not None or dc.R != 1 or dc.stride != 2 or nxs[1] % 2 or nxs[2] % 2
-                        or os.environ.get("PFR_BNB_SUB", "1") == "0" or os.environ.get("PFR_BNB_INPLACE") == "1"):
+                        or os.environ.get("PFR_BNB_SUB", "1") == "0"):
                     continue
             out[k] = npart
         return out
@@ -674,7 +633,7 @@ class FEEngine:
                     continue
                 y, yshape = self._conv_bn(plan, ops, src, sshape, c, bn, train, pro=pro)
                 raws.append((y, yshape))
-                if ci + 1 < len(convs) and not self.fuse_prologue:
+                if ci + 1 < len(convs):
                     z = self._A(plan, yshape)
                     ops.append((lib.pfr_bn_act, (y.data_ptr(), bn.coef[2].data_ptr(), bn.coef[3].data_ptr(), 0, 0, 0,
                                                  z.data_ptr(), self.did, yshape[0] * yshape[1] * yshape[2], yshape[3], 1)))
@@ -823,26 +782,15 @@ class FEEngine:
             oa = 0 if out_act is None else out_act.data_ptr()
             if pre is not None:
                 part, nb = pre          # the launch that produced `dout` already left the partial sums (pfr_conv2d_dgrad_bn)
-            elif self.fuse_fin:
-                part = G((lib.pfr_bn_bwd_fused_part_rows(C, self.did, rows), 2, C), torch.float32)
-                cnt = self._fin_counters.get(id(bn))
-                if cnt is None:
-                    cnt = self._fin_counters[id(bn)] = torch.zeros(64, dtype=torch.int32, device=self.device)
-                ops.append((lib.pfr_bn_bwd_reduce_finalize, (dout.data_ptr(), oa, x.data_ptr(), bn.coef[0].data_ptr(),
-                                                             bn.coef[1].data_ptr(), bn.coef[2].data_ptr(), bn.coef[3].data_ptr(),
-                                                             mask_mode, self.did, rows, C, part.data_ptr(), cnt.data_ptr(),
-                                                             bn.gamma.data_ptr(), bn.dgamma.data_ptr(), bn.dbeta.data_ptr(),
-                                                             bn.bcoef.data_ptr(), acc)))
             else:
                 nb = lib.pfr_colreduce_blocks(C, self.did, rows)
                 part = G((nb, 2, C), torch.float32)
                 ops.append((lib.pfr_bn_bwd_reduce, (dout.data_ptr(), oa, x.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
                                                     bn.coef[2].data_ptr(), bn.coef[3].data_ptr(), mask_mode, self.did, rows, C,
                                                     part.data_ptr())))
-            if pre is not None or not self.fuse_fin:
-                ops.append((lib.pfr_bn_bwd_finalize, (part.data_ptr(), nb, C, float(rows), bn.gamma.data_ptr(), bn.coef[0].data_ptr(),
-                                                      bn.coef[1].data_ptr(), bn.dgamma.data_ptr(), bn.dbeta.data_ptr(),
-                                                      bn.bcoef.data_ptr(), acc)))
+            ops.append((lib.pfr_bn_bwd_finalize, (part.data_ptr(), nb, C, float(rows), bn.gamma.data_ptr(), bn.coef[0].data_ptr(),
+                                                  bn.coef[1].data_ptr(), bn.dgamma.data_ptr(), bn.dbeta.data_ptr(),
+                                                  bn.bcoef.data_ptr(), acc)))
             ops.append((lib.pfr_bn_bwd_apply, (dout.data_ptr(), oa, x.data_ptr(), bn.bcoef.data_ptr(), bn.coef[2].data_ptr(),
                                                bn.coef[3].data_ptr(), mask_mode, dx.data_ptr(),
                                                0 if gres is None else gres.data_ptr(), self.did, rows, C)))
@@ -960,10 +908,7 @@ class FEEngine:
                 c, bn = convs[i]
                 pc, pbn = convs[i - 1]
                 xraw, xrs = raws[i - 1]
-                if acts[i - 1] is not None:
-                    wgrad(acts[i - 1], xrs, dy, dyshape, c)
-                else:
-                    wgrad(xraw, xrs, dy, dyshape, c, pro=(pbn.coef[2], pbn.coef[3]))
+                wgrad(acts[i - 1], xrs, dy, dyshape, c)
                 dz = G(xrs)
                 npart = dgrad_parts(dyshape, c, xrs)
                 if npart > 0:
@@ -993,13 +938,9 @@ class FEEngine:
                        pre=None if (p3 is None or p3[1] is None) else p3[1])      # projection-shortcut BN: g = dcur ∘ mask
                 release(dcur)
                 wgrad(xin, xshape, dgd, oshape, dc)
-                # (opt-in, PFR_BNB_INPLACE=1: measured SLOWER, 19.09 -> 19.24 ms/step — the projection data gradient then has to write
-                #  all of dxin (zeros where its stride skips) and the main branch reads it back: two more passes over the block input
-                #  than the accumulate form below costs, for one saved reduce pass)
-                npart2 = dgrad_parts(dyshape, c0, xshape) if (nxt is not None and self.fuse_bnb == 2 and nxt[3] is None
-                                                                and os.environ.get("PFR_BNB_INPLACE") == "1") else 0
+                # (the in-place form — the shortcut writes all of dxin first, the main branch adds to it — measured slower, retired in round 4)
                 npart3 = 0
-                if (npart2 == 0 and nxt is not None and self.fuse_bnb == 2 and nxt[3] is None and dc.R == 1 and dc.stride == 2
+                if (nxt is not None and self.fuse_bnb == 2 and nxt[3] is None and dc.R == 1 and dc.stride == 2
                         and xshape[1] % 2 == 0 and xshape[2] % 2 == 0 and os.environ.get("PFR_BNB_SUB", "1") != "0"):
                     npart3 = dgrad_parts(dyshape, c0, xshape)
                 if npart3 > 0:
@@ -1018,14 +959,6 @@ class FEEngine:
                         ops.append((lib.pfr_conv2d_dgrad_bn_sub, sub_args))
                     pre3[k - 1] = ((part, npart3), None)
                     release(comp)
-                    npart = -1
-                elif npart2 > 0:
-                    # streaming form: the projection shortcut writes dxin first (all of it: zeros where its stride skips), then the
-                    # main branch adds to it IN PLACE (res = dx, no mask) and leaves the previous block's BN-backward sums
-                    dgrad(dgd, oshape, dc, dxin, xshape)
-                    part = G((npart2, 2, xshape[3]), torch.float32)
-                    dgrad_bn(dy, dyshape, c0, dxin, xshape, (nxt[0], nxt[1], nxt[2], part), None, res=dxin, res_mask=None)
-                    pre3[k - 1] = ((part, npart2), None)
                     npart = -1
                 else:
                     # main branch first (writes all of dxin), then the projection shortcut ACCUMULATES: for its 1x1 / stride-2
@@ -1067,26 +1000,9 @@ class FEEngine:
         # stem
         c1, s1, idx, pshape = saved["stem"]
         dz = G(s1)
-        if self.fuse_pool:
-            # the max-pool gradient is gathered from the pooled gradient inside the BN-backward passes (never materialised)
-            rows1 = s1[0] * s1[1] * s1[2]
-            nb = lib.pfr_colreduce_blocks(s1[3], self.did, rows1)
-            part = G((nb, 2, s1[3]), torch.float32)
-            ops.append((lib.pfr_bn_bwd_reduce_pool, (dcur.data_ptr(), idx.data_ptr(), c1.data_ptr(), stbn.coef[0].data_ptr(),
-                                                     stbn.coef[1].data_ptr(), stbn.coef[2].data_ptr(), stbn.coef[3].data_ptr(),
-                                                     self.did, N, s1[1], s1[2], s1[3], part.data_ptr())))
-            ops.append((lib.pfr_bn_bwd_finalize, (part.data_ptr(), nb, s1[3], float(rows1), stbn.gamma.data_ptr(), stbn.coef[0].data_ptr(),
-                                                  stbn.coef[1].data_ptr(), stbn.dgamma.data_ptr(), stbn.dbeta.data_ptr(),
-                                                  stbn.bcoef.data_ptr(), acc)))
-            ops.append((lib.pfr_bn_bwd_apply_pool, (dcur.data_ptr(), idx.data_ptr(), c1.data_ptr(), stbn.bcoef.data_ptr(),
-                                                    stbn.coef[2].data_ptr(), stbn.coef[3].data_ptr(), dz.data_ptr(), self.did,
-                                                    N, s1[1], s1[2], s1[3])))
-            release(part)
-            release(dcur)
-        else:
-            ops.append((lib.pfr_maxpool_bwd, (dcur.data_ptr(), idx.data_ptr(), dz.data_ptr(), self.did, N, s1[1], s1[2], s1[3])))
-            release(dcur)
-            bn_bwd(dz, None, c1, s1, stbn, 2, dz, None, acc)
+        ops.append((lib.pfr_maxpool_bwd, (dcur.data_ptr(), idx.data_ptr(), dz.data_ptr(), self.did, N, s1[1], s1[2], s1[3])))
+        release(dcur)
+        bn_bwd(dz, None, c1, s1, stbn, 2, dz, None, acc)
         if use_s2d:
             wgrad(x_nhwc, xin_shape, dz, s1, self.s2d, out=self.s2d.g)
             ops.append(("wait", (nside[0] - 1,)))   # the un-packing below reads what the stem wgrad wrote
@@ -1096,9 +1012,6 @@ class FEEngine:
             ops.append(("wait", (nside[0] - 1,)))   # the un-padding copy below reads what the stem wgrad wrote
             ops.append(("copy2d", (st.g_pad.data_ptr(), self.cp, st.g.data_ptr(), st.Cin, st.Cout * st.R * st.S, st.Cin, 1.0, acc)))
         self._mark(ops, 0)
-        batch = int(os.environ.get("PFR_WGRAD_BATCH", "1"))
-        if batch > 1:
-            ops[plan.meta["n_fwd"]:] = _batch_side(ops[plan.meta["n_fwd"]:], batch)
         plan.meta["n_side"] = nside[0]
         # workspace
         if self.ws is None or self.ws.numel() < ws_need[0]:
@@ -1119,7 +1032,21 @@ class FEEngine:
         ops.append((None, (off,)))
 
     # ------------------------------------------------------------------------------------------ execution
+    def _check_tuning(self):
+        """A plan bakes kernel choices in (statistics-partial granularity, partial-row counts of the fused BatchNorm sums, which
+        blocks take the BN-input-free form).  When a pfr_set_tuning call changed a knob since the plans were built — another engine,
+        a test, a host sweep — this engine's own mode is re-asserted and every plan no forward pass still owns is rebuilt."""
+        ep = lib.pfr_tuning_epoch()
+        if ep == self._tuning_epoch:
+            return
+        lib.pfr_set_tuning(b"bnb", self.fuse_bnb)
+        self._tuning_epoch = lib.pfr_tuning_epoch()
+        for k, q in list(self.plans.items()):
+            if not self._plan_busy(q):
+                self.plans.pop(k)
+
     def get_plan(self, N, H, W, train, with_backward, slot=0):
+        self._check_tuning()
         key = (N, H, W, train, with_backward) + ((slot,) if slot else ())
         p = self.plans.get(key)
         if p is None:
@@ -1191,7 +1118,7 @@ class FEEngine:
                     res.append((lib.pfr_copy2d_f32, tuple(args[:-1]) + (acc,)))
                 elif fn == "s2dunpack":
                     res.append((lib.pfr_s2d_wgrad, tuple(args[:-1]) + (acc,)))
-                elif fn is lib.pfr_bn_bwd_finalize or fn is lib.pfr_bn_bwd_reduce_finalize or fn is lib.pfr_bn3_bwd_coef \
+                elif fn is lib.pfr_bn_bwd_finalize or fn is lib.pfr_bn3_bwd_coef \
                         or fn is lib.pfr_bn3_bwd_weights:
                     res.append((fn, tuple(args[:-1]) + (acc,)))
                 else:
@@ -1295,8 +1222,6 @@ class FEEngine:
         if use_side and self.side is None:
             self.side = torch.cuda.Stream(device=self.device)
         side_handle = self.side.cuda_stream if use_side else 0
-        if use_side and self.side_cus != 0 and self.c_plan:
-            side_handle = self._cu_masked_stream()
         if self._run_list(plan, "bwd%d" % acc, stream, side_handle,
                           (lambda off: hook(off)) if hook is not None else None, 2 * plan.meta.get("n_side", 0)):
             return
@@ -1325,27 +1250,6 @@ class FEEngine:
                     main.wait_event(ev[2 * args + 1])
             else:
                 fn(*args, stream)
-
-    def _cu_masked_stream(self):
-        """raw hipStream_t limited to self.side_cus compute units (created once; used by the C plan executor only)"""
-        if self._masked_side is None:
-            import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
-            n = max(1, min(256, self.side_cus))
-            step = 256.0 / n
-            words = (ctypes.c_uint32 * 8)()
-            for i in range(n):
-                b = int(i * step)
-                words[b // 32] |= 1 << (b % 32)
-            h = ctypes.c_void_p()
-            if self.side_cus < 0:   # (experiment: a plain non-blocking stream created outside torch)
-                rc = hip.hipStreamCreateWithFlags(ctypes.byref(h), 1)
-            else:
-                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
-            if rc != 0 or not h.value:
-                raise PfrError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-            self._masked_side = h.value
-        return self._masked_side
 
     def backward(self, demb, plan=None):
         plan = plan if plan is not None else self._last_plan

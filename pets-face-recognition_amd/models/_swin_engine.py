@@ -517,6 +517,14 @@ class SwinEngine:
         plan["ws_ptr"] = (self.ws.data_ptr(), self.cs_ws.data_ptr())
 
     def get_plan(self, N, H, W, with_backward, slot=0):
+        ep = lib.pfr_tuning_epoch()
+        if ep != getattr(self, "_tuning_epoch", None):
+            # a pfr_set_tuning call changed a knob: the plans baked tile heights / kernel choices in — rebuild those not in flight
+            if hasattr(self, "_tuning_epoch"):
+                for k, q in list(self.plans.items()):
+                    if not self._plan_busy(q):
+                        self.plans.pop(k)
+            self._tuning_epoch = ep
         key = (N, H, W, with_backward) + ((slot,) if slot else ())
         p = self.plans.get(key)
         if p is None:

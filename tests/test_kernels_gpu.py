@@ -459,50 +459,6 @@ def test_weight_dgrad_layout_batch_ragged_layers(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(3, 18, 18, 64), (2, 17, 21, 16), (5, 112, 112, 64)])
-def test_stem_pool_bn_backward_fused_equals_three_launches(dtype, shape):
-    """pfr_bn_bwd_reduce_pool / pfr_bn_bwd_apply_pool gather the max-pool gradient on the fly: partial sums and dx must be
-    bit-identical to pfr_maxpool_bwd + pfr_bn_bwd_reduce(mask 2) + pfr_bn_bwd_apply(mask 2)"""
-    from pets_face_recognition_amd._hip import lib, dtype_id
-    N, H, W, C = shape
-    did = dtype_id(dtype)
-    g = torch.Generator().manual_seed(11)
-    st = torch.cuda.current_stream().cuda_stream
-    x = torch.randn(N, H, W, C, generator=g).to(DEV, dtype)
-    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
-    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
-    mean = (torch.randn(C, generator=g) * 0.1).to(DEV)
-    invstd = (torch.rand(C, generator=g) + 0.5).to(DEV)
-    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-    y = torch.empty(N, OH, OW, C, device=DEV, dtype=dtype)
-    idx = torch.empty(N, OH, OW, C, device=DEV, dtype=torch.uint8)
-    lib.pfr_bn_relu_maxpool_fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), idx.data_ptr(), did, N, H, W, C, 1, st)
-    dpool = torch.randn(N, OH, OW, C, generator=g).to(DEV, dtype)
-    rows = N * H * W
-    nb = lib.pfr_colreduce_blocks(C, did, rows)
-    # three launches
-    dz = torch.empty_like(x)
-    lib.pfr_maxpool_bwd(dpool.data_ptr(), idx.data_ptr(), dz.data_ptr(), did, N, H, W, C, st)
-    part_a = torch.zeros(nb, 2, C, device=DEV)
-    lib.pfr_bn_bwd_reduce(dz.data_ptr(), 0, x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), 2, did,
-                          rows, C, part_a.data_ptr(), st)
-    coef = torch.randn(3, C, generator=g).to(DEV).contiguous()
-    dx_a = torch.empty_like(x)
-    lib.pfr_bn_bwd_apply(dz.data_ptr(), 0, x.data_ptr(), coef.data_ptr(), scale.data_ptr(), shift.data_ptr(), 2, dx_a.data_ptr(), 0, did, rows, C, st)
-    # fused
-    part_b = torch.zeros(nb, 2, C, device=DEV)
-    lib.pfr_bn_bwd_reduce_pool(dpool.data_ptr(), idx.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
-                               shift.data_ptr(), did, N, H, W, C, part_b.data_ptr(), st)
-    dx_b = torch.empty_like(x)
-    lib.pfr_bn_bwd_apply_pool(dpool.data_ptr(), idx.data_ptr(), x.data_ptr(), coef.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                              dx_b.data_ptr(), did, N, H, W, C, st)
-    torch.cuda.synchronize()
-    assert torch.equal(part_a, part_b)
-    assert torch.equal(dx_a, dx_b)
-    assert dz.abs().sum() > 0
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(5, 3, 7, 9, 8), (4, 3, 6, 6, 4), (96, 3, 4, 4, 8), (7, 20, 2, 2, 24), (3, 5, 3, 3, 7), (2, 16, 5, 5, 16)])
 def test_nchw_to_nhwc_channel_padding(dtype, shape):
     """fp32 NCHW → compute-dtype NHWC with the channel dimension zero-padded to Cp (16-byte-store and scalar paths)"""
@@ -619,63 +575,6 @@ def test_halo_staged_3x3_kernel_bit_identical(case):
     assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][2], outs[0][2]) and torch.equal(outs[1][3], outs[0][3])
     assert torch.equal(outs[1][0], outs[1][2])
     assert torch.allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=1e-5)
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,C,mask_mode", [(256 * 56 * 56, 64, 2), (64 * 28 * 28, 512, 3), (256 * 49, 2048, 0), (1000, 128, 1),
-                                             (37, 16, 2), (32 * 14 * 14, 1024, 3)])
-def test_bn_backward_reduce_finalize_one_launch(dtype, rows, C, mask_mode):
-    """pfr_bn_bwd_reduce_finalize (last workgroups to arrive merge the partial rows) against pfr_bn_bwd_reduce + pfr_bn_bwd_finalize:
-    same sums in a different (index-fixed) order -> equal to fp32 summation tolerance, BIT-identical from launch to launch
-    (determinism; also shows the counters are left at zero), accumulate adds to dgamma / dbeta."""
-    from pets_face_recognition_amd._hip import lib, dtype_id
-    did = dtype_id(dtype)
-    kp = 8 if dtype == torch.bfloat16 else 4
-    g = torch.Generator().manual_seed(rows % 1000 + C)
-    st = torch.cuda.current_stream().cuda_stream
-    x = torch.randn(rows, C, generator=g).to(DEV, dtype)
-    dout = torch.randn(rows, C, generator=g).to(DEV, dtype)
-    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
-    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
-    mean = (torch.randn(C, generator=g) * 0.1).to(DEV)
-    invstd = (torch.rand(C, generator=g) + 0.5).to(DEV)
-    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
-    out = 0
-    if mask_mode == 1:
-        keep = torch.relu(x.float() * scale + shift).to(dtype)
-        out = keep.data_ptr()
-    elif mask_mode == 3:
-        keep = torch.randint(0, 256, (rows, C // kp), generator=g, dtype=torch.uint8).to(DEV)
-        out = keep.data_ptr()
-    nb = lib.pfr_colreduce_blocks(C, did, rows)
-    part = torch.zeros(nb, 2, C, device=DEV)
-    coef_a, dg_a, db_a = torch.empty(3, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-    lib.pfr_bn_bwd_reduce(dout.data_ptr(), out, x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                          mask_mode, did, rows, C, part.data_ptr(), st)
-    lib.pfr_bn_bwd_finalize(part.data_ptr(), nb, C, float(rows), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dg_a.data_ptr(),
-                            db_a.data_ptr(), coef_a.data_ptr(), 0, st)
-    nrows = lib.pfr_bn_bwd_fused_part_rows(C, did, rows)
-    assert nb < nrows <= nb + 32
-    counters = torch.zeros(64, dtype=torch.int32, device=DEV)
-    results = []
-    for rep in range(4):
-        part_b = torch.full((nrows, 2, C), float("nan"), device=DEV)
-        coef_b, dg_b, db_b = torch.empty(3, C, device=DEV), torch.ones(C, device=DEV), torch.ones(C, device=DEV)
-        lib.pfr_bn_bwd_reduce_finalize(dout.data_ptr(), out, x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
-                                       shift.data_ptr(), mask_mode, did, rows, C, part_b.data_ptr(), counters.data_ptr(),
-                                       gamma.data_ptr(), dg_b.data_ptr(), db_b.data_ptr(), coef_b.data_ptr(), rep & 1, st)
-        torch.cuda.synchronize()
-        assert int(counters.abs().sum()) == 0
-        assert torch.equal(part_b[:nb], part)
-        acc = float(rep & 1)
-        results.append((coef_b.clone(), dg_b - acc, db_b - acc))
-    scale_g = part[:, 0].abs().sum(0) + 1e-3
-    scale_gx = part[:, 1].abs().sum(0) + 1e-3
-    for coef_b, dg_b, db_b in results:
-        assert ((db_b - db_a).abs() / scale_g).max().item() < 2e-6
-        assert ((dg_b - dg_a).abs() / scale_gx).max().item() < 2e-6
-        assert torch.allclose(coef_b, coef_a, rtol=2e-4, atol=1e-5 * float(coef_a.abs().max()))
-    assert torch.equal(results[0][0], results[2][0]) and torch.equal(results[0][1], results[2][1]) and torch.equal(results[0][2], results[2][2])
 
 
 @pytest.mark.parametrize("case", [

@@ -522,3 +522,40 @@ def test_bn_input_free_backward_of_conv3_bn3(monkeypatch):
         e1 = ((res["1"][0][n] - p64[n].grad).norm() / p64[n].grad.norm()).item()
         e0 = ((res["0"][0][n] - p64[n].grad).norm() / p64[n].grad.norm()).item()
         assert e1 <= 1.2 * e0 + 2e-3, (n, e1, e0)
+
+
+def test_resnet_plans_are_rebuilt_when_a_tuning_knob_changes():
+    """ADVICE r3 (_fe_engine.py:180) / VERDICT weak #8: the engine's plans bake statistics-partial granularities, fused-BatchNorm-sum
+    partial counts and the set of BN-input-free blocks in.  A pfr_set_tuning call after they were built (here: the streaming kernels
+    off, which changes all three) must make the engine rebuild them; the step then equals a fresh engine's under the new knobs."""
+    from oracle import resnet_ref
+    from pets_face_recognition_amd._hip import lib
+    sd = resnet_ref.init_state_dict("resnet50", 512, seed=4)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(8, 3, 128, 128, generator=g).to(DEV)
+    demb = (torch.randn(8, 512, generator=g) * 0.05).to(DEV)
+
+    def step(m):
+        for p in m.parameters():
+            p.grad = None
+        e = m(x)
+        e.backward(demb)
+        torch.cuda.synchronize()
+        return e.detach().clone(), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+
+    try:
+        lib.pfr_set_tuning(b"sconv", 2)
+        m = build("resnet50", torch.bfloat16, sd).train()
+        e_a, g_a = step(m)
+        assert m.hip_engine()._last_plan.meta["bnfree_blocks"] == [0, 1, 2, 3, 4, 5, 6]
+        lib.pfr_set_tuning(b"sconv", 0)              # no streaming kernels: tile-kernel partial granularity, no BN-input-free blocks
+        e_b, g_b = step(m)
+        assert m.hip_engine()._last_plan.meta["bnfree_blocks"] == []
+        m2 = build("resnet50", torch.bfloat16, sd).train()
+        # (the first step of m already moved its BN running statistics; the train-mode forward does not depend on them)
+        e_c, g_c = step(m2)
+        assert torch.equal(e_b, e_c) and torch.equal(g_b, g_c)
+        assert torch.isfinite(g_a).all() and ((g_a - g_b).norm() / g_b.norm()).item() < 3e-2
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+        lib.pfr_set_tuning(b"bnb", 0)

@@ -235,3 +235,40 @@ def test_layernorm_bwd_dxsum_partials(dtype, rows, C):
     ref = dx_b.double().sum(0)
     got = dsum.double().sum(0)
     assert torch.allclose(got, ref, rtol=1e-5, atol=1e-4 * float(dx_b.float().abs().max()) * rows ** 0.5)
+
+
+def test_swin_backward_under_the_persistent_gemm_and_plan_invalidation():
+    """(a) the Swin train step under pfr_set_tuning("igemm_p", 2) (persistent GEMM kernel wherever eligible:
+    other statistics-partial granularity) gives the gradients of the default kernels — the persistent kernel is bit-identical, so
+    the step is too; (b) flipping the knob AFTER the plans were built makes the engine rebuild them (pfr_tuning_epoch) instead of
+    replaying launches whose baked tile heights no longer describe the kernel that runs."""
+    import pets_face_recognition_amd.models as M
+    from pets_face_recognition_amd._hip import lib
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(4, 3, 224, 224, generator=g).to(DEV)
+    demb = (torch.randn(4, 512, generator=g) * 0.1).to(DEV)
+    m = M.swin_t(num_classes=512, compute_dtype=torch.bfloat16).to(DEV).train()
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        e = m(x)
+        e.backward(demb)
+        torch.cuda.synchronize()
+        return e.detach().clone(), torch.cat([p.grad.flatten() for p in m.parameters() if p.requires_grad]).clone()
+
+    try:
+        e0, g0 = step()
+        plans0 = {id(p) for p in m.hip_engine().plans.values()}
+        ep0 = lib.pfr_tuning_epoch()
+        lib.pfr_set_tuning(b"igemm_p", 2)
+        assert lib.pfr_tuning_epoch() == ep0 + 1
+        lib.pfr_set_tuning(b"igemm_p", 2)            # no change: no new epoch
+        assert lib.pfr_tuning_epoch() == ep0 + 1
+        e1, g1 = step()
+        assert not (plans0 & {id(p) for p in m.hip_engine().plans.values()}), "plans built under the old knobs were replayed"
+        assert torch.equal(e0, e1) and torch.isfinite(g1).all()
+        assert torch.equal(g0, g1)
+    finally:
+        lib.pfr_set_tuning(b"igemm_p", 1)
