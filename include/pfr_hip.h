@@ -147,13 +147,19 @@ int pfr_conv2d_dgrad_bn_sub_ex(const void* dy, const void* wt, void* dx, int dty
  *                        (G1[c][k] - dbeta_c zbar_k); coef [3][C] = A = gamma invstd, B = -gamma invstd^2 dgamma / M, C0 = -gamma invstd dbeta / M
  *   pfr_bn3_bwd_weights: dW = A*G1 + B*(W (G2 - M zbar zbar^T)) + C0 (x) (M zbar)   (fp32, += if accumulate);
  *                        wa_t [K][C] bf16 = A_c W[c][k] (data-gradient weight layout), S [K][K] bf16 = W^T diag(B) W, bias [K] = C0^T W - zbar S
- * and the data gradient is dZ = G wa_t^T + Z S + bias: pfr_conv2d_fwd(Z, S, bias) then pfr_conv2d_dgrad_bn(G, wa_t, res = that, no masks).
+ * and the data gradient is dZ = G wa_t^T + Z S + bias: pfr_conv2d_fwd(Z, S, bias) then pfr_conv2d_dgrad_bn(G, wa_t, res = that, no masks),
+ * or — S == NULL: wa_t is then ONE concatenated tensor wcat [K][C + K], row k = [A*W column k | S row k] — a single
+ * pfr_conv1x1_dgrad2_bn(G, Z, wcat, bias) launch over both row sources (bias added in fp32 inside the accumulators; BatchNorm-backward
+ * sums of the BN dZ feeds as pfr_conv2d_dgrad_bn with a recomputed ReLU mask; pfr_conv1x1_dgrad2_bn_parts = partial rows, 0 = not taken).
  * W = the fp32 master weights [C][K]; count = M rows. */
 int pfr_bn3_bwd_coef(const float* part, int nparts, const float* G1, const float* zsum, const float* W, const float* gamma,
                      const float* invstd, int C, int K, float count, float* dgamma, float* dbeta, float* coef, int accumulate,
                      pfr_stream_t stream);
 int pfr_bn3_bwd_weights(const float* coef, const float* G1, const float* G2, const float* zsum, const float* W, int C, int K, float count,
                         float* dW, void* wa_t, void* S, float* bias, int accumulate, pfr_stream_t stream);
+int pfr_conv1x1_dgrad2_bn_parts(int dtype, int N, int H, int W, int C1, int C2, int Cout);
+int pfr_conv1x1_dgrad2_bn(const void* g, const void* z, const void* wcat, const float* bias, void* dx, int dtype, int N, int H, int W,
+                          int C1, int C2, int Cout, const void* bn_x, const float* bn_coef, float* bn_part, pfr_stream_t stream);
 
 /* G2 = X^T X [Q][Q] and the column sums of X [Q] in ONE streaming pass over X [M][Q] (bf16, Q = 64 | 128): the two forward-only inputs
  * of pfr_bn3_bwd_coef / pfr_bn3_bwd_weights.  out = Q*Q floats then Q floats; workspace = pfr_gram_ws_floats(M, Q) floats (0: geometry

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void bn3_weights_kernel(const float* __restric
                                                           const float* __restrict__ G2, const float* __restrict__ zsum,
                                                           const float* __restrict__ W, int C, int K, float count,
                                                           float* __restrict__ dW, bf16_t* __restrict__ wa_t, bf16_t* __restrict__ S,
-                                                          float* __restrict__ bias, int accumulate) {
+                                                          float* __restrict__ bias, int accumulate, int ldw, int lds_) {
   __shared__ float red[256];
   const int tid = threadIdx.x;
   const float inv_m = 1.f / count;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bn3_weights_kernel(const float* __restric
     if (tid < K) {
       for (int q = 1; q < np; ++q) s += red[q * K + tid];     // fixed order
       const bf16_t sb = (bf16_t)s;
-      S[(size_t)tid * K + k] = sb;    // symmetric: row / column orientation is the same matrix
+      S[(size_t)tid * lds_ + k] = sb;    // symmetric: row / column orientation is the same matrix
       // bias_k = sum_c C0_c W[c][k] - sum_j zbar_j S_bf16[j][k]   (the ROUNDED S: the two terms then cancel as (Z - zbar)·S does)
       b = -(zsum[tid] * inv_m) * (float)sb;
     }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void bn3_weights_kernel(const float* __restric
     const float w = W[(size_t)c * K + k];
     const float v = fmaf(A, G1[(size_t)c * K + k], fmaf(B, t, C0 * zsum[k]));
     dW[(size_t)c * K + k] = accumulate ? dW[(size_t)c * K + k] + v : v;
-    wa_t[(size_t)k * C + c] = (bf16_t)(A * w);
+    wa_t[(size_t)k * ldw + c] = (bf16_t)(A * w);
   }
 }
 
@@ -110,10 +110,13 @@ extern "C" int pfr_bn3_bwd_coef(const float* part, int nparts, const float* G1, 
 
 extern "C" int pfr_bn3_bwd_weights(const float* coef, const float* G1, const float* G2, const float* zsum, const float* W, int C, int K,
                                    float count, float* dW, void* wa_t, void* S, float* bias, int accumulate, hipStream_t st) {
-  PFR_CHECK_ARG(coef && G1 && G2 && zsum && W && dW && wa_t && S && bias, "pfr_bn3_bwd_weights: null pointer");
+  PFR_CHECK_ARG(coef && G1 && G2 && zsum && W && dW && wa_t && bias, "pfr_bn3_bwd_weights: null pointer");
+  // S == NULL: ONE concatenated weight tensor wa_t = wcat [K][C + K], row k = [A∘W column k | S row k] (pfr_conv1x1_dgrad2_bn)
+  const int ldw = S ? C : C + K, lds_ = S ? K : C + K;
+  if (!S) S = (bf16_t*)wa_t + C;
   PFR_CHECK_ARG(C > 0 && (K == 64 || K == 128 || K == 256) && count > 0.f, "pfr_bn3_bwd_weights: K must be 64, 128 or 256");
   hipLaunchKernelGGL(bn3_weights_kernel, dim3(K + (C + 3) / 4), dim3(256), 0, st, coef, G1, G2, zsum, W, C, K, count, dW, (bf16_t*)wa_t,
-                     (bf16_t*)S, bias, accumulate);
+                     (bf16_t*)S, bias, accumulate, ldw, lds_);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

@@ -55,6 +55,11 @@ struct SconvParams {
   // sign of the pre-ReLU value as one bit per element (mask_out [M][N/8]) — pfr_bn_act_mask's arithmetic in this epilogue
   const float* tail_a1; const float* tail_b1; const float* tail_a2; const float* tail_b2;
   unsigned char* mask_out;
+  // EP 12 (two-source data gradient): the reduction runs over [x | x2] — x [M][K - K2] followed by x2 [M][K2] — against weight rows of
+  // K columns, and the accumulators start from cbias [N] instead of zero: dZ = G·(A∘W) + Z·S + bias of pfr_bnfree.hip in ONE launch
+  const void* x2;
+  int K2, x2bytes;
+  const float* cbias;
   int store_masked;       // BNB with a bit mask: y is stored THROUGH the mask (g*mask; every consumer of a block-output gradient
                           // reads it through that mask anyway, so they may then skip it: pfr_conv2d_dgrad_bn_ex)
   int npanels, nranges, R;    // R: rows per range (multiple of the 32-row block height)
@@ -77,11 +82,13 @@ struct SconvParams {
 // plain variant, but nothing is stored (first pass of the recompute form of a bottleneck's last convolution, pfr_conv1x1_stats).
 // EP 10 / 11: the second pass (pfr_conv1x1_bn_tail): the convolution again, then the block tail relu(bn3(.) + shortcut) and its ReLU
 // bit mask in the epilogue — the convolution output itself never reaches HBM.
+// EP 12 = EP 4 (data gradient + BatchNorm-backward sums) over TWO row sources with an fp32 bias in the accumulators (see SconvParams).
 template <int TP, int NS, bool STATS, int EP = 0>
 __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   constexpr bool JOIN = EP == 1 || EP == 5 || EP == 6 || EP == 7 || EP == 8;
   constexpr bool HASRES = EP == 1 || EP == 3 || EP == 5 || EP == 6 || EP == 7 || EP == 8 || EP == 10 || EP == 11;
-  constexpr bool BNB = EP == 4 || EP == 5 || EP == 6 || EP == 7 || EP == 8;
+  constexpr bool BNB = EP == 4 || EP == 5 || EP == 6 || EP == 7 || EP == 8 || EP == 12;
+  constexpr bool SRC2 = EP == 12;
   constexpr bool BNB2 = EP == 6 || EP == 8;     // + the projection-shortcut BN of the previous block (same g, same mask, its own x)
   constexpr bool NOX = EP == 7 || EP == 8;      // the first BN's input is not read (bit mask required)
   constexpr bool INFER = EP == 2 || EP == 3;
@@ -103,6 +110,8 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = p.K, RB = K * 2;                 // weight row bytes
   const int KG = K >> 6;                         // granules per block
+  const int KG1 = SRC2 ? (K - p.K2) >> 6 : KG;   // ... of which the first KG1 come from x, the rest from x2
+  const bool tail8 = SRC2 && p.K2 == 64;         // a 64-wide x2 part: its 8 weight chunks per row swizzle in a group of 8 (as K == 64)
   const int NPW = p.npw;                         // couts of the workgroup's weight panel
   const int wbytes = NPW * RB;
   const int nsub = NPW / NPV;                    // column slices per panel (1, 2 or 4): wave -> (slice, row lane)
@@ -126,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 
   __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.N * RB, 0x00020000);
   __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.xbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t x2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(SRC2 ? p.x2 : p.x), 0, SRC2 ? p.x2bytes : 16, 0x00020000);
   __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.M * p.N * 2, 0x00020000);
   const uint32_t OOBB = 0xF0000000u;
   __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.y), 0,
@@ -210,12 +220,23 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
     for (int t = wave; t < ninst; t += 8) {
       const int L = (t << 10) + (lane << 4);
       const int row = L / RB, pc = (L - row * RB) >> 4;
-      const int lc = (K == 64) ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 15));
+      const int lc = (K == 64 || (tail8 && pc >= KG1 * 8)) ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 15));
       const uint32_t off = (uint32_t)((pn * NPW + row) * RB + (lc << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + (t << 10)), 16, (int)off, 0, 0, 0);
     }
   }
 
+  // accumulator-initial bias (EP 12): acc[i][4*qd + j] belongs to cout i*32 + 8*qd + 4*(lane >> 5) + j
+  f32x16 cb[TP];
+  if constexpr (SRC2) {
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cb[i][4 * qd + j] = p.cbias[n0 + i * 32 + 8 * qd + 4 * (lane >> 5) + j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   // ---- per-lane constants (LDS byte addresses are 32-bit)
   const int frow = lane & 31, fhalf = lane >> 5;
   const int sx = (frow >> 1) & 7;                                     // swizzle of a granule / window row (128-byte rows)
@@ -238,12 +259,14 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
   // ---- loader state
   const int g_row = lane >> 3, g_pc = lane & 7;                       // DMA: row within an 8-row instruction, physical chunk
   int l_blk = wrow, l_kc = 0;
-  uint32_t rowoff[GI];
+  uint32_t rowoff[GI], rowoff2[GI];
   auto set_rows = [&](int blk) {
 #pragma unroll
     for (int t = 0; t < GI; ++t) {
       const int m = row_lo + blk * bstep + t * 8 + g_row;
       uint32_t off = OOBB;
+      if constexpr (SRC2)
+        rowoff2[t] = blk < nblk ? (uint32_t)m * (uint32_t)(p.K2 * 2) + (uint32_t)((g_pc ^ ((t * 4 + (g_row >> 1)) & 7)) << 4) : OOBB;
       if (blk < nblk) {
         uint32_t xr = (uint32_t)m;
         if (p.ostride != 1) {
@@ -253,17 +276,24 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
           xr = (n_img * p.H + oh * p.ostride) * p.W + ow * p.ostride;
         }
         const int lc = g_pc ^ ((t * 4 + (g_row >> 1)) & 7);
-        off = xr * (uint32_t)RB + (uint32_t)(lc << 4);     // rows past the end lie beyond num_records: zero-filled
+        off = xr * (uint32_t)(SRC2 ? (K - p.K2) * 2 : RB) + (uint32_t)(lc << 4);     // rows past the end lie beyond num_records: zero-filled
       }
       rowoff[t] = off;
     }
   };
   set_rows(l_blk);
   auto issue = [&](int slot) {
+    if (SRC2 && l_kc >= KG1) {
 #pragma unroll
-    for (int t = 0; t < GI; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(ringp + slot * GB + t * 1024), 16,
-                                               (int)(rowoff[t] + (uint32_t)(l_kc << 7)), 0, 0, 0);
+      for (int t = 0; t < GI; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x2rsrc, (__attribute__((address_space(3))) void*)(ringp + slot * GB + t * 1024), 16,
+                                                 (int)(rowoff2[t] + (uint32_t)((l_kc - KG1) << 7)), 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < GI; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(ringp + slot * GB + t * 1024), 16,
+                                                 (int)(rowoff[t] + (uint32_t)(l_kc << 7)), 0, 0, 0);
+    }
     if (++l_kc == KG) {
       l_kc = 0;
       l_blk += nrw;
@@ -385,14 +415,16 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const u32x4 fq = *(lds_cptr)(uintptr_t)(gbase + xo[s]);
-        const uint32_t wa = wlane + ((((uint32_t)(kc * 8 + 2 * s) | (uint32_t)fhalf) ^ (uint32_t)sw) << 4);
+        const uint32_t swk = (tail8 && kc >= KG1) ? (uint32_t)sx : (uint32_t)sw;
+        const uint32_t wa = wlane + ((((uint32_t)(kc * 8 + 2 * s) | (uint32_t)fhalf) ^ swk) << 4);
         u32x4 fp[TP];
 #pragma unroll
         for (int i = 0; i < TP; ++i) fp[i] = *(lds_cptr)(uintptr_t)(wa + i * 32 * RB);
         if (s == 0 && kc == 0) {
 #pragma unroll
           for (int i = 0; i < TP; ++i) {
-            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const f32x16 z0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const f32x16 z = SRC2 ? cb[i] : z0;
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fp[i]), __builtin_bit_cast(bf16x8, fq), z, 0, 0, 0);
           }
         } else {
@@ -418,6 +450,8 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
       if (KG == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GI) : "memory");
       else if (KG == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GI) : "memory");
       else if (KG == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * GI) : "memory");
+      else if (KG == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * GI) : "memory");
+      else if (KG == 10) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * GI) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * GI) : "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -637,9 +671,9 @@ int sconv_mode() {
 void sconv_set_mode(int v) { g_sconv_mode = v; }
 
 // panel width for (N, K): the widest of 256 / 128 / 64 couts that divides N and keeps the panel within 64 KiB
-static int sconv_panel(int N, int K) {
+static int sconv_panel(int N, int K, long limit = 65536) {
   for (int np = 256; np >= 64; np >>= 1)
-    if (N % np == 0 && (long)np * K * 2 <= 65536) return np;
+    if (N % np == 0 && (long)np * K * 2 <= limit) return np;
   return 0;
 }
 
@@ -648,12 +682,13 @@ struct SconvPlan {
 };
 // geometry-only eligibility — the ONE test shared by pfr_conv2d_mtile, pfr_conv2d_dgrad_bn_parts and the launch: bf16, K in {64, 128,
 // 256, 512}, panel fits, enough rows, output AND input extents (in_rows = N*H*W: 4x the output rows of a stride-2 1x1) below 2 GiB
-bool sconv_plan(int M, int N, int K, long in_rows, int dtype, int out_dtype, SconvPlan* sp) {
+// (k2 > 0: the two-source form, K = k1 + k2 with k1 in {256, 512} and k2 = k1 / 4: the panel may then take 96 KiB, two ring slots)
+bool sconv_plan(int M, int N, int K, long in_rows, int dtype, int out_dtype, SconvPlan* sp, int k2 = 0) {
   const int mode = sconv_mode();
   if (mode == 0 || dtype != PFR_BF16 || out_dtype != PFR_BF16) return false;
-  if (K != 64 && K != 128 && K != 256 && K != 512) return false;
+  if (k2 ? !((K - k2 == 256 || K - k2 == 512) && (k2 == 64 || k2 == 128)) : (K != 64 && K != 128 && K != 256 && K != 512)) return false;
   if (N % 64 != 0 || (long)M * N * 2 >= ((long)1 << 31) || (long)M * K * 2 >= ((long)1 << 31) || in_rows * K * 2 >= ((long)1 << 31)) return false;
-  const int np = sconv_panel(N, K);
+  const int np = sconv_panel(N, K, k2 ? 96 * 1024 : 65536);
   if (!np) return false;
   const int npanels = N / np;
   if (npanels > 32 || (256 % npanels) != 0) return false;
@@ -662,7 +697,7 @@ bool sconv_plan(int M, int N, int K, long in_rows, int dtype, int out_dtype, Sco
     // (measured, tools/sconv_bench.py: K = 512 with 4 panels 81 vs 94 us for the tile kernel, with 16 panels 68-72 vs 76-78)
     static const int maxp = getenv("PFR_SCONV_MAXPANELS") ? atoi(getenv("PFR_SCONV_MAXPANELS")) : 16;
     static const int maxk = getenv("PFR_SCONV_MAXK") ? atoi(getenv("PFR_SCONV_MAXK")) : 512;
-    if (npanels > maxp || K > maxk || (K < 512 && npanels > 8)) return false;
+    if (npanels > maxp || (!k2 && K > maxk) || (K < 512 && npanels > 8)) return false;
     if (M < 256 * 64) return false;    // too few rows per workgroup for a pipeline
   }
   int nranges = 256 / npanels;
@@ -836,4 +871,39 @@ extern "C" int pfr_conv1x1_bn_tail(const void* x, const void* w, void* y, unsign
   sp.tail_a1 = a1; sp.tail_b1 = b1; sp.tail_a2 = a2; sp.tail_b2 = b2;
   if (a2) { pl.tp = 2; return sconv_launch_ns<2, false, 11>(sp, pl, st); }   // (64-cout slices: four coefficient sets in registers)
   return pl.tp == 2 ? sconv_launch_ns<2, false, 10>(sp, pl, st) : sconv_launch_ns<4, false, 10>(sp, pl, st);
+}
+
+// ------------------------------------------------------------------------------------------------ two-source data gradient (pfr_bnfree.hip)
+// dx [M][Cout] = [g | z] · wcatᵀ + bias with g [M][C1] (the masked block-output gradient), z [M][C2] (conv3's input), wcat [Cout][C1 + C2]
+// (= [A∘W | S] rows, pfr_bn3_bwd_weights) — conv3's BN-input-free data gradient in ONE launch, bias added in fp32 inside the accumulators —
+// plus the BatchNorm-backward sums of the BN whose output gradient dx is (recomputed ReLU mask: coef rows 2, 3), as pfr_conv2d_dgrad_bn.
+static bool dgrad2_geom(int dtype, int N, int H, int W, int C1, int C2, int Cout, SconvPlan* pl) {
+  if (dtype != PFR_BF16 || sconv_bnb_mode() != 2 || (long)N * H * W >= ((long)1 << 31)) return false;
+  const long M = (long)N * H * W;
+  if (M * (C1 + C2) * 2 >= ((long)1 << 31)) return false;
+  return sconv_plan((int)M, Cout, C1 + C2, M, dtype, dtype, pl, C2);
+}
+// partial rows of bn_part ([parts][2][Cout]) the launch writes; 0: geometry not taken (run pfr_conv2d_fwd(z, S, bias) + pfr_conv2d_dgrad_bn)
+extern "C" int pfr_conv1x1_dgrad2_bn_parts(int dtype, int N, int H, int W, int C1, int C2, int Cout) {
+  SconvPlan pl;
+  return dgrad2_geom(dtype, N, H, W, C1, C2, Cout, &pl) ? pl.nranges : 0;
+}
+extern "C" int pfr_conv1x1_dgrad2_bn(const void* g, const void* z, const void* wcat, const float* bias, void* dx, int dtype, int N, int H,
+                                     int W, int C1, int C2, int Cout, const void* bn_x, const float* bn_coef, float* bn_part,
+                                     hipStream_t st) {
+  PFR_CHECK_ARG(g && z && wcat && bias && dx && bn_x && bn_coef && bn_part, "pfr_conv1x1_dgrad2_bn: null pointer");
+  SconvPlan pl;
+  if (!dgrad2_geom(dtype, N, H, W, C1, C2, Cout, &pl)) {
+    pfr_set_error("pfr_conv1x1_dgrad2_bn: geometry not taken by the streaming kernel (pfr_conv1x1_dgrad2_bn_parts == 0)");
+    return PFR_ERR_UNSUPPORTED;
+  }
+  SconvParams sp;
+  tail_params(sp, pl, g, wcat, N, H, W, C1 + C2, Cout);
+  sp.xbytes = (int)((long)sp.M * C1 * 2);
+  sp.x2 = z; sp.K2 = C2; sp.x2bytes = (int)((long)sp.M * C2 * 2);
+  sp.cbias = bias;
+  sp.y = dx;
+  sp.bnx = bn_x; sp.bn_coef = bn_coef; sp.bn_part = bn_part;
+  pl.tp = 2;
+  return sconv_launch_ns<2, false, 12>(sp, pl, st);
 }

@@ -857,7 +857,7 @@ class FEEngine:
                 kmax = max(self.blocks[k][0][2][0].Cin for k in bnf)
                 bnf_G1 = self._A(plan, (cmax * kmax,), torch.float32)
                 bnf_coef = self._A(plan, (3 * cmax,), torch.float32)
-                bnf_wat = self._A(plan, (cmax * kmax,))
+                bnf_wat = self._A(plan, ((cmax + kmax) * kmax,))      # [K][C] (A∘W)ᵀ, or — two-source form — wcat [K][C + K] = [(A∘W)ᵀ | S]
                 bnf_S = self._A(plan, (kmax * kmax,))
                 bnf_bias = self._A(plan, (kmax,), torch.float32)
         for k in range(nblk - 1, -1, -1):
@@ -887,18 +887,27 @@ class FEEngine:
                 ops.append((lib.pfr_bn3_bwd_coef, (part3.data_ptr(), np3, bnf_G1.data_ptr(), f["zsum"].data_ptr(), Wm, bn3.gamma.data_ptr(),
                                                    bn3.coef[1].data_ptr(), C3, K3, rows3, bn3.dgamma.data_ptr(), bn3.dbeta.data_ptr(),
                                                    bnf_coef.data_ptr(), acc)))
+                np2 = lib.pfr_conv1x1_dgrad2_bn_parts(self.did, zs[0], zs[1], zs[2], C3, K3, K3) if os.environ.get("PFR_BNFREE_2SRC", "1") != "0" else 0
                 ops.append((lib.pfr_bn3_bwd_weights, (bnf_coef.data_ptr(), bnf_G1.data_ptr(), f["G2"].data_ptr(), f["zsum"].data_ptr(), Wm,
-                                                      C3, K3, rows3, c3.g.data_ptr(), bnf_wat.data_ptr(), bnf_S.data_ptr(),
+                                                      C3, K3, rows3, c3.g.data_ptr(), bnf_wat.data_ptr(), 0 if np2 > 0 else bnf_S.data_ptr(),
                                                       bnf_bias.data_ptr(), acc)))
                 release(part3)
-                y1 = G(zs)
-                ops.append((lib.pfr_conv2d_fwd, (z2.data_ptr(), bnf_S.data_ptr(), y1.data_ptr(), self.did, self.did, zs[0], zs[1], zs[2], K3, K3,
-                                                 1, 1, 1, 0, 0, zs[1], zs[2], K3, bnf_bias.data_ptr(), 0, 0, 0, 0, 0, 0, 0)))
                 dz2 = G(zs)
-                part2 = G((f["npart"], 2, K3), torch.float32)
-                dgrad_bn(dcur, oshape, c3, dz2, zs, (c2raw, bn2, None, part2), res=y1, wt=bnf_wat)
-                release(y1)
-                bn_bwd(dz2, None, c2raw, zs, bn2, 2, dz2, None, acc, pre=(part2, f["npart"]))
+                if np2 > 0:
+                    # ONE launch over both row sources [G | z2] against wcat = [(A∘W)ᵀ | S], bias inside the accumulators
+                    part2 = G((np2, 2, K3), torch.float32)
+                    ops.append((lib.pfr_conv1x1_dgrad2_bn, (dcur.data_ptr(), z2.data_ptr(), bnf_wat.data_ptr(), bnf_bias.data_ptr(), dz2.data_ptr(),
+                                                            self.did, zs[0], zs[1], zs[2], C3, K3, K3, c2raw.data_ptr(), bn2.coef.data_ptr(),
+                                                            part2.data_ptr())))
+                else:
+                    np2 = f["npart"]
+                    y1 = G(zs)
+                    ops.append((lib.pfr_conv2d_fwd, (z2.data_ptr(), bnf_S.data_ptr(), y1.data_ptr(), self.did, self.did, zs[0], zs[1], zs[2], K3, K3,
+                                                     1, 1, 1, 0, 0, zs[1], zs[2], K3, bnf_bias.data_ptr(), 0, 0, 0, 0, 0, 0, 0)))
+                    part2 = G((np2, 2, K3), torch.float32)
+                    dgrad_bn(dcur, oshape, c3, dz2, zs, (c2raw, bn2, None, part2), res=y1, wt=bnf_wat)
+                    release(y1)
+                bn_bwd(dz2, None, c2raw, zs, bn2, 2, dz2, None, acc, pre=(part2, np2))
                 dy, dyshape = dz2, zs
             else:
                 dz3 = G(oshape)

@@ -912,3 +912,53 @@ def test_gram_matrix_and_column_sums_in_one_pass(M, Q):
     got = outs[0].double().cpu()
     assert torch.allclose(got[:Q * Q].view(Q, Q), G2, rtol=2e-5, atol=1e-3)
     assert torch.allclose(got[Q * Q:Q * Q + Q], zs, rtol=2e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", [(2, 56, 256, 64), (3, 28, 512, 128), (1, 9, 256, 64), (7, 13, 512, 128), (2, 57, 256, 64)])
+def test_two_source_data_gradient_with_bn_sums(case):
+    """pfr_conv1x1_dgrad2_bn (csrc/pfr_sconv.hip EP 12): dx = [g | z]·wcatᵀ + bias over TWO row sources with the bias in the fp32
+    accumulators, plus the BatchNorm-backward sums of the BN dx feeds (recomputed ReLU mask) — against fp64 torch on the same bf16
+    operands (one bf16 rounding of the result), sums against the stored dx; ragged row counts; deterministic."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, C1, C2 = case
+    Co = C2
+    g = torch.Generator().manual_seed(H * C1 + C2)
+    M = N * H * H
+    G_ = (torch.randn(M, C1, generator=g) * (torch.rand(M, C1, generator=g) > 0.5)).bfloat16().to(DEV)
+    Z = torch.relu(torch.randn(M, C2, generator=g)).bfloat16().to(DEV)
+    wcat = (torch.randn(Co, C1 + C2, generator=g) / (C1 + C2) ** 0.5).bfloat16().to(DEV)
+    bias = (0.1 * torch.randn(Co, generator=g)).to(DEV)
+    bnx = torch.randn(M, Co, generator=g).bfloat16().to(DEV)
+    coef = torch.stack([0.1 * torch.randn(Co, generator=g), 1 + 0.1 * torch.rand(Co, generator=g),
+                        1 + 0.1 * torch.randn(Co, generator=g), 0.2 * torch.randn(Co, generator=g)]).to(DEV)   # mean, invstd, scale, shift
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        lib.pfr_set_tuning(b"sconv", 2)
+        lib.pfr_set_tuning(b"bnb", 2)
+        npart = lib.pfr_conv1x1_dgrad2_bn_parts(1, N, H, H, C1, C2, Co)
+        assert npart > 0
+        for _ in range(2):
+            dx = torch.full((M + 1, Co), 9.0, dtype=torch.bfloat16, device=DEV)
+            part = torch.full((npart + 1, 2, Co), 55.0, dtype=torch.float32, device=DEV)
+            lib.pfr_conv1x1_dgrad2_bn(G_.data_ptr(), Z.data_ptr(), wcat.data_ptr(), bias.data_ptr(), dx.data_ptr(), 1, N, H, H, C1, C2, Co,
+                                      bnx.data_ptr(), coef.data_ptr(), part.data_ptr(), st)
+            torch.cuda.synchronize()
+            outs.append((dx.clone(), part.clone()))
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+        lib.pfr_set_tuning(b"bnb", 0)
+    dx, part = outs[0]
+    assert torch.equal(dx, outs[1][0]) and torch.equal(part, outs[1][1])
+    assert torch.all(dx[M] == 9.0) and torch.all(part[npart] == 55.0)
+    ref = torch.cat([G_, Z], 1).double() @ wcat.double().t() + bias.double()
+    got = dx[:M].double()
+    assert (got - ref).abs().max() <= 1e-2 * ref.abs().max()
+    assert ((got - ref).norm() / ref.norm()).item() < 3e-3
+    mask = (bnx.double() * coef[2].double() + coef[3].double()) > 0
+    xh = (bnx.double() - coef[0].double()) * coef[1].double()
+    s1 = (got * mask).sum(0)
+    s2 = (got * mask * xh).sum(0)
+    assert torch.allclose(part[:npart, 0].double().sum(0), s1, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(part[:npart, 1].double().sum(0), s2, rtol=1e-4, atol=1e-2)
