@@ -929,9 +929,10 @@ def test_two_source_data_gradient_with_bn_sums(case):
     Z = torch.relu(torch.randn(M, C2, generator=g)).bfloat16().to(DEV)
     wcat = (torch.randn(Co, C1 + C2, generator=g) / (C1 + C2) ** 0.5).bfloat16().to(DEV)
     bias = (0.1 * torch.randn(Co, generator=g)).to(DEV)
-    bnx = torch.randn(M, Co, generator=g).bfloat16().to(DEV)
+    # BN input away from the ReLU threshold (|scale*x + shift| >= 0.2): the recomputed mask must not depend on fma rounding
+    bnx = ((0.5 + torch.rand(M, Co, generator=g)) * (torch.randint(0, 2, (M, Co), generator=g) * 2 - 1)).bfloat16().to(DEV)
     coef = torch.stack([0.1 * torch.randn(Co, generator=g), 1 + 0.1 * torch.rand(Co, generator=g),
-                        1 + 0.1 * torch.randn(Co, generator=g), 0.2 * torch.randn(Co, generator=g)]).to(DEV)   # mean, invstd, scale, shift
+                        1 + 0.1 * torch.rand(Co, generator=g), 0.2 * (torch.rand(Co, generator=g) - 0.5)]).to(DEV)   # mean, invstd, scale, shift
     st = torch.cuda.current_stream().cuda_stream
     outs = []
     try:

@@ -531,6 +531,9 @@ def test_resnet_plans_are_rebuilt_when_a_tuning_knob_changes():
     from oracle import resnet_ref
     from pets_face_recognition_amd._hip import lib
     sd = resnet_ref.init_state_dict("resnet50", 512, seed=4)
+    for k in sd:       # damped residual branches (an undamped random-init net amplifies bf16 rounding noise to O(1) in the early layers)
+        if k.startswith("layer") and k.endswith(".bn3.weight"):
+            sd[k] = torch.full_like(sd[k], 0.2)
     g = torch.Generator().manual_seed(2)
     x = torch.rand(8, 3, 128, 128, generator=g).to(DEV)
     demb = (torch.randn(8, 512, generator=g) * 0.05).to(DEV)
