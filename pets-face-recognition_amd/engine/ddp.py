@@ -10,13 +10,21 @@ finishes it from the end towards the front.  `BucketReducer.ready(off)` is calle
 [off, end) became final; full buckets of that suffix are all-reduced (AVG) in place on a dedicated communication
 stream while the remaining dgrad/wgrad kernels run.  No gradient copies, no per-parameter hooks, 5 large
 collectives per step for ResNet-50 (xGMI is point-to-point: few, large messages).
+
+ONE collective implementation at a time: by default the RCCL communicator torch.distributed ("nccl") owns; with
+`collective="pfr"` (or PFR_DDP_COLLECTIVE=pfr) the all-reduces go through the C-ABI communicator of csrc/pfr_comm.hip
+(`pfr_comm_allreduce`, RCCL resolved by dlopen) — what a non-Python host of libpfr_hip.so drives; torch.distributed is then only
+the rendezvous that hands the 128-byte unique id around.  Both are exercised by the same tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class BucketReducer:
-    def __init__(self, flat, bucket_elems=6 * 1024 * 1024, group=None, average=True):
+    def __init__(self, flat, bucket_elems=6 * 1024 * 1024, group=None, average=True, comm=None):
+        self.comm = comm     # a _hip.comm.Communicator: all-reduces through the C-ABI (pfr_comm_allreduce) instead of torch.distributed
         self.flat = flat
         self.n = flat.numel()
         self.bucket = int(bucket_elems)
@@ -47,8 +55,13 @@ class BucketReducer:
                 # the weight gradients of this range were enqueued on the engine's side stream: the COMMUNICATION stream waits for
                 # them, the main stream (the dgrad -> BN-backward chain) does not stall at the bucket boundary
                 self.comm_stream.wait_stream(side)
-            with torch.cuda.stream(self.comm_stream):
-                h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+            if self.comm is not None:
+                # stream-ordered on the communication stream: no handle to wait for, finish() joins the stream
+                self.comm.allreduce_(view, average=self.average, stream=self.comm_stream)
+                h = None
+            else:
+                with torch.cuda.stream(self.comm_stream):
+                    h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         else:
             h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         self.handles.append((h, view if (lo == 0 and hi == 0) else None, lo, hi))
@@ -71,6 +84,8 @@ class BucketReducer:
         if self.hi > 0:
             self.ready(0)
         for h, t, lo, hi in self.handles:
+            if h is None:
+                continue
             if self.cuda:
                 with torch.cuda.stream(self.comm_stream):
                     h.wait()
@@ -86,19 +101,27 @@ class BucketReducer:
 class FlatDDP:
     """Wraps a `SoftmaxBasedMetricLearning` (HIP backbone + margin head) for data-parallel training."""
 
-    def __init__(self, model_loss, bucket_mb=25, group=None):
+    def __init__(self, model_loss, bucket_mb=25, group=None, collective=None):
         self.model_loss = model_loss
         self.group = group
         eng = model_loss.module.hip_engine()
         self.eng = eng
-        # replicate rank 0's parameters / BN buffers
-        dist.broadcast(eng.master, 0, group=group)
-        if hasattr(eng, "stats"):
-            dist.broadcast(eng.stats, 0, group=group)   # BN running statistics (ResNet engines)
         self.extra = [p for n, p in model_loss.named_parameters() if not n.startswith("module.")]
-        for p in self.extra:
-            dist.broadcast(p.data, 0, group=group)
-        self.reducer = BucketReducer(eng.grad, bucket_elems=bucket_mb * 1024 * 1024 // 4, group=group)
+        collective = collective or os.environ.get("PFR_DDP_COLLECTIVE", "torch")
+        if collective not in ("torch", "pfr"):
+            raise ValueError(f"collective must be 'torch' or 'pfr', got {collective!r}")
+        self.comm = None
+        if collective == "pfr":
+            from .._hip import comm as C
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            uid = torch.zeros(C.UNIQUE_ID_BYTES, dtype=torch.uint8, device=eng.grad.device)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(C.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0, group=group)          # rendezvous only
+            self.comm = C.Communicator(rank, world, bytes(uid.cpu().tolist()), device=eng.grad.device)
+        # replicate rank 0's parameters / BN buffers
+        self.broadcast_parameters()
+        self.reducer = BucketReducer(eng.grad, bucket_elems=bucket_mb * 1024 * 1024 // 4, group=group, comm=self.comm)
         eng.grad_ready_hook = self.reducer.ready
         if self.reducer.cuda:
             self.reducer.side_stream_fn = lambda: getattr(eng, "side", None)
@@ -110,11 +133,25 @@ class FlatDDP:
 
     def broadcast_parameters(self):
         """rank 0's parameters / BN statistics / head weights → every rank (construction, and after a checkpoint was loaded)"""
-        dist.broadcast(self.eng.master, 0, group=self.group)
-        if hasattr(self.eng, "stats"):
-            dist.broadcast(self.eng.stats, 0, group=self.group)
-        for p in self.extra:
-            dist.broadcast(p.data, 0, group=self.group)
+        ts = [self.eng.master] + ([self.eng.stats] if hasattr(self.eng, "stats") else []) + [p.data for p in self.extra]
+        self._bcast(ts)
+
+    def _bcast(self, tensors):
+        if self.comm is None:
+            for t in tensors:
+                dist.broadcast(t, 0, group=self.group)
+            return
+        # through the C-ABI communicator: the other ranks contribute zeros to a SUM all-reduce (x + 0 + ... + 0 = x exactly)
+        for t in tensors:
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                dist.broadcast(t, 0, group=self.group)
+                continue
+            c = t if t.is_contiguous() else t.contiguous()
+            if self.comm.rank != 0:
+                c.zero_()
+            self.comm.allreduce_(c, average=False)
+            if c is not t:
+                t.copy_(c)
 
     def detach(self):
         """unhook from the model (the trainer builds a new FlatDDP when the model got a new engine)"""
@@ -154,7 +191,7 @@ class FlatDDP:
         with rank 0's statistics; here the statistics of a step never feed the next train step (train-mode BN uses batch
         statistics), so one broadcast before an evaluation pass gives the same evaluation-time state."""
         if hasattr(self.eng, "stats"):
-            dist.broadcast(self.eng.stats, 0, group=self.group)
+            self._bcast([self.eng.stats])
             dist.broadcast(self.eng.nbt, 0, group=self.group)
 
 

@@ -93,10 +93,16 @@ for arch, hw in (("resnet18", 64), ("swin_t", 224)):
     x = torch.rand(4, 3, hw, hw, generator=g).to(dev)
     y = torch.randint(0, 100, (4,), generator=g).to(dev)
     a = grads(build(arch), None, x, y)
-    ml = build(arch)
-    b = grads(ml, FlatDDP(ml, bucket_mb=1), x, y)
-    assert torch.isfinite(a).all() and a.abs().sum() > 0
-    assert torch.equal(a, b), (arch, (a - b).abs().max().item())
+    for coll in ("torch", "pfr"):      # torch.distributed's RCCL communicator, and the C-ABI one (pfr_comm_allreduce)
+        ml = build(arch)
+        ddp = FlatDDP(ml, bucket_mb=1, collective=coll)
+        assert (ddp.comm is not None) == (coll == "pfr") and ddp.reducer.comm is ddp.comm
+        b = grads(ml, ddp, x, y)
+        assert torch.isfinite(a).all() and a.abs().sum() > 0
+        assert torch.equal(a, b), (arch, coll, (a - b).abs().max().item())
+        ddp.sync_buffers()
+        if ddp.comm is not None:
+            ddp.comm.close()
     print("OK", arch, a.numel())
 # gallery-sharded match over RCCL (one all-gather of the per-rank top-K lists) == unsharded match
 from pets_face_recognition_amd.match import cosine_topk, cosine_topk_sharded
@@ -112,7 +118,8 @@ dist.destroy_process_group()
 
 def test_flat_ddp_world1_rccl_path_equals_single_gpu(tmp_path):
     """The RCCL path (bucketed in-place all-reduce on the communication stream, head-gradient hook, side stream joined at
-    the bucket marks) with world size 1 must give bit-identical gradients to the plain single-GPU step."""
+    the bucket marks) with world size 1 must give bit-identical gradients to the plain single-GPU step — through either collective
+    implementation: torch.distributed's communicator (default) and the C-ABI pfr_comm_* one (collective="pfr")."""
     script = tmp_path / "ddp_w1.py"
     script.write_text(_DDP_SCRIPT.format(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
@@ -320,10 +327,10 @@ _DDP_N_SCRIPT = textwrap.dedent("""
 """)
 
 
-def _run_ddp_n(tmp_path, nproc, port):
+def _run_ddp_n(tmp_path, nproc, port, collective="torch"):
     script = tmp_path / "ddp_n.py"
     script.write_text(_DDP_N_SCRIPT.format(root=ROOT))
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0", PFR_DDP_COLLECTIVE=collective)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
@@ -331,17 +338,20 @@ def _run_ddp_n(tmp_path, nproc, port):
     assert f"RCCL ranks {nproc}" in r.stdout
 
 
-def test_flat_ddp_script_world1_sanity(tmp_path):
-    """the multi-rank parity script below, run with ONE rank (this is what a 1-GPU box can execute of it)"""
-    _run_ddp_n(tmp_path, 1, 29551)
+@pytest.mark.parametrize("collective", ["torch", "pfr"])
+def test_flat_ddp_script_world1_sanity(tmp_path, collective):
+    """the multi-rank parity script below, run with ONE rank (this is what a 1-GPU box can execute of it), through either collective
+    implementation (torch.distributed's communicator / the C-ABI pfr_comm_* one)"""
+    _run_ddp_n(tmp_path, 1, 29551 if collective == "torch" else 29555, collective)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 MI355X on the node")
-def test_flat_ddp_world2_equals_mean_of_shard_gradients(tmp_path):
+@pytest.mark.parametrize("collective", ["torch", "pfr"])
+def test_flat_ddp_world2_equals_mean_of_shard_gradients(tmp_path, collective):
     """SURVEY 8(e) parity statement on hardware: 2 ranks (torchrun, RCCL over xGMI), per-rank data and per-shard BN statistics:
     the all-reduced gradients equal the mean of the per-shard single-GPU gradients to 1e-6 (ResNet-18 and Swin-T), the
     engine reports exactly grad_ready_marks(), every element is reduced once.  Reference: utils/__init__.py:114-119."""
-    _run_ddp_n(tmp_path, 2, 29553)
+    _run_ddp_n(tmp_path, 2, 29553 if collective == "torch" else 29557, collective)
 
 
 def test_integration_md_binding_blocks_run_against_the_library():
