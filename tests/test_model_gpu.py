@@ -562,3 +562,34 @@ def test_resnet_plans_are_rebuilt_when_a_tuning_knob_changes():
     finally:
         lib.pfr_set_tuning(b"sconv", 1)
         lib.pfr_set_tuning(b"bnb", 0)
+
+
+def test_resnet50_224_bf16_undamped_vs_bf16_emulating_oracle():
+    """the headline dtype at the headline resolution, UNDAMPED random-init ResNet-50 (the worst case: every block amplifies
+    a perturbation ~1.5x), 8 x 3 x 224 x 224, train-mode BN.  Asserted bounds on the bf16 HIP embedding:
+      * against the oracle with bf16 rounding emulated at the path's storage points (resnet_ref.forward(quant=bf16_round)): the two differ
+        only in accumulation order / where fp32 intermediates are kept — <= 6e-2 relative (measured 2-3e-2), cosine >= 0.998;
+      * against the fp32 oracle: <= 2e-1 relative (measured 1.1e-1), cosine >= 0.99 — the deviation any bf16-activation evaluation
+        of this net has (the emulating oracle itself is that far from the fp32 one)."""
+    from oracle import resnet_ref
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = resnet_ref.init_state_dict("resnet50", 512, seed=21)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(8, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        e32 = resnet_ref.forward(sd, x, "resnet50", train=True)
+        eq = resnet_ref.forward(sd, x, "resnet50", train=True, quant=resnet_ref.bf16_round)
+    m = build("resnet50", torch.bfloat16, sd).train()
+    with torch.no_grad():
+        e = m(x.to(DEV)).float().cpu()
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()   # noqa: E731
+    r_q, r_32, r_q32 = rel(e, eq), rel(e, e32), rel(eq, e32)
+    print(f"[bf16 parity r50 224] hip-vs-emulating {r_q:.3e} (cos {cos(e, eq):.5f}); hip-vs-fp32 {r_32:.3e} (cos {cos(e, e32):.5f}); "
+          f"emulating-vs-fp32 {r_q32:.3e}")
+    out = os.environ.get("PFR_PARITY_LOG")
+    if out:
+        with open(out, "a") as f:
+            f.write(f"resnet50 8x3x224x224 undamped bf16: hip_vs_bf16_emulating_oracle={r_q:.3e} cos={cos(e, eq):.6f} hip_vs_fp32_oracle={r_32:.3e} "
+                    f"cos={cos(e, e32):.6f} emulating_vs_fp32={r_q32:.3e}\n")
+    assert r_q < 6e-2 and cos(e, eq) > 0.998, (r_q, cos(e, eq))
+    assert r_32 < 2e-1 and cos(e, e32) > 0.99, (r_32, cos(e, e32))

@@ -1,12 +1,18 @@
 """fp32-vs-bf16 TRAINING equivalence (VERDICT r2 weak #1b): ResNet-18 + ArcFace on the separable synthetic set through
 `main.py --config`, ~300 optimizer steps in each compute dtype with identical seeds / data order; compares the loss curves and the
 final validation ROC AUC / accuracy / Recall@K the drop-in evaluation prints.  Writes profiles/<tag>_train_equiv.json.
-usage: python tools/train_equiv.py [tag]"""
+usage: python tools/train_equiv.py [tag] [noise] [arch] [n_train_ids] [n_val_ids] [photos] [epochs]
+  round 4: python tools/train_equiv.py r04_r50 1.0 resnet50 200 256 8 8   -> ResNet-50, 2048 validation images"""
 import json, os, re, subprocess, sys, tempfile, textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 noise = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+arch = sys.argv[3] if len(sys.argv) > 3 else "resnet18"
+n_train_ids = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+n_val_ids = int(sys.argv[5]) if len(sys.argv) > 5 else 40
+photos = int(sys.argv[6]) if len(sys.argv) > 6 else 8
+epochs = int(sys.argv[7]) if len(sys.argv) > 7 else 12
 common = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic")
 runs = {}
 for name, dt in (("f32", "torch.float32"), ("bf16", "torch.bfloat16")):
@@ -16,11 +22,11 @@ for name, dt in (("f32", "torch.float32"), ("bf16", "torch.bfloat16")):
             import sys, torch
             sys.path.insert(0, {common!r})
             from _common import make as _make
-            _make(globals(), arch='resnet18', n_train_ids=100, n_val_ids=40, photos=8, image_size=64, train_bs=32, test_bs=40,
-                  device='cuda:0', n_epochs=12, n_pairs=400, compute_dtype={dt}, seed=3, noise={noise})
+            _make(globals(), arch={arch!r}, n_train_ids={n_train_ids}, n_val_ids={n_val_ids}, photos={photos}, image_size=64, train_bs=32,
+                  test_bs=64, device='cuda:0', n_epochs={epochs}, n_pairs=400, compute_dtype={dt}, seed=3, noise={noise})
         """))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", cfg], cwd=td, capture_output=True, text=True,
-                           timeout=1500)
+                           timeout=3000)
         if r.returncode != 0:
             print(r.stdout[-2000:], r.stderr[-3000:])
             raise SystemExit(1)
@@ -45,8 +51,10 @@ for k in sorted(set(a["per_epoch"]) & set(b["per_epoch"])):
     d = [round(y - x, 5) for x, y in zip(fa, fb)]
     per_epoch[k] = {"f32": fa, "bf16": fb, "bf16_minus_f32_last_epoch": d[-1]}
     met_ok = met_ok and (d[-1] >= -tol[k] if k.startswith("Recall") else abs(d[-1]) <= tol[k])
-out = {"workload": "ResNet-18 + ArcFace(100 ids), synthetic 64x64 (pattern + noise * N(0,1)), bs 32, 12 epochs x 25 steps, FusedSGD, seed 3, main.py --config",
-       "steps": 300, "loss_f32": a["logged_losses"][:n], "loss_bf16": b["logged_losses"][:n],
+steps_per_epoch = n_train_ids * photos // 32
+out = {"workload": f"{arch} + ArcFace({n_train_ids} ids), synthetic 64x64 (pattern + noise * N(0,1)), bs 32, {epochs} epochs x {steps_per_epoch} steps, "
+                   f"FusedSGD, seed 3, main.py --config; validation on {n_val_ids * photos} images of {n_val_ids} held-out ids",
+       "steps": epochs * steps_per_epoch, "loss_f32": a["logged_losses"][:n], "loss_bf16": b["logged_losses"][:n],
        "loss_tolerance": "logged single-batch losses within 5 % over the first half of training and 20 % everywhere", "max_rel_loss_diff": round(max(rel), 4), "noise": noise, "loss_within_tolerance": bool(loss_ok),
        "validation_per_epoch": per_epoch, "metric_tolerances": tol, "within_tolerance": bool(loss_ok and met_ok)}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
