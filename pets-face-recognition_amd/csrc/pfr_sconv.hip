@@ -526,9 +526,11 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
               Chunk<bf16_t>::unpack(bxr[g][ps], xv);
             }
             const uint32_t bits = bmk[g][ps];
+            // (two-source form: the accumulators start from the bias, so rows past M hold the bias, not 0: they must not enter the sums)
+            const bool rowok = !SRC2 || (m0 + ps * 8 + e_row) < p.M;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const f32x2 gs = {__uint_as_float(o[e] << 16), __uint_as_float(o[e] & 0xffff0000u)};
+              const f32x2 gs = {rowok ? __uint_as_float(o[e] << 16) : 0.f, rowok ? __uint_as_float(o[e] & 0xffff0000u) : 0.f};
               f32x2 gm;
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
