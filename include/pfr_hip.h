@@ -164,6 +164,9 @@ int pfr_conv1x1_dgrad2_bn(const void* g, const void* z, const void* wcat, const 
 /* G2 = X^T X [Q][Q] and the column sums of X [Q] in ONE streaming pass over X [M][Q] (bf16, Q = 64 | 128): the two forward-only inputs
  * of pfr_bn3_bwd_coef / pfr_bn3_bwd_weights.  out = Q*Q floats then Q floats; workspace = pfr_gram_ws_floats(M, Q) floats (0: geometry
  * not supported — pfr_conv2d_wgrad(x, x) + pfr_colsum give the same). */
+/* batch statistics of x = Z W^T from pfr_gram_colsum's output for Z (no pass over x): mean_c = W[c] . zbar, var_c = W[c] (G2/M - zbar zbar^T)
+ * W[c]^T; part = ONE (mean, M2) partial row [2][C] for pfr_bn_finalize(nparts = 1, rows_per_part = M).  W: the bf16 weights [C][K]. */
+int pfr_bn_stats_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, float* part, pfr_stream_t stream);
 long pfr_gram_ws_floats(long M, int Q);
 int pfr_gram_colsum(const void* x, int dtype, long M, int Q, float* out, float* workspace, pfr_stream_t stream);
 

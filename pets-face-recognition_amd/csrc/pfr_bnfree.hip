@@ -97,6 +97,42 @@ __global__ __launch_bounds__(256) void bn3_weights_kernel(const float* __restric
   }
 }
 
+// Batch statistics of x = Z·Wᵀ WITHOUT computing x: mean_c = W[c,:]·z̄ and var_c = W[c,:]·(G2/M − z̄z̄ᵀ)·W[c,:]ᵀ from the Gram matrix and the
+// column sums of Z (pfr_gram_colsum) — a bottleneck's bn3 gets its statistics from conv3's INPUT, so the forward pass needs no
+// statistics pass over conv3 at all.  W = the bf16 weights the convolution itself uses.  Output: one (mean, M2 = M·var) partial row,
+// the form pfr_bn_finalize merges (nparts = 1, rows_per_part = M).  fp32; checked against fp64: invstd to ~1e-6 relative.
+__global__ __launch_bounds__(256) void bn_stats_gram_kernel(const float* __restrict__ gram, const bf16_t* __restrict__ W, int C, int K,
+                                                            float count, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const float* G2 = gram;
+  const float* zsum = gram + (size_t)K * K;
+  const float inv_m = 1.f / count;
+  float mu = 0.f, q = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float wk = (float)W[(size_t)c * K + k], zk = zsum[k] * inv_m;
+    float t = 0.f;   // sum_j W[c][j] Cov[j][k]
+#pragma unroll 8
+    for (int j = 0; j < K; ++j) t = fmaf((float)W[(size_t)c * K + j], fmaf(G2[(size_t)j * K + k], inv_m, -(zsum[j] * inv_m) * zk), t);
+    mu = fmaf(wk, zk, mu);
+    q = fmaf(t, wk, q);
+  }
+  mu = wave_sum(mu);
+  q = wave_sum(q);
+  if (lane == 0) {
+    part[c] = mu;
+    part[C + c] = fmaxf(q, 0.f) * count;
+  }
+}
+extern "C" int pfr_bn_stats_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, float* part, hipStream_t st) {
+  PFR_CHECK_ARG(gram && W && part, "pfr_bn_stats_from_gram: null pointer");
+  PFR_CHECK_ARG(dtype == PFR_BF16 && C > 0 && K > 0 && count > 0.f, "pfr_bn_stats_from_gram: bf16 weights only");
+  hipLaunchKernelGGL(bn_stats_gram_kernel, dim3((C + 3) / 4), dim3(256), 0, st, gram, (const bf16_t*)W, C, K, count, part);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 extern "C" int pfr_bn3_bwd_coef(const float* part, int nparts, const float* G1, const float* zsum, const float* W, const float* gamma,
                                 const float* invstd, int C, int K, float count, float* dgamma, float* dbeta, float* coef,
                                 int accumulate, hipStream_t st) {

@@ -153,6 +153,10 @@ class FEEngine:
         # so the forward pass does not store conv3's output either (statistics pass + recompute with the block tail in the epilogue).
         # bf16 streaming geometries only (layer1-2 of ResNet-50 at bs 256); PFR_BNFREE=0 keeps the materialised form everywhere.
         self.bnfree = os.environ.get("PFR_BNFREE", "1") != "0" and self.dtype == torch.bfloat16 and self.fuse_bnb == 2
+        # bn3's batch statistics of those blocks from the Gram matrix of conv3's input (pfr_bn_stats_from_gram) instead of a statistics
+        # pass over conv3: the statistics of the EXACT convolution (~1e-6 from those of its bf16-rounded values), -0.3 ms/step;
+        # PFR_BNFREE_GRAMSTATS=0 keeps the statistics pass, whose forward is bit-identical to the stored form
+        self.gram_stats = os.environ.get("PFR_BNFREE_GRAMSTATS", "1") != "0"
         self.ws_main = None             # split-K workspace of weight-gradient launches on the MAIN stream (self.ws belongs to the side stream)
         self.grad_ready_hook = None     # callable(lo, hi): flat-grad range [lo, hi) is final (DDP bucket hook)
         self.hook_syncs_side = False    # True: the hook makes ITS stream wait for self.side (the main stream then never waits at a mark)
@@ -622,10 +626,19 @@ class FEEngine:
                 if bk in free_set and ci == 2:
                     # recompute form: this pass leaves only bn3's statistics; the tail launch below computes conv3 again
                     OH3, OW3 = conv_out_hw(sshape[1], sshape[2], c.R, c.S, c.stride, c.pad)
-                    part3, nt3, mt3 = self._stats_buf(plan, sshape, c, OH3, OW3)
-                    ops.append((lib.pfr_conv1x1_stats, (src.data_ptr(), c.w.data_ptr(), self.did, sshape[0], sshape[1], sshape[2], c.Cin,
-                                                        c.Cout, part3.data_ptr())))
-                    self._bn_fwd(ops, bn, part3, nt3, sshape[0] * OH3 * OW3, train, mt3)
+                    gram = plan.meta.get("gram", {}).get(bk)
+                    if gram is not None and self.gram_stats:
+                        # bn3's batch statistics from conv3's INPUT (Gram matrix + column sums of z2): no pass over conv3 at all
+                        rows3 = sshape[0] * OH3 * OW3
+                        part3 = self._A(plan, (1, 2, c.Cout), torch.float32)
+                        ops.append((lib.pfr_bn_stats_from_gram, (gram.data_ptr(), c.w.data_ptr(), self.did, c.Cout, c.Cin, float(rows3),
+                                                                 part3.data_ptr())))
+                        self._bn_fwd(ops, bn, part3, 1, rows3, train, rows3)
+                    else:
+                        part3, nt3, mt3 = self._stats_buf(plan, sshape, c, OH3, OW3)
+                        ops.append((lib.pfr_conv1x1_stats, (src.data_ptr(), c.w.data_ptr(), self.did, sshape[0], sshape[1], sshape[2], c.Cin,
+                                                            c.Cout, part3.data_ptr())))
+                        self._bn_fwd(ops, bn, part3, nt3, sshape[0] * OH3 * OW3, train, mt3)
                     z2_in = (src, sshape)
                     raws.append((None, (sshape[0], OH3, OW3, c.Cout)))
                     acts.append(None)
@@ -640,7 +653,7 @@ class FEEngine:
                     acts.append(z)
                     pro = None
                     src, sshape = z, yshape
-                    if bk in free_set and ci == 1 and with_backward:
+                    if bk in free_set and ci == 1:
                         # z2ᵀz2 and the column sums of z2 for the BN-input-free backward, while z2 is fresh in the Infinity Cache
                         rows2 = yshape[0] * yshape[1] * yshape[2]
                         nws = lib.pfr_gram_ws_floats(rows2, yshape[3])

@@ -963,3 +963,28 @@ def test_two_source_data_gradient_with_bn_sums(case):
     s2 = (got * mask * xh).sum(0)
     assert torch.allclose(part[:npart, 0].double().sum(0), s1, rtol=1e-4, atol=1e-2)
     assert torch.allclose(part[:npart, 1].double().sum(0), s2, rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,K,C", [(8192, 64, 256), (25088, 128, 512), (100357, 64, 256)])
+def test_batchnorm_statistics_from_the_gram_matrix(M, K, C):
+    """pfr_bn_stats_from_gram: mean / variance of x = Z·Wᵀ from Z's Gram matrix and column sums (no pass over x), through pfr_bn_finalize,
+    against fp64 statistics of the exact product: mean to 1e-5 of the standard deviation, invstd to 1e-5 relative."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(K, K, generator=g) / K ** 0.5
+    Z = torch.relu(torch.randn(M, K, generator=g) @ A + 0.5).bfloat16().to(DEV)
+    W = (torch.randn(C, K, generator=g) / K ** 0.5).bfloat16().to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.pfr_gram_ws_floats(M, K), dtype=torch.float32, device=DEV)
+    gram = torch.empty(K * K + K, dtype=torch.float32, device=DEV)
+    lib.pfr_gram_colsum(Z.data_ptr(), 1, M, K, gram.data_ptr(), ws.data_ptr(), st)
+    part = torch.empty(1, 2, C, dtype=torch.float32, device=DEV)
+    lib.pfr_bn_stats_from_gram(gram.data_ptr(), W.data_ptr(), 1, C, K, float(M), part.data_ptr(), st)
+    coef = o.bn_finalize(part, M, M, None, None, 1e-5, 0.1, None, None)
+    torch.cuda.synchronize()
+    x = Z.double() @ W.double().t()
+    mu, var = x.mean(0), x.var(0, unbiased=False)
+    assert ((coef[0].double() - mu).abs() / var.sqrt()).max().item() < 1e-5
+    r = (var + 1e-5).rsqrt()
+    assert ((coef[1].double() - r).abs() / r).max().item() < 1e-5

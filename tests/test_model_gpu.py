@@ -506,7 +506,21 @@ def test_bn_input_free_backward_of_conv3_bn3(monkeypatch):
     finally:
         lib.pfr_set_tuning(b"sconv", 1)
         lib.pfr_set_tuning(b"bnb", 0)
-    assert torch.equal(res["0"][1], res["1"][1])          # the forward pass is the same launches
+    # forward: bn3's statistics come from the Gram matrix of conv3's input (exact convolution, not its bf16-rounded values): ~1e-6 apart
+    # in the coefficients, i.e. a few bf16 roundings flip downstream; with the statistics pass instead the forward is bit-identical
+    assert rel(res["1"][1], res["0"][1]) < 1e-2
+    monkeypatch.setenv("PFR_BNFREE", "1")
+    monkeypatch.setenv("PFR_BNFREE_GRAMSTATS", "0")
+    try:
+        lib.pfr_set_tuning(b"sconv", 2)
+        m = build("resnet50", torch.bfloat16, sd).train()
+        with torch.no_grad():
+            e_bit = m(x.to(DEV)).double().cpu()
+        assert m.hip_engine()._last_plan.meta["free_set"]
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+        lib.pfr_set_tuning(b"bnb", 0)
+    assert torch.equal(e_bit, res["0"][1])
     f64 = torch.cat([p64[n].grad.flatten() for n in res["0"][0]])
     err = {}
     for flag in ("0", "1"):
