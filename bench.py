@@ -36,7 +36,8 @@ PEAK_HBM_GBS = 8000.0
 # every C-ABI entry point whose launches execute the FLOPs counted by conv_flops_per_img (conv / Linear forward, data and
 # weight gradients incl. the fused-epilogue variants, windowed attention)
 CONV_FAMILY = ("pfr_conv2d_fwd", "pfr_conv2d_wgrad", "pfr_conv2d_dgrad_join", "pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub",
-               "pfr_conv2d_dgrad_bn_ex", "pfr_conv2d_dgrad_bn_sub_ex", "pfr_conv1x1_stats", "pfr_conv1x1_bn_tail", "pfr_gemm_act",
+               "pfr_conv2d_dgrad_bn_ex", "pfr_conv2d_dgrad_bn_sub_ex", "pfr_conv1x1_stats", "pfr_conv1x1_bn_tail", "pfr_conv1x1_dgrad2_bn",
+               "pfr_gram_colsum", "pfr_gemm_act",
                "pfr_window_attn_fwd", "pfr_window_attn_bwd")
 
 
@@ -522,6 +523,12 @@ def main():
                 key = "%s N%d H%d W%d C%d Co%d" % (name[4:], Nn, Hh, Ww, Cc, Co)
                 fl = 0.0 if name == "pfr_conv1x1_stats" else 2.0 * Nn * Hh * Ww * Cc * Co
                 by = esz * Nn * Hh * Ww * Cc + (0 if name == "pfr_conv1x1_stats" else esz * 2 * Nn * Hh * Ww * Co + Nn * Hh * Ww * Co // 8)
+            elif name == "pfr_conv1x1_dgrad2_bn":
+                # (g, z, wcat, bias, dx, dtype, N, H, W, C1, C2, Cout, bn_x, ...): conv3's BN-input-free data gradient over [g | z]; the
+                # algorithmic FLOPs are those of the plain data gradient (C1 -> Cout); the z·S part is extra work
+                key = "dgrad2_bn N%d H%d W%d C%d+%d Co%d" % (a[6], a[7], a[8], a[9], a[10], a[11])
+                fl = 2.0 * a[6] * a[7] * a[8] * a[9] * a[11]
+                by = esz * a[6] * a[7] * a[8] * (a[9] + a[10] + 2 * a[11])
             elif name in ("pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_ex"):
                 # (dy, wt, dx, dtype, N, H, W, C, Cout, R, S, pad, idil, OH, OW, res, mask, acc, bn_x, ...): the data gradient (+ join)
                 # that also reads the BN input for the BatchNorm-backward sums (what pfr_bn_bwd_reduce read in a separate pass)
@@ -561,8 +568,8 @@ def main():
         # roofline.frac = ALL conv / linear FLOPs of the step / the time of ALL conv-family launches / peak.  The data-gradient
         # launches that also do the BatchNorm-backward reduction in their epilogue (pfr_conv2d_dgrad_bn[_sub]) are conv launches: their
         # FLOPs and their time both count.  The ratio without them is kept under its own key (`frac_excl_bn_sum_launches`).
-        fused_ms = sum(summ[k][1] for k in ("pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub", "pfr_conv2d_dgrad_bn_ex", "pfr_conv2d_dgrad_bn_sub_ex") if k in summ) / nprof
-        fused_flops = sum(v[0] / nprof * v[2] for k, v in det.items() if k.startswith("dgrad_bn"))
+        fused_ms = sum(summ[k][1] for k in ("pfr_conv2d_dgrad_bn", "pfr_conv2d_dgrad_bn_sub", "pfr_conv2d_dgrad_bn_ex", "pfr_conv2d_dgrad_bn_sub_ex", "pfr_conv1x1_dgrad2_bn") if k in summ) / nprof
+        fused_flops = sum(v[0] / nprof * v[2] for k, v in det.items() if k.startswith("dgrad_bn") or k.startswith("dgrad2_bn"))
         conv_ms = conv_ms_all
         ach = flops / (conv_ms_all * 1e-3) / 1e12
         ach_excl = (flops - fused_flops) / ((conv_ms_all - fused_ms) * 1e-3) / 1e12 if conv_ms_all > fused_ms else None

@@ -40,7 +40,7 @@ f=$(find $OUT/prof_${TAG}_match -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" $OUT/${TAG}_kernel_stats_match_10kx1M.csv
 rm -rf $OUT/prof_${TAG}_swin $OUT/prof_${TAG}_match $OUT/pmc_${TAG}_swin_FETCH_SIZE $OUT/pmc_${TAG}_swin_WRITE_SIZE
 unset PFR_SIDE_STREAM
-python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default.json
+python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default.json
 python bench.py --arch swin_t --batch 128 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_swin_t_bs128.json
 rm -rf $OUT/prof_$TAG $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
 ls -la $OUT | tail -12

@@ -20,7 +20,7 @@ def load(d, counter):
 
 
 def family(name):
-    if "igemm" in name or "wgrad" in name or "sconv" in name:
+    if "igemm" in name or "wgrad" in name or "sconv" in name or "gram_kernel" in name:
         return "conv"
     if "window_attn" in name:
         return "attention"
