@@ -20,7 +20,9 @@ def load(d, counter):
 
 
 def family(name):
-    if "igemm" in name or "wgrad" in name or "sconv" in name or "gram_kernel" in name:
+    if "gram_kernel" in name:
+        return "bn"      # BatchNorm bookkeeping (statistics / backward sums of bn3 from conv3's input), not a layer
+    if "igemm" in name or "wgrad" in name or "sconv" in name:
         return "conv"
     if "window_attn" in name:
         return "attention"
