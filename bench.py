@@ -254,14 +254,14 @@ def extras(args, device):
     try:
         cfg = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic", "fe_r50_mi355x_pipeline.py")
         ncpu = os.cpu_count() or 8
-        env = dict(os.environ, PFR_LIMIT_TRAIN_BATCHES="45", PFR_VAL_IDS="32", PFR_WORKERS=str(max(4, min(16, ncpu - 2))))
+        env = dict(os.environ, PFR_LIMIT_TRAIN_BATCHES="65", PFR_VAL_IDS="32", PFR_WORKERS=str(max(4, min(16, ncpu - 2))))
         import tempfile
         with tempfile.TemporaryDirectory() as td:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", cfg], env=env, cwd=td, capture_output=True,
                                text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("THROUGHPUT ")][-1]
         j = json.loads(line[len("THROUGHPUT "):])
-        out["main_py_pipeline"] = {"value": j["train_img_s"], "unit": "images/sec", "steps": 40, "loader_workers": int(env["PFR_WORKERS"]),
+        out["main_py_pipeline"] = {"value": j["train_img_s"], "unit": "images/sec", "steps": 60, "loader_workers": int(env["PFR_WORKERS"]),
                                    "host_cores": ncpu, "prefetch_batches": j["prefetch_batches"],
                                    "input": "uint8 frames from DataLoader workers, pinned, copy stream, device augmentation"}
     except Exception as e:   # noqa: BLE001
