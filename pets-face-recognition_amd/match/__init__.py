@@ -59,7 +59,10 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     if rescore:
         kc = max(k, min(512, k + (slack if slack is not None else max(28, k // 2 + k))))
     q32 = q.float().contiguous()
-    g32 = g.float().contiguous()
+    gkey = _gallery_key(g, rescore)
+    hit = _GCACHE.get("entry")
+    use_cache = normalize and T == torch.bfloat16 and D % 4 == 0 and D <= 2048 and hit is not None and hit[0] == gkey
+    g32 = None if use_cache else g.float().contiguous()      # (a cache hit needs neither the fp32 copy nor the normalisation pass)
     if normalize and T == torch.bfloat16 and D % 4 == 0 and D <= 2048:
         # one pass per matrix: bf16 GEMM operand + (when re-scoring) the fp32 copy
         def prep(x):
@@ -68,9 +71,7 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
             lib.pfr_l2norm_dual(x.data_ptr(), xb.data_ptr(), 0 if xf is None else xf.data_ptr(), 0, x.shape[0], D, 1e-12, _stream())
             return xb, xf
         qn, qn32 = prep(q32)
-        gkey = _gallery_key(g, rescore)
-        hit = _GCACHE.get("entry")
-        if hit is not None and hit[0] == gkey:
+        if use_cache:
             gn, gn32 = hit[1], hit[2]
         else:
             _GCACHE.clear()          # (drop the old copies before the new ones are allocated)
