@@ -102,8 +102,8 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
         # gallery segments (first column, columns, filter fused into the GEMM?): the first chunk goes through a materialised fp32 score
         # chunk (its running lists start empty), every later one through the GEMM whose epilogue is the top-K filter.
         # (Round 4 measured a seeded variant — an 8 k-column unfused seed segment, then growing fused segments of the first chunk too:
-        #  same results, 20.7 instead of 18.7 ms: the early segments carry 2x the candidates per query and the extra merges cost more
-        #  than the 1.3 ms of the unfused first chunk they replace.)
+        #  same results, 20.8 / 19.3 / 18.7 ms for seeds of 8 k / 16 k / 32 k columns against 18.5 ms: the early segments carry several times
+        #  the candidates per query and their merges cost more than the unfused first chunk they replace; profiles/r04_match_seed_ab.txt.)
         segs = [(c0, min(chunk, G - c0), bool(fused and c0 > 0)) for c0 in range(0, G, chunk)]
         ld = (max(n for _, n, f in segs if not f) + 3) // 4 * 4
         if sbuf is None or sbuf.shape[-1] < ld:
