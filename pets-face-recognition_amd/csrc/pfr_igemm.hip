@@ -776,6 +776,9 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
     return PFR_ERR_ARG;
   }
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+    // (round 4 re-measured the alternatives on the 14x14 256->256 3x3 layer, 66.8 us / 886 TFLOP/s as is: 64-byte k-steps in a 4- / 3-slot
+    //  ring 72.0 / 73.2 us — DMA latency is not what stalls the tile; 4 waves with 128x128 or 64x256 register tiles, compiler-scheduled,
+    //  82.9 / 83.6 us — one wave per SIMD needs the hand-scheduled k-loop of pfr_sconv3.hip.  profiles/r04_tile_variants.txt)
     if (v == TILE_256x256) return launch_tile_k<T, TO, 256, 256, 8, 8, 2>(p, st);
     if (v == TILE_256x128) return launch_tile_k<T, TO, 256, 128, 8, 8, 2>(p, st);
   }
