@@ -505,13 +505,16 @@ def test_bn_input_free_backward_of_conv3_bn3(monkeypatch):
             eng = m.hip_engine()
             blocks = eng._last_plan.meta["bnfree_blocks"]
             assert blocks == ([] if flag == "0" else [0, 1, 2, 3, 4, 5, 6]), blocks
-            res[flag] = ({n: p.grad.double().cpu() for n, p in m.named_parameters()}, emb.double().cpu())
+            res[flag] = ({n: p.grad.double().cpu() for n, p in m.named_parameters()}, emb.double().cpu(),
+                         {k: v.double().cpu() for k, v in m.state_dict().items() if "bn3.running" in k})
     finally:
         lib.pfr_set_tuning(b"sconv", 1)
         lib.pfr_set_tuning(b"bnb", 0)
     # forward: bn3's statistics come from the Gram matrix of conv3's input (exact convolution, not its bf16-rounded values): ~1e-6 apart
     # in the coefficients, i.e. a few bf16 roundings flip downstream; with the statistics pass instead the forward is bit-identical
     assert rel(res["1"][1], res["0"][1]) < 1e-2
+    for k in ("layer1.1.bn3.running_mean", "layer1.1.bn3.running_var", "layer2.3.bn3.running_var"):   # running statistics through the Gram path
+        assert rel(res["1"][2][k], res["0"][2][k]) < 1e-3, k
     monkeypatch.setenv("PFR_BNFREE", "1")
     monkeypatch.setenv("PFR_BNFREE_GRAMSTATS", "0")
     try:
