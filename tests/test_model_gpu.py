@@ -514,7 +514,7 @@ def test_bn_input_free_backward_of_conv3_bn3(monkeypatch):
     # in the coefficients, i.e. a few bf16 roundings flip downstream; with the statistics pass instead the forward is bit-identical
     assert rel(res["1"][1], res["0"][1]) < 1e-2
     for k in ("layer1.1.bn3.running_mean", "layer1.1.bn3.running_var", "layer2.3.bn3.running_var"):   # running statistics through the Gram path
-        assert rel(res["1"][2][k], res["0"][2][k]) < 1e-3, k
+        assert rel(res["1"][2][k], res["0"][2][k]) < 1e-2, k
     monkeypatch.setenv("PFR_BNFREE", "1")
     monkeypatch.setenv("PFR_BNFREE_GRAMSTATS", "0")
     try:
