@@ -1161,6 +1161,7 @@ class FEEngine:
         x = x.contiguous()
         N, _, H, W = x.shape
         plan = self.acquire_plan(N, H, W, train, with_backward, ticket if with_backward else None)
+        plan.meta["epoch"] = self._tuning_epoch     # the knobs this forward pass (and the launches its backward replays) ran under
         if with_backward and plan.meta.get("ws_ptr", 0) != self._ws_key():
             self._finalize_plan(plan)
         if plan.meta.get("folded") and self.graph_eval and _TRACER[0] is None:
@@ -1275,6 +1276,11 @@ class FEEngine:
 
     def backward(self, demb, plan=None):
         plan = plan if plan is not None else self._last_plan
+        if lib.pfr_tuning_epoch() != plan.meta.get("epoch", self._tuning_epoch):
+            # the backward list was built for the kernels the knobs selected at forward time (partial-row counts of the fused BatchNorm
+            # sums, which blocks dropped conv3's output): replaying it under other knobs would compute wrong sums silently
+            raise PfrError("a pfr_set_tuning call changed a kernel-selection knob between this forward pass and its backward pass "
+                           "(another engine with a different PFR_FUSE_BNB mode, or a host sweep): run forward again")
         stream = torch.cuda.current_stream().cuda_stream
         demb = demb.contiguous()
         if demb.numel() != plan.meta["demb"].numel():

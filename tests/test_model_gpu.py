@@ -616,3 +616,26 @@ def test_resnet50_224_bf16_undamped_vs_bf16_emulating_oracle():
                     f"cos={cos(e, e32):.6f} emulating_vs_fp32={r_q32:.3e}\n")
     assert r_q < 1e-1 and cos(e, eq) > 0.995, (r_q, cos(e, eq))
     assert r_32 < 2e-1 and cos(e, e32) > 0.99, (r_32, cos(e, e32))
+
+
+def test_backward_refuses_to_replay_under_changed_tuning_knobs():
+    """ADVICE r3 (_fe_engine.py:180): the fused-BatchNorm-sum mode is process-global state that changes what the data-gradient launches of a
+    plan mean.  A knob flipped between a forward pass and ITS backward pass must not be replayed silently: the engine raises, and a fresh
+    forward + backward under the new knobs works."""
+    from oracle import resnet_ref
+    from pets_face_recognition_amd._hip import lib, PfrError
+    sd = resnet_ref.init_state_dict("resnet18", 512, seed=2)
+    m = build("resnet18", torch.bfloat16, sd).train()
+    x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    try:
+        e = m(x)
+        lib.pfr_set_tuning(b"sconv", 0)
+        with pytest.raises(PfrError):
+            e.sum().backward()
+        e = m(x)
+        e.sum().backward()
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    finally:
+        lib.pfr_set_tuning(b"sconv", 1)
+        lib.pfr_set_tuning(b"bnb", 0)
