@@ -297,14 +297,23 @@ def extras(args, device):
     gal = centers[gcls] + 3.2 * torch.randn(G, D, device=device, generator=g)
     qcls = torch.randint(0, ncls, (Q,), device=device, generator=g)
     qry = centers[qcls] + 3.2 * torch.randn(Q, D, device=device, generator=g)
+    from pets_face_recognition_amd.match import clear_gallery_cache
     cosine_topk(qry, gal, K)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sc, idx = cosine_topk(qry, gal, K)
+    sc, idx = cosine_topk(qry, gal, K)          # (the L2-normalised gallery of the previous call is reused: match._GCACHE)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    clear_gallery_cache()
+    t0 = time.perf_counter()
+    cosine_topk(qry, gal, K)                    # first contact with a gallery: normalisation included
+    torch.cuda.synchronize()
+    dt_cold = time.perf_counter() - t0
     hit = gcls[idx.long().clamp_min(0)] == qcls[:, None]
-    m = {"seconds": round(dt, 4), "tflops": round(2.0 * Q * G * D / dt / 1e12, 1), "dtype": "bf16 candidates + fp32 re-score",
+    m = {"seconds": round(dt, 4), "seconds_first_contact_with_the_gallery": round(dt_cold, 4),
+         "note": "`seconds`: the gallery's normalised bf16 + fp32 copies are cached from the previous call (one gallery, many query batches); "
+                 "`seconds_first_contact…`: cache cleared first",
+         "tflops": round(2.0 * Q * G * D / dt / 1e12, 1), "dtype": "bf16 candidates + fp32 re-score",
          "candR10": round(hit[:, :10].any(1).float().mean().item(), 4), "candR100": round(hit.any(1).float().mean().item(), 4),
          "roofline": {"bound": "mfma", "achieved": round(2.0 * Q * G * D / dt / 1e12, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                       "frac": round(2.0 * Q * G * D / dt / 1e12 / PEAK_TFLOPS["bf16"], 4)}}
