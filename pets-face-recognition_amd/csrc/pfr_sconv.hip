@@ -453,6 +453,19 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
       else if (KG == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * GI) : "memory");
       else if (KG == 10) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * GI) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * GI) : "memory");
+      // The destination registers of the inline-asm loads above are DEFINED here as far as the compiler is concerned: their
+      // "=v" outputs were valid to it at the asm statement itself, so nothing but this tie stops it from copying / spilling them before the
+      // data has landed.  (Empty statements: no instruction is emitted.)
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          if constexpr (HASRES) asm volatile("" : "+v"(rres[g][ps]));
+          if constexpr (JOIN) asm volatile("" : "+v"(rmk[g][ps]));
+          if constexpr (BNB && !NOX) asm volatile("" : "+v"(bxr[g][ps]));
+          if constexpr (BNB) asm volatile("" : "+v"(bmk[g][ps]));
+          if constexpr (BNB2) asm volatile("" : "+v"(cxr[g][ps]));
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
