@@ -742,6 +742,7 @@ static int set_tuning_impl(const char* key, int value) {
   if (!strcmp(key, "wgrad_big")) { wgrad_set_big(value); return PFR_OK; }
   if (!strcmp(key, "bnb")) { sconv_set_bnb_mode(value); return PFR_OK; }
   if (!strcmp(key, "swgrad")) { swgrad_set_mode(value); return PFR_OK; }
+  if (!strcmp(key, "wgrad9")) { wgrad9_set_mode(value); return PFR_OK; }
   pfr_set_error("pfr_set_tuning: unknown key %s", key);
   return PFR_ERR_ARG;
 }

@@ -1090,6 +1090,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// halo-staged 3x3 / stride-1 weight gradient (pfr_wgrad9.hip)
+int wgrad9_launch(const void* x, const void* dy, float* slabs, int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad,
+                  int lddy, hipStream_t st);
+int wgrad9_max_splits(int Cout, int KK);
+
 static int wgrad_v3() {
   static const int v = getenv("PFR_WGRAD_V3") ? atoi(getenv("PFR_WGRAD_V3")) : 1;
   return v;
@@ -1147,7 +1152,7 @@ static bool wgrad_big_geom(int M, int Cout, int KK) {
 //     t_pass * (ceil(W/512)*512 / W)  +  s * slab * 2 / 4 TB/s          (fp32 partial slabs written once, read once)
 // with t_pass = the pass at full occupancy (600 TFLOP/s or 4 TB/s of operand bytes, whichever is slower).  Measured on MI355X
 // (profiles/repro/split_sweep.sh): 3x3 256ch 14x14: 10 -> 14 splits = 98 -> 82 us; 3x3 512ch 7x7: 4 -> 3 splits = 115 -> 91 us.
-extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
+static int wgrad_tile_splits(int M, int Cout, int KK) {
   int bp, bq;
   wgrad_tiles(Cout, KK, &bp, &bq);
   // (the 256x256 form is only taken by bf16 launches without a fused prologue; others run 128-wide tiles over the same number of
@@ -1173,9 +1178,15 @@ extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   }
   static const int forced = getenv("PFR_WGRAD_FORCE_SPLITS") ? atoi(getenv("PFR_WGRAD_FORCE_SPLITS")) : 0;   // tuning sweeps
   if (forced > 0) best = forced < maxs ? forced : maxs;
-  SwgradPlan spl;
-  if (swgrad_plan(M, Cout, KK, &spl) && spl.nsplit > best) best = spl.nsplit;   // (room for the streaming kernel's slabs)
   return (int)best;
+}
+// the caller's workspace: room for the slabs of whichever kernel takes the launch
+extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
+  int best = wgrad_tile_splits(M, Cout, KK);
+  SwgradPlan spl;
+  if (swgrad_plan(M, Cout, KK, &spl) && spl.nsplit > best) best = spl.nsplit;   // (the streaming 1x1 kernel's)
+  if (wgrad9_max_splits(Cout, KK) > best) best = wgrad9_max_splits(Cout, KK);     // (the halo-staged 3x3 kernel's)
+  return best;
 }
 
 extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float* workspace, int dtype, int N, int H,
@@ -1194,7 +1205,8 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_relu = pro_relu;
   p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
   p.div_ow = make_fastdiv((uint32_t)OW);
-  p.splits = pfr_conv2d_wgrad_splits(p.M, Cout, p.KK);
+  p.splits = wgrad_tile_splits(p.M, Cout, p.KK);
+  const int ws_splits = pfr_conv2d_wgrad_splits(p.M, Cout, p.KK);
   { const int ohow = OH * OW, r1 = 32 % ohow; p.adv_q1 = 32 / ohow; p.adv_q2 = r1 / OW; p.adv_r2 = r1 % OW; }
   { const char* e = getenv("PFR_WGRAD_V2"); p.v2 = (!pro_scale && !(e && e[0] == '0')) ? 1 : 0; }
   const int bmr = p.v2 ? (dtype == PFR_BF16 ? 64 : 32) : PFR_WGRAD_MUL * (dtype == PFR_BF16 ? 32 : 16);
@@ -1202,13 +1214,20 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   int mchunk = (p.M + p.splits - 1) / p.splits;
   mchunk = (mchunk + bmr - 1) / bmr * bmr;
   p.mchunk = mchunk;
-  const bool direct = (p.splits == 1 && scale == 1.0f && !accumulate);
+  const bool direct = (ws_splits == 1 && scale == 1.0f && !accumulate);   // no slabs, no reduce pass
   PFR_CHECK_ARG(direct || workspace, "pfr_conv2d_wgrad: workspace required (splits=%d)", p.splits);
   p.dw = direct ? dw : workspace;
   int bp, bq, rc;
   wgrad_tiles(Cout, p.KK, &bp, &bq);
   SwgradPlan spl;
-  if (dtype == PFR_BF16 && p.v2 && p.simple && !direct && p.lddy % 8 == 0 && (long)p.M * p.lddy * 2 < (1L << 31) &&
+  int n9 = 0;
+  if (dtype == PFR_BF16 && p.v2 && !p.simple)
+    n9 = wgrad9_launch(x, dy, p.dw, N, H, W, C, Cout, R, S, stride, pad, p.lddy, stream);
+  if (n9 < 0) { pfr_set_error("pfr_conv2d_wgrad: launch failed"); return PFR_ERR_HIP; }
+  if (n9 > 0) {
+    p.splits = n9;
+    rc = PFR_OK;
+  } else if (dtype == PFR_BF16 && p.v2 && p.simple && !direct && p.lddy % 8 == 0 && (long)p.M * p.lddy * 2 < (1L << 31) &&
       (long)p.M * p.KK * 2 < (1L << 31) && swgrad_plan(p.M, Cout, p.KK, &spl)) {
     rc = swgrad_launch(p, spl, workspace, stream);
     if (rc != PFR_OK) return rc;

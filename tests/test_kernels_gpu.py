@@ -988,3 +988,37 @@ def test_batchnorm_statistics_from_the_gram_matrix(M, K, C):
     assert ((coef[0].double() - mu).abs() / var.sqrt()).max().item() < 1e-5
     r = (var + 1e-5).rsqrt()
     assert ((coef[1].double() - r).abs() / r).max().item() < 1e-5
+
+
+W9_CASES = [
+    # N, H, W, C, Cout (3x3, stride 1, pad 1): row slots of 16 / 32 / 64 positions, ragged row counts, image rows that straddle stages
+    (3, 14, 14, 64, 64), (2, 9, 13, 128, 64), (5, 8, 8, 64, 192), (2, 28, 28, 128, 128), (3, 17, 20, 64, 128), (2, 30, 30, 64, 64),
+    (2, 56, 56, 64, 64), (1, 3, 40, 64, 64), (1, 2, 62, 64, 64), (33, 14, 14, 256, 256), (7, 28, 28, 64, 128),
+]
+
+
+@pytest.mark.parametrize("case", W9_CASES)
+def test_halo_staged_3x3_weight_gradient(case):
+    """pfr_wgrad9.hip against torch's fp32 convolution weight gradient of the same bf16 inputs, and against the tile kernel (the
+    same products in another fp32 summation order)"""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, W, C, Cout = case
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(N, C, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(N, Cout, H, W, generator=g).bfloat16().float()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, C, 3, 3), dy.double(), stride=1, padding=1).permute(0, 2, 3, 1).float()
+    xd, dyd = nhwc(x).to(DEV, torch.bfloat16), nhwc(dy).to(DEV, torch.bfloat16)
+    try:
+        lib.pfr_set_tuning(b"wgrad9", 1)
+        a = o.conv2d_wgrad(xd, dyd, 3, 3, 1, 1)
+        a2 = o.conv2d_wgrad(xd, dyd, 3, 3, 1, 1)
+        lib.pfr_set_tuning(b"wgrad9", 0)
+        b = o.conv2d_wgrad(xd, dyd, 3, 3, 1, 1)
+    finally:
+        lib.pfr_set_tuning(b"wgrad9", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a2)                                   # deterministic
+    scale = ref.abs().max().item()
+    assert (a.cpu() - ref).abs().max().item() < 1e-5 * scale, (a.cpu() - ref).abs().max().item() / scale
+    assert (a - b).abs().max().item() < 1e-5 * scale

@@ -18,6 +18,8 @@ RESNET = [  # N, H, W, C, Cout, R, stride, pad
     (256, 28, 28, 128, 512, 1, 1, 0), (256, 28, 28, 512, 128, 1, 1, 0), (256, 56, 56, 64, 256, 1, 1, 0), (256, 56, 56, 256, 64, 1, 1, 0),
     (256, 56, 56, 64, 64, 1, 1, 0), (256, 56, 56, 256, 128, 1, 1, 0), (256, 28, 28, 256, 512, 1, 1, 0),
 ]
+if os.environ.get("WGRAD_AB") == "wgrad9":
+    RESNET = [g for g in RESNET if g[5] == 3 and g[6] == 1]
 if os.environ.get("WGRAD_AB") == "swgrad":
     RESNET = [g for g in RESNET if g[5] == 1 and g[6] == 1]
 SWIN = [(25088, 1, 1, 1536, 384, 1, 1, 0), (25088, 1, 1, 384, 1536, 1, 1, 0), (25088, 1, 1, 384, 1152, 1, 1, 0), (25088, 1, 1, 384, 384, 1, 1, 0),
@@ -38,7 +40,7 @@ def run(geom, reps=20):
         lib.pfr_set_tuning(b"wgrad_big", 0)
     else:
         lib.pfr_set_tuning(b"swgrad", 0)
-    for mode in (0, 2):
+    for mode in ((0, 1) if key == b"wgrad9" else (0, 2)):
         lib.pfr_set_tuning(key, mode)
         out = ops.conv2d_wgrad(x, dy, R, R, s, p, workspace=ws)
         for _ in range(3):
