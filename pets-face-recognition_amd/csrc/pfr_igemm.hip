@@ -315,10 +315,13 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
     if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
     mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc);
 #else
-    // the next tile's DMA is issued behind the first k-group's MFMAs (see mma_kstep_sw)
+    // the next tile's DMA is issued behind the first k-group's MFMAs (see mma_kstep_sw) — behind the SECOND by waves 4-7 of an
+    // 8-wave tile: waves w and w + 4 share a SIMD, an LDS-DMA instruction holds its wave for 60-180 cycles, and with both of them
+    // in their DMA burst the SIMD's matrix pipe stands still (3x3 256 ch at 14x14: 68.2 -> 63.9 us; one k-group later again, or
+    // two, the DMA lands after the k-step's barrier: 71 / 75 us; profiles/r04_tile_variants.txt)
     mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc, [&]() {
       if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
-    });
+    }, (NW == 8 && (threadIdx.x >> 8)) ? 1 : 0);
 #endif
     if (kt + 1 < nk) {
       const int last = kt + NST - 1 < nk - 1 ? kt + NST - 1 : nk - 1;  // newest k-step in flight

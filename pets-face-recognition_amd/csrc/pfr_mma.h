@@ -92,7 +92,7 @@ struct NoMid { __device__ __forceinline__ void operator()() const {} };
 // `mid` is invoked after the MFMAs of the first k-group have been ISSUED: work placed there (the next tile's DMA issue and
 // its address arithmetic) executes while the matrix pipe drains those MFMAs instead of in front of an idle pipe.
 template <typename T, int KCH, int TP, int TQ, typename Mid = NoMid>
-__device__ __forceinline__ void mma_kstep_sw(const char* ldsP, const char* ldsQ, int lane, f32x16 (&acc)[TP][TQ], Mid mid = Mid()) {
+__device__ __forceinline__ void mma_kstep_sw(const char* ldsP, const char* ldsQ, int lane, f32x16 (&acc)[TP][TQ], Mid mid = Mid(), int midkg = 0) {
   // ldsP / ldsQ: row 0 of this wave's slice (slice bases are multiples of 16 rows, so the swizzle depends on lane only).
   // Fragments of k-group kg+1 are read while the MFMAs of k-group kg run (explicit register double buffering).
   constexpr int ROWB = KCH * 16;
@@ -129,6 +129,6 @@ __device__ __forceinline__ void mma_kstep_sw(const char* ldsP, const char* ldsQ,
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fp[b][i][e]), __uint_as_float(fq[b][j][e]),
                                                               acc[i][j], 0, 0, 0);
     }
-    if (kg == 0) mid();
+    if (kg == midkg) mid();
   }
 }

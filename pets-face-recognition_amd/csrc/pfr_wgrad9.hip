@@ -7,21 +7,29 @@
 //
 // The tile kernel (wgrad3_kernel, pfr_wgrad.hip) treats the nine taps as nine independent slices of the GEMM's kk axis: x is
 // gathered from L2 once per tap and dy once per 128 kk-columns, 1.4 GB (64->64 at 56x56) / 0.9 GB (256->256 at 14x14) of
-// L2->LDS traffic per launch = 13 TB/s — the kernel sits on the L2, at 0.23-0.30 of its MFMA / HBM bound.
+// L2->LDS traffic per launch = 13 TB/s — that kernel sits on the L2, at 0.23-0.30 of its MFMA / HBM bound.
 //
-// Here a workgroup owns a [64 co] x [9 taps] x [64 ci] block of dw over a run of image rows, and every image row of dy and of x
-// is staged into LDS ONCE, in a padded row slot [0 | x_0 .. x_{W-1} | 0 ..] of PW = 16 / 32 / 64 pixel positions (128 B each:
-// the 64 channels of the block).  In that layout a tap is a pure ADDRESS SHIFT: for the 16 positions of a k-group of dy the
-// matching x positions are the same positions + ts - 1 in the slot of image row oh + tr - 1 (an all-zero slot when that row is
-// outside the image), so one A fragment (dy, ds_read_b64_tr_b16) meets nine B fragments read from nine shifted addresses.
-// L2->LDS traffic = every byte once per co- / ci-block pair (0.2 GB at 56x56, 0.2 GB at 14x14).  Pad positions of dy are zero,
-// so whatever finite x value sits opposite them contributes nothing; the MFMA work is W / PW = 0.875 efficient.
+// Here a workgroup owns a [64 co] x [9 taps] x [64 ci] block of dw over a run of image rows.  Rows of dy and of x are staged into
+// LDS in padded row slots [0 | p_0 .. p_{W-1} | 0 ..] of PW = 16 / 32 / 64 pixel positions (128 B each: the 64 channels of the
+// block), and the row sequence is EXTENDED by one all-zero row after every image (row index e = n (H + 1) + r).  In that layout a
+// tap is a pure ADDRESS SHIFT: for the 16 positions of a k-group of dy, the matching x positions are the same positions + (ts - 1)
+// in the row slot tr - 1 below / above — an immediate offset on a lane base — and everything outside the image reads zeros that the
+// DMA wrote (out-of-range lanes of a buffer load).  Pad positions of dy are zero, so whatever finite x value sits opposite them
+// contributes nothing; the MFMA work is (W / PW)(H / (H + 1)) = 0.82-0.86 efficient.
 //
-//   * 8 waves: (co half) x (ci half) x (k-group parity); a wave holds 9 accumulators of 32x32 (144 VGPRs);
-//   * stage = 128 dy positions (2 / 4 / 8 image rows) + as many x rows, ring of 4 stages by LDS-DMA with counted vmcnt, one
-//     barrier per stage (36 MFMAs per wave between barriers; the tile kernel has 8);
-//   * x rows live in their own ring of 4*SR + 2 row slots (row r at slot r mod NXR): the halo rows are not staged twice;
+//   * stage = 128 dy positions (SR = 2 / 4 / 8 extended rows) + the SR + 2 rows of x around them, ring of 3 stages filled by
+//     LDS-DMA; L2->LDS traffic = 0.3 GB at 56x56 (x rows twice: a stage brings its own halo rows), 0.25 GB at 14x14;
+//   * 8 waves = (ci half) x (k-group parity) x (tap group: taps 0-4 | 5-8); a wave multiplies BOTH co halves of a k-group of dy
+//     with its taps' x fragments: 1.44 LDS fragment reads per MFMA (a 32x32 wave tile over all nine taps needs 2.22);
+//   * one barrier per stage, one step before the stage ends (see the main loop); the two waves of a SIMD issue their DMA shares one
+//     step apart;
+//   * the rows a wave's DMA instructions fetch are tabulated per 64 stages (v_readlane in the loop);
 //   * partial sums per (split, block pair) go to fp32 slabs [split][Cout][9*C] summed by wgrad_reduce_kernel (fixed order).
+//
+// Measured (bs 256, tools/wgrad_bench.py, incl. the reduce pass): 64->64 at 56x56 114 -> 68 us, 128->128 at 28x28 84 -> 75 us,
+// 256->256 at 14x14 84 -> 70 us.  What the kernel time is made of (profiles/r04_wgrad9.txt): ~34 us of MFMAs at the sustained
+// clock, ~10 us of stage hand-overs / DMA issue, ~4 us prologue, ~12 us epilogue (the parity hand-over through LDS and 37.7 MB of
+// slab stores: 256 workgroups x 147 KB, the price of one accumulator set per CU).
 #include "pfr_mma.h"
 #include <stdlib.h>
 
@@ -30,10 +38,10 @@ struct Wg9Params {
   const void* dy;
   float* slabs;
   int H, W, C, Cout, lddy;
-  int nrows;   // N * H image rows
-  int rps;     // image rows per split (a multiple of the stage's rows)
+  int nrows;   // N * (H + 1) extended rows
+  int rps;     // extended rows per split (a multiple of the stage's rows)
   int nsplit, ncb, nib;
-  FastDiv div_h;
+  FastDiv div_h;   // by H + 1
 };
 
 __device__ __forceinline__ u32x2 w9_read_tr16(uint32_t addr, int imm) {
@@ -109,8 +117,9 @@ __global__ __launch_bounds__(512, 1) void wgrad9_kernel(Wg9Params p) {
   // The rows a wave's DMA instructions fetch are tabulated 64 stages at a time: tab[jj] holds, in lane l, the byte offset of the
   // tensor row instruction jj reads in stage tbase + l (~0: no such row — out of the split / the tensor, or a zero row).  In the
   // loop an instruction costs v_readlane + add + compare + select: the row offset is the buffer instruction's SGPR offset and
-  // num_records = row offset + one row's bytes (0 for a missing row), which bounds the lane offsets of the row's pixels whether or not
-  // the hardware counts the SGPR offset in its range check; pad lanes sit 2 GiB out.
+  // num_records = row offset + one row's bytes (0 for a missing row): gfx950 range-checks lane offset + SGPR offset (measured: with
+  // num_records = one row's bytes every row but the first came back as zeros), and this bound is right under either reading; pad
+  // lanes sit 2 GiB out (tensors here stay below 2 GiB: no 32-bit wrap).
   uint32_t tab[IPW];
   auto build = [&](int tbase) __attribute__((always_inline)) {
 #pragma unroll

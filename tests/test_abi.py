@@ -41,12 +41,14 @@ def test_hip_path_refuses_cpu_tensors():
 
 
 def test_wgrad_split_model_is_sane_on_cpu():
-    """pfr_conv2d_wgrad_splits is host arithmetic (no device work): >= 1 split, >= 256 reduction rows per split, the fp32 partial
-    slabs within the 48 MB budget, and a whole number of 512-workgroup rounds where the budget allows one"""
+    """pfr_conv2d_wgrad_splits is host arithmetic (no device work) and sizes the caller's workspace for whichever kernel takes the launch:
+    >= 1 split, >= 128 reduction rows per split, the fp32 partial slabs within the 48 MB budget; 3x3-shaped geometries get the halo-staged
+    kernel's slab count (256 workgroups / block pairs)"""
     from pets_face_recognition_amd._hip import lib
     for (M, Co, KK) in [(802816, 64, 576), (200704, 128, 1152), (50176, 256, 2304), (12544, 512, 4608), (802816, 256, 64),
                         (50176, 1024, 256), (12544, 2048, 512), (256, 512, 2048), (256, 10000, 512), (401408, 288, 96), (64, 8, 8)]:
         s = lib.pfr_conv2d_wgrad_splits(M, Co, KK)
         assert s >= 1 and (s == 1 or (M + s - 1) // s >= 128)
         assert s == 1 or s * Co * KK * 4 <= 48 << 20
-    assert lib.pfr_conv2d_wgrad_splits(200704, 128, 1152) * 9 == 504      # 9 tiles x 56 splits = one full round (the old rule gave 513)
+    assert lib.pfr_conv2d_wgrad_splits(200704, 128, 1152) == 64           # 4 block pairs x 64 splits = 256 workgroups (tile kernel alone: 56)
+    assert lib.pfr_conv2d_wgrad_splits(50176, 1024, 256) * 16 <= 512      # (tile kernel: whole 512-workgroup rounds)
