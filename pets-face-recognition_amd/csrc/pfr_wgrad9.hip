@@ -10,7 +10,7 @@
 // L2->LDS traffic per launch = 13 TB/s — that kernel sits on the L2, at 0.23-0.30 of its MFMA / HBM bound.
 //
 // Here a workgroup owns a [64 co] x [9 taps] x [64 ci] block of dw over a run of image rows.  Rows of dy and of x are staged into
-// LDS in padded row slots [0 | p_0 .. p_{W-1} | 0 ..] of PW = 16 / 32 / 64 pixel positions (128 B each: the 64 channels of the
+// LDS in padded row slots [0 | p_0 .. p_{W-1} | 0 ..] of PW = 8 / 16 / 32 / 64 pixel positions (128 B each: the 64 channels of the
 // block), and the row sequence is EXTENDED by one all-zero row after every image (row index e = n (H + 1) + r).  In that layout a
 // tap is a pure ADDRESS SHIFT: for the 16 positions of a k-group of dy, the matching x positions are the same positions + (ts - 1)
 // in the row slot tr - 1 below / above — an immediate offset on a lane base — and everything outside the image reads zeros that the
@@ -370,8 +370,9 @@ int wgrad9_max_splits(int Cout, int KK) {
 int wgrad9_launch(const void* x, const void* dy, float* slabs, int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad,
                   int lddy, hipStream_t st) {
   if (!wgrad9_mode() || R != 3 || S != 3 || stride != 1 || pad != 1 || C % 64 || Cout % 64 || lddy < Cout) return 0;
-  const int pw = W + 2 <= 16 ? 16 : W + 2 <= 32 ? 32 : W + 2 <= 64 ? 64 : 0;
-  if (!pw || W < 8) return 0;
+  // row slot: [0 | W pixels | 0 ...]; at W = 7 the slot is [0 | 7 pixels] and the right neighbour of the last pixel is the next slot's pad
+  const int pw = W + 1 <= 8 ? 8 : W + 2 <= 16 ? 16 : W + 2 <= 32 ? 32 : W + 2 <= 64 ? 64 : 0;
+  if (!pw || W < 4) return 0;
   const int npairs = (Cout / 64) * (C / 64);
   if (npairs > 256) return 0;
   if ((long)N * H * W * lddy * 2 >= (1L << 31) || (long)N * H * W * C * 2 >= (1L << 31)) return 0;   // (row offsets + the pad lanes' offset stay below 2^32)
@@ -395,7 +396,7 @@ int wgrad9_launch(const void* x, const void* dy, float* slabs, int N, int H, int
     if (!attr) { hipFuncSetAttribute((const void*)wgrad9_kernel<PWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
     hipLaunchKernelGGL((wgrad9_kernel<PWV>), grid, dim3(512), lds, st, p);                                                   \
   }
-  if (pw == 16) PFR_W9_GO(16) else if (pw == 32) PFR_W9_GO(32) else PFR_W9_GO(64)
+  if (pw == 8) PFR_W9_GO(8) else if (pw == 16) PFR_W9_GO(16) else if (pw == 32) PFR_W9_GO(32) else PFR_W9_GO(64)
 #undef PFR_W9_GO
   if (hipGetLastError() != hipSuccess) return -1;
   return nsplit;

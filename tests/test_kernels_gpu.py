@@ -994,6 +994,7 @@ W9_CASES = [
     # N, H, W, C, Cout (3x3, stride 1, pad 1): row slots of 16 / 32 / 64 positions, ragged row counts, image rows that straddle stages
     (3, 14, 14, 64, 64), (2, 9, 13, 128, 64), (5, 8, 8, 64, 192), (2, 28, 28, 128, 128), (3, 17, 20, 64, 128), (2, 30, 30, 64, 64),
     (2, 56, 56, 64, 64), (1, 3, 40, 64, 64), (1, 2, 62, 64, 64), (33, 14, 14, 256, 256), (7, 28, 28, 64, 128),
+    (9, 7, 7, 128, 64), (3, 5, 4, 64, 64), (40, 7, 7, 512, 512),     # 8-position row slots: a k-group spans two image rows
 ]
 
 
