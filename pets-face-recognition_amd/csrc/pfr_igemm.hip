@@ -71,7 +71,11 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   const int wp = wave / WQ, wq = wave % WQ;
   TSTAMP(0);
 
-  const uint32_t t = xcd_remap(blockIdx.x, gridDim.x);
+  // FILT launches are persistent (one workgroup per CU walks the tiles: a 256x256x512 match tile is 8 k-steps, and a fresh workgroup
+  // per tile left a launch gap after every one of them); all other launches have one tile per workgroup and run the body once.
+  const uint32_t ntile = (uint32_t)(p.tilesM * p.tilesN);
+  for (uint32_t tt = blockIdx.x; tt < ntile; tt += gridDim.x) {
+  const uint32_t t = FILT ? tt : xcd_remap(blockIdx.x, gridDim.x);
   const int tn = t % p.tilesN, tm = t / p.tilesN;
   const int n0 = tn * BP;
   const int cls = p.pclass ? tm / p.tpc : 0;
@@ -190,23 +194,27 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   }
 
   // issues the LDS-DMA of one k-step into ring slot `buf` (weights + gathered activations, zero-filled when invalid)
-  auto gload = [&](int buf) {
+  auto gload = [&](int buf, bool issue = true) {   // issue = false: the k-step's DMA is already in flight (FILT), only the walker steps
     char* base = smem + buf * STAGE;
     if constexpr (FAST) {
 #ifdef PFR_IGEMM_TRACE
       if (!(p.dbg & 8))   // experiment: no weight staging at all (halves the L2->LDS fill volume of a 128x128 tile)
 #endif
+      if (issue) {
 #pragma unroll
       for (int j = 0; j < PCH; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * NW + wave) * RPI * ROWB),
                                                  16, (int)(wbase[j] + (uint32_t)(tapbyte + cbyte)), 0, 0, 0);
+      }
 #ifdef PFR_IGEMM_TRACE
       if (!(p.dbg & 4) || tapbyte == 0)
 #endif
+      if (issue) {
 #pragma unroll
       for (int j = 0; j < QCH; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * NW + wave) * RPI) * ROWB),
                                                  16, (int)(qbase[j] + (uint32_t)cbyte), 0, 0, 0);
+      }
       okA = okB; cA = cB;
       okB = okcur; cB = cbyte / (int)sizeof(T) + lc * KP;
       cbyte += BK * (int)sizeof(T);
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   const int nk = nk_all;
   const int npre = nk < NST - 1 ? nk : NST - 1;
   TSTAMP(1);
-  for (int s0 = 0; s0 < npre; ++s0) gload(s0);
+  for (int s0 = 0; s0 < npre; ++s0) gload(s0, !(FILT && s0 == 0 && tt != blockIdx.x));   // (FILT: k-step 0 of a later tile went out under the previous tile's epilogue)
   wait_pending(npre - 1);
   if constexpr (PRO) {
     __syncthreads();  // coefficients visible
@@ -340,11 +348,37 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
     // ---- top-K filter epilogue (gallery match): a lane owns query row m of each 32x32 tile and 16 gallery columns of it
     const uint32_t* thrk = reinterpret_cast<const uint32_t*>(p.y2);
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(p.y);
+    uint32_t tks[TQ];
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int m = m0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
+      tks[j] = m < p.M ? thrk[m] : 0xFFFFFFFFu;
+    }
+    // the first k-step of this workgroup's NEXT tile goes out now, under the compare loops (every wave is past the k-loop's last
+    // barrier: ring slot 0 is free); the thresholds above were requested first, so waiting for them does not wait for the DMA
+    if constexpr (FAST) {
+      const uint32_t tnx = tt + gridDim.x;
+      if (tnx < ntile) {
+        const int n0n = (int)(tnx % p.tilesN) * BP, m0n = (int)(tnx / p.tilesN) * BQ;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j) {
+          const int row = n0n + (j * NW + wave) * RPI + rsub;
+          const uint32_t off = row < p.Cout ? (uint32_t)(((size_t)row * p.K + lc * KP) * sizeof(T)) : OOBB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(smem + (j * NW + wave) * RPI * ROWB), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < QCH; ++j) {
+          const int m = m0n + (j * NW + wave) * RPI + rsub;
+          const uint32_t off = m < p.M ? (uint32_t)(((size_t)m * p.C + lc * KP) * sizeof(T)) : OOBB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(smem + (BP + (j * NW + wave) * RPI) * ROWB), 16, (int)off, 0, 0, 0);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
       const int m = m0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
       if (m >= p.M) continue;
-      const uint32_t tk = thrk[m];
+      const uint32_t tk = tks[j];
 #pragma unroll
       for (int i = 0; i < TP; ++i)
 #pragma unroll
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
           }
         }
     }
-    return;
+    continue;   // (every wave is past the k-loop's last barrier: the ring is free for the next tile's DMA)
   }
   // ---- epilogue phase 1: accumulators -> LDS tile [BQ rows m][BP couts] of TO
 #pragma unroll
@@ -638,6 +672,8 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
     }
   }
   TSTAMP(6);
+  if constexpr (!FILT) break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1050,7 +1086,10 @@ static int launch_filter_k(IgemmParams& p, hipStream_t st) {
   p.div_chw = make_fastdiv(1u); p.div_cw = make_fastdiv(1u);
   p.tilesM = (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
-  const dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(NW * 64);
+  const int total = p.tilesM * p.tilesN;
+  static const bool persist = !(getenv("PFR_MATCH_PERSIST") && getenv("PFR_MATCH_PERSIST")[0] == '0');
+  const int slots = num_cus() * (NW == 8 ? 1 : 2);
+  const dim3 grid((unsigned)(persist && total > slots ? slots : total)), block(NW * 64);
   hipLaunchKernelGGL((igemm_kernel<T, float, BQ, BP, false, true, KCH, NW, WP, 2, true>), grid, block, 0, st, p);
   PFR_CHECK_LAUNCH();
   return PFR_OK;

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(WS ? 320 : 256, WS ? 3 : (((BP + BQ) * KCH_ * 16 * 
 }
 
 // ------------------------------------------------------------------------------------------------
-static int num_cus() {
+int num_cus() {
   static int n = 0;
   if (n == 0) {
     int dev = 0;
