@@ -167,6 +167,12 @@ int pfr_conv1x1_dgrad2_bn(const void* g, const void* z, const void* wcat, const 
 /* batch statistics of x = Z W^T from pfr_gram_colsum's output for Z (no pass over x): mean_c = W[c] . zbar, var_c = W[c] (G2/M - zbar zbar^T)
  * W[c]^T; part = ONE (mean, M2) partial row [2][C] for pfr_bn_finalize(nparts = 1, rows_per_part = M).  W: the bf16 weights [C][K]. */
 int pfr_bn_stats_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, float* part, pfr_stream_t stream);
+/* the same followed by pfr_bn_finalize(nparts = 1, rows_per_part = count) in one launch (results agree to the last bit or two; replaces torch.nn.BatchNorm2d's
+ * training-mode statistics + running-stat update for a bottleneck's bn3: torchvision resnet.py Bottleneck.forward, third-party to /root/reference,
+ * backbone built at configs/dog_fe/fe_dogs_config.py:102-103) */
+int pfr_bn_finalize_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, const float* gamma, const float* beta,
+                              float eps, float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                              float* shift, pfr_stream_t stream);
 long pfr_gram_ws_floats(long M, int Q);
 int pfr_gram_colsum(const void* x, int dtype, long M, int Q, float* out, float* workspace, pfr_stream_t stream);
 

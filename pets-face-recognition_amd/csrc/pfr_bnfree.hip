@@ -101,8 +101,13 @@ __global__ __launch_bounds__(256) void bn3_weights_kernel(const float* __restric
 // column sums of Z (pfr_gram_colsum) — a bottleneck's bn3 gets its statistics from conv3's INPUT, so the forward pass needs no
 // statistics pass over conv3 at all.  W = the bf16 weights the convolution itself uses.  Output: one (mean, M2 = M·var) partial row,
 // the form pfr_bn_finalize merges (nparts = 1, rows_per_part = M).  fp32; checked against fp64: invstd to ~1e-6 relative.
+struct BnFinArgs {   // the tail of pfr_bn_finalize, done by the same launch (pfr_bn_finalize_from_gram)
+  const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var; float* mean; float* invstd; float* scale; float* shift;
+};
+template <bool FIN>
 __global__ __launch_bounds__(256) void bn_stats_gram_kernel(const float* __restrict__ gram, const bf16_t* __restrict__ W, int C, int K,
-                                                            float count, float* __restrict__ part) {
+                                                            float count, float* __restrict__ part, BnFinArgs f) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
@@ -121,14 +126,44 @@ __global__ __launch_bounds__(256) void bn_stats_gram_kernel(const float* __restr
   mu = wave_sum(mu);
   q = wave_sum(q);
   if (lane == 0) {
-    part[c] = mu;
-    part[C + c] = fmaxf(q, 0.f) * count;
+    const float m2 = fmaxf(q, 0.f) * count;
+    if constexpr (!FIN) {
+      part[c] = mu;
+      part[C + c] = m2;
+    } else {   // the tail of bn_finalize_kernel for this one partial row
+      const float g = f.gamma ? f.gamma[c] : 1.f, bb = f.beta ? f.beta[c] : 0.f;
+      const float var = fmaxf(m2 / count, 0.f);
+      const float invstd = rsqrtf(var + f.eps);
+      f.mean[c] = mu;
+      f.invstd[c] = invstd;
+      f.scale[c] = g * invstd;
+      f.shift[c] = bb - mu * g * invstd;
+      if (f.running_mean) {
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mu;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unb;
+      }
+    }
   }
 }
 extern "C" int pfr_bn_stats_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, float* part, hipStream_t st) {
   PFR_CHECK_ARG(gram && W && part, "pfr_bn_stats_from_gram: null pointer");
   PFR_CHECK_ARG(dtype == PFR_BF16 && C > 0 && K > 0 && count > 0.f, "pfr_bn_stats_from_gram: bf16 weights only");
-  hipLaunchKernelGGL(bn_stats_gram_kernel, dim3((C + 3) / 4), dim3(256), 0, st, gram, (const bf16_t*)W, C, K, count, part);
+  hipLaunchKernelGGL(bn_stats_gram_kernel<false>, dim3((C + 3) / 4), dim3(256), 0, st, gram, (const bf16_t*)W, C, K, count, part, BnFinArgs{});
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+// pfr_bn_stats_from_gram + pfr_bn_finalize(nparts = 1) in ONE launch (the forward pass of a BN-input-free block is a chain of small
+// dependent launches: Gram -> slab sum -> statistics -> finalize -> tail; this removes a link): the same arithmetic (pfr_bn_finalize's
+// merge of the single row rounds the mean once more: results agree to the last bit or two)
+extern "C" int pfr_bn_finalize_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, const float* gamma,
+                                         const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                         float* invstd, float* scale, float* shift, hipStream_t st) {
+  PFR_CHECK_ARG(gram && W && mean && invstd && scale && shift, "pfr_bn_finalize_from_gram: null pointer");
+  PFR_CHECK_ARG(dtype == PFR_BF16 && C > 0 && K > 0 && count > 0.f, "pfr_bn_finalize_from_gram: bf16 weights only");
+  PFR_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "pfr_bn_finalize_from_gram: running_mean and running_var go together");
+  BnFinArgs f{gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+  hipLaunchKernelGGL(bn_stats_gram_kernel<true>, dim3((C + 3) / 4), dim3(256), 0, st, gram, (const bf16_t*)W, C, K, count, nullptr, f);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

@@ -630,10 +630,13 @@ class FEEngine:
                     if gram is not None and self.gram_stats:
                         # bn3's batch statistics from conv3's INPUT (Gram matrix + column sums of z2): no pass over conv3 at all
                         rows3 = sshape[0] * OH3 * OW3
-                        part3 = self._A(plan, (1, 2, c.Cout), torch.float32)
-                        ops.append((lib.pfr_bn_stats_from_gram, (gram.data_ptr(), c.w.data_ptr(), self.did, c.Cout, c.Cin, float(rows3),
-                                                                 part3.data_ptr())))
-                        self._bn_fwd(ops, bn, part3, 1, rows3, train, rows3)
+                        if train:    # statistics + finalize in one launch (pfr_bn_stats_from_gram + pfr_bn_finalize give the same)
+                            ops.append((lib.pfr_bn_finalize_from_gram, (gram.data_ptr(), c.w.data_ptr(), self.did, c.Cout, c.Cin, float(rows3),
+                                                                        bn.gamma.data_ptr(), bn.beta.data_ptr(), float(bn.eps), float(bn.momentum),
+                                                                        bn.rm.data_ptr(), bn.rv.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
+                                                                        bn.coef[2].data_ptr(), bn.coef[3].data_ptr())))
+                        else:
+                            self._bn_fwd(ops, bn, None, 1, rows3, train, rows3)
                     else:
                         part3, nt3, mt3 = self._stats_buf(plan, sshape, c, OH3, OW3)
                         ops.append((lib.pfr_conv1x1_stats, (src.data_ptr(), c.w.data_ptr(), self.did, sshape[0], sshape[1], sshape[2], c.Cin,

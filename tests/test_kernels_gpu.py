@@ -988,6 +988,18 @@ def test_batchnorm_statistics_from_the_gram_matrix(M, K, C):
     assert ((coef[0].double() - mu).abs() / var.sqrt()).max().item() < 1e-5
     r = (var + 1e-5).rsqrt()
     assert ((coef[1].double() - r).abs() / r).max().item() < 1e-5
+    # statistics + finalize in one launch: the same to the last bit or two (pfr_bn_finalize's merge of the one row rounds once more)
+    gm, bt = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    rm1, rv1 = torch.randn(C, device=DEV), torch.rand(C, device=DEV) + 0.5
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    two = o.bn_finalize(part, M, M, gm, bt, 1e-5, 0.1, rm1, rv1)
+    one = [torch.empty(C, dtype=torch.float32, device=DEV) for _ in range(4)]
+    lib.pfr_bn_finalize_from_gram(gram.data_ptr(), W.data_ptr(), 1, C, K, float(M), gm.data_ptr(), bt.data_ptr(), 1e-5, 0.1, rm2.data_ptr(),
+                                  rv2.data_ptr(), one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), one[3].data_ptr(), st)
+    torch.cuda.synchronize()
+    for a, b in zip(two, one):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(rm1, rm2, rtol=1e-6, atol=1e-7) and torch.allclose(rv1, rv2, rtol=1e-6, atol=1e-7)
 
 
 W9_CASES = [
