@@ -31,6 +31,9 @@ for name, (N, H, W, C, Co, R, s, p) in CASES.items():
     dll.pfr_debug_igemm_trace(ctypes.c_void_p(0))
     t = tr.cpu().numpy()
     n = int((t[:, 0] != 0).sum())
+    if n == 0:
+        print(f"{name}: not a tile-kernel launch (streaming kernel)")
+        continue
     t = t[:n].astype('float64') * 0.01  # 100 MHz -> us
     t0 = t[:, 0].min()
     d = t[:, 1:7] - t[:, 0:6]
