@@ -68,7 +68,7 @@ bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride,
 int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
 void swgrad_set_mode(int v);   // pfr_wgrad.hip: streaming 1x1 weight gradient (0 off, 1 heuristic, 2 forced)
 int num_cus();               // pfr_igemm_p.hip: CUs of the current device (256 when it cannot be asked)
-void wgrad9_set_mode(int v);   // pfr_wgrad9.hip: halo-staged 3x3 / stride-1 weight gradient (0 off, 1 on)
+void wgrad9_set_mode(int v);   // pfr_wgrad9.hip: halo-staged 3x3 / stride-1 weight gradient (0 off, 1 the 56x56 class, 2 every geometry)
 void wgrad_set_big(int v);   // pfr_wgrad.hip: 256x256 8-wave weight-gradient tiles (0 off, 1 heuristic, 2 forced)
 int sconv_bnb_mode();
 void sconv_set_bnb_mode(int v);

@@ -352,6 +352,12 @@ __global__ __launch_bounds__(512, 1) void wgrad9_kernel(Wg9Params p) {
 }
 
 // ---- host side -----------------------------------------------------------------------------------
+// PFR_WGRAD9 / pfr_set_tuning("wgrad9"): 0 off; 1 (default) the 56x56-class layers only (row slots of 64 positions); 2 every geometry
+// the kernel takes.  Per launch the kernel wins everywhere (x1.13-1.7, profiles/r04_wgrad9.txt) and with the weight gradients serialised
+// behind the main stream mode 2 is worth +1.0 % of the step; NEXT TO the main stream (the default: side stream) its workgroups — one per
+// CU for the whole launch, all of the LDS, 8 x 228 VGPRs — keep the main stream's small dependent launches waiting for a CU, and the
+// step LOSES 0.4-0.6 % with mode 2 (leaving 16-64 CUs unused gets that back, no more); at 56x56, where the tile kernel is slowest, the
+// two effects cancel (+0.1 %).  Interleaved A/B in profiles/r04_wgrad9.txt.
 static int g_wgrad9 = -1;
 void wgrad9_set_mode(int v) { g_wgrad9 = v; }
 static int wgrad9_mode() {
@@ -373,6 +379,7 @@ int wgrad9_launch(const void* x, const void* dy, float* slabs, int N, int H, int
   // row slot: [0 | W pixels | 0 ...]; at W = 7 the slot is [0 | 7 pixels] and the right neighbour of the last pixel is the next slot's pad
   const int pw = W + 1 <= 8 ? 8 : W + 2 <= 16 ? 16 : W + 2 <= 32 ? 32 : W + 2 <= 64 ? 64 : 0;
   if (!pw || W < 4) return 0;
+  if (wgrad9_mode() == 1 && pw != 64) return 0;   // (see wgrad9_mode)
   const int npairs = (Cout / 64) * (C / 64);
   if (npairs > 256) return 0;
   if ((long)N * H * W * lddy * 2 >= (1L << 31) || (long)N * H * W * C * 2 >= (1L << 31)) return 0;   // (row offsets + the pad lanes' offset stay below 2^32)

@@ -998,8 +998,8 @@ def test_batchnorm_statistics_from_the_gram_matrix(M, K, C):
                                   rv2.data_ptr(), one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), one[3].data_ptr(), st)
     torch.cuda.synchronize()
     for a, b in zip(two, one):
-        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
-    assert torch.allclose(rm1, rm2, rtol=1e-6, atol=1e-7) and torch.allclose(rv1, rv2, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)      # (shift = beta - mean * scale cancels: absolute tolerance)
+    assert torch.allclose(rm1, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv1, rv2, rtol=1e-5, atol=1e-6)
 
 
 W9_CASES = [
@@ -1023,7 +1023,7 @@ def test_halo_staged_3x3_weight_gradient(case):
     ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, C, 3, 3), dy.double(), stride=1, padding=1).permute(0, 2, 3, 1).float()
     xd, dyd = nhwc(x).to(DEV, torch.bfloat16), nhwc(dy).to(DEV, torch.bfloat16)
     try:
-        lib.pfr_set_tuning(b"wgrad9", 1)
+        lib.pfr_set_tuning(b"wgrad9", 2)
         a = o.conv2d_wgrad(xd, dyd, 3, 3, 1, 1)
         a2 = o.conv2d_wgrad(xd, dyd, 3, 3, 1, 1)
         lib.pfr_set_tuning(b"wgrad9", 0)

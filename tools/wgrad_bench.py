@@ -40,7 +40,7 @@ def run(geom, reps=20):
         lib.pfr_set_tuning(b"wgrad_big", 0)
     else:
         lib.pfr_set_tuning(b"swgrad", 0)
-    for mode in ((0, 1) if key == b"wgrad9" else (0, 2)):
+    for mode in (0, 2):
         lib.pfr_set_tuning(key, mode)
         out = ops.conv2d_wgrad(x, dy, R, R, s, p, workspace=ws)
         for _ in range(3):
