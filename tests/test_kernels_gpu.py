@@ -1035,3 +1035,33 @@ def test_halo_staged_3x3_weight_gradient(case):
     scale = ref.abs().max().item()
     assert (a.cpu() - ref).abs().max().item() < 1e-5 * scale, (a.cpu() - ref).abs().max().item() / scale
     assert (a - b).abs().max().item() < 1e-5 * scale
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_3x3_weight_gradient_of_a_channel_slice_of_dy(mode):
+    """pfr_conv2d_wgrad with lddy > Cout (dy is a channel slice of a wider tensor) on the tile kernel and on pfr_wgrad9.hip: the same
+    numbers as for a contiguous copy of the slice"""
+    from pets_face_recognition_amd._hip import lib
+    N, H, W, C, Cout, ld = 5, 14, 14, 64, 64, 192
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(N, H, W, C, generator=g).bfloat16().to(DEV)
+    wide = torch.randn(N, H, W, ld, generator=g).bfloat16().to(DEV)
+    dy_c = wide[..., :Cout].contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        lib.pfr_set_tuning(b"wgrad9", mode)
+        splits = lib.pfr_conv2d_wgrad_splits(N * H * W, Cout, 9 * C)
+        ws = torch.empty(splits * Cout * 9 * C, dtype=torch.float32, device=DEV)
+        for dy, lddy in ((dy_c, Cout), (wide, ld)):
+            dw = torch.empty(Cout, 3, 3, C, dtype=torch.float32, device=DEV)
+            lib.pfr_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), 1, N, H, W, C, Cout, 3, 3, 1, 1, H, W, lddy,
+                                 0, 0, 0, 1.0, 0, st)
+            outs.append(dw)
+    finally:
+        lib.pfr_set_tuning(b"wgrad9", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2).double().cpu(), (Cout, C, 3, 3),
+                                      dy_c.float().permute(0, 3, 1, 2).double().cpu(), stride=1, padding=1).permute(0, 2, 3, 1).float()
+    assert (outs[0].cpu() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
