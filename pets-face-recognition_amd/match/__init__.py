@@ -8,7 +8,6 @@ optional exact fp32 re-scoring of the candidate lists); CPU tensors use plain to
 behaviour, used by the CPU plumbing config).  Ordering everywhere: score descending, ties → lower index.
 """
 import ctypes
-import os
 
 import torch
 
@@ -20,37 +19,72 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_FUSED_DEFAULT = os.environ.get("PFR_MATCH_FUSED", "1") != "0"
+class PreparedGallery:
+    """An L2-normalised gallery kept on the device for MANY query batches (generate_tsv.py:91-125 loops over query cards; a served
+    gallery answers query batch after query batch): the bf16 GEMM operand and, for the exact re-scoring, the fp32 copy.  Reuse is
+    EXPLICIT — the caller builds the handle with `prepare_gallery(g)` and passes it to `cosine_topk` in place of `g`; nothing is keyed
+    on tensor identity or version counters (writes through raw pointers — every kernel of this library — are invisible to them), so a
+    gallery buffer that was refilled needs a new handle.  1 M x 512: 1 GB (bf16) + 2 GB (fp32)."""
 
-# The L2-normalised gallery (bf16 GEMM operand + fp32 copy for the exact re-scoring) of the LAST cosine_topk call, reused when the
-# same tensor comes back unmodified (torch's version counter catches every in-place write): a gallery is matched against many query
-# batches (generate_tsv.py:91-125 loops over query cards; Controller.test_epoch_end scores one embedding matrix), and normalising
-# 1 M x 512 fp32 rows is 0.75 ms of the 19 ms match.  One entry (3 GB for the 1 M gallery); clear_gallery_cache() drops it.
-_GCACHE = {}
+    def __init__(self, gn, gn32, compute_dtype, rescore, normalized):
+        self.gn, self.gn32 = gn, gn32
+        self.compute_dtype, self.rescore, self.normalized = compute_dtype, rescore, normalized
+        self.shape, self.device = tuple(gn.shape), gn.device
+
+    def __len__(self):
+        return self.shape[0]
 
 
-def clear_gallery_cache():
-    _GCACHE.clear()
+def _prep_rows(x32, T, rescore, normalize):
+    """rows of an fp32 matrix -> (GEMM operand in T, fp32 copy for the re-scoring or None)"""
+    D = x32.shape[1]
+    if normalize and T == torch.bfloat16 and D % 4 == 0 and D <= 2048:
+        # one pass per matrix: bf16 GEMM operand + (when re-scoring) the fp32 copy
+        xb = torch.empty(x32.shape, dtype=torch.bfloat16, device=x32.device)
+        xf = torch.empty(x32.shape, dtype=torch.float32, device=x32.device) if rescore else None
+        lib.pfr_l2norm_dual(x32.data_ptr(), xb.data_ptr(), 0 if xf is None else xf.data_ptr(), 0, x32.shape[0], D, 1e-12, _stream())
+        return xb, xf
+    if normalize:
+        xn, _, _ = ops.l2norm_fwd(x32, T)
+        xf = ops.l2norm_fwd(x32, torch.float32)[0] if rescore else None
+        return xn, xf
+    # rows are used as given (card centroids)
+    return (x32 if T == torch.float32 else ops.cast(x32, T)), x32
 
 
-def _gallery_key(g, rescore):
-    return (g.data_ptr(), tuple(g.shape), g.dtype, g._version, str(g.device), bool(rescore))
+def prepare_gallery(g, compute_dtype=torch.bfloat16, rescore=None, normalize=True):
+    """Normalise a gallery once for many `cosine_topk(q, handle, k)` calls (same compute_dtype / rescore / normalize as those calls)."""
+    if not g.is_cuda:
+        raise PfrError("prepare_gallery: the gallery handle is a device object (CPU tensors go to cosine_topk directly)")
+    T = compute_dtype
+    if rescore is None:
+        rescore = T != torch.float32
+    gn, gn32 = _prep_rows(g.float().contiguous(), T, rescore, normalize)
+    return PreparedGallery(gn, gn32, T, bool(rescore), bool(normalize))
 
 
 def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self=False, rescore=None, slack=None,
-                normalize=True, fused_filter=_FUSED_DEFAULT):
-    """Top-k gallery rows per query by cosine similarity.  q [Q,D], g [G,D] (any scale; rows are L2-normalised here).
+                normalize=True, fused_filter=True, merge_every=2):
+    """Top-k gallery rows per query by cosine similarity.  q [Q,D], g [G,D] (any scale; rows are L2-normalised here) or a
+    `prepare_gallery(g)` handle (the gallery's normalisation is then not repeated per call).
     → (scores [Q,k] fp32 cosine, idx [Q,k] int32, −1 / −inf padded when fewer than k exist).
     exclude_self: q and g are the same set, the diagonal is skipped (the reference excludes the query itself).
     rescore (default: True for bf16): candidates are selected on bf16-input scores with `slack` extra entries, then
     re-scored exactly in fp32 and re-sorted, so that the final order is the fp32 order."""
+    prepared = g if isinstance(g, PreparedGallery) else None
     if not q.is_cuda:
+        if prepared is not None:
+            raise PfrError("cosine_topk: a PreparedGallery is a device object; pass the CPU gallery tensor itself")
         return _cosine_topk_torch(q, g, k, exclude_self, normalize)
     Q, D = q.shape
     G = g.shape[0]
     T = compute_dtype
     if rescore is None:
         rescore = T != torch.float32
+    if prepared is not None and (prepared.compute_dtype != T or prepared.rescore != bool(rescore) or prepared.normalized != bool(normalize)
+                                 or prepared.shape[1] != D or prepared.device != q.device):
+        raise PfrError("cosine_topk: the PreparedGallery was built for other settings "
+                       f"({prepared.compute_dtype}, rescore={prepared.rescore}, normalize={prepared.normalized}, D={prepared.shape[1]}, {prepared.device})")
     if k > 512:
         # the running lists of the top-K kernels hold at most 512 entries per query (pfr_match.hip); silently returning
         # fewer columns, or re-scoring past the candidate list, would be wrong answers
@@ -59,34 +93,11 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     if rescore:
         kc = max(k, min(512, k + (slack if slack is not None else max(28, k // 2 + k))))
     q32 = q.float().contiguous()
-    gkey = _gallery_key(g, rescore)
-    hit = _GCACHE.get("entry")
-    use_cache = normalize and T == torch.bfloat16 and D % 4 == 0 and D <= 2048 and hit is not None and hit[0] == gkey
-    g32 = None if use_cache else g.float().contiguous()      # (a cache hit needs neither the fp32 copy nor the normalisation pass)
-    if normalize and T == torch.bfloat16 and D % 4 == 0 and D <= 2048:
-        # one pass per matrix: bf16 GEMM operand + (when re-scoring) the fp32 copy
-        def prep(x):
-            xb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-            xf = torch.empty(x.shape, dtype=torch.float32, device=x.device) if rescore else None
-            lib.pfr_l2norm_dual(x.data_ptr(), xb.data_ptr(), 0 if xf is None else xf.data_ptr(), 0, x.shape[0], D, 1e-12, _stream())
-            return xb, xf
-        qn, qn32 = prep(q32)
-        if use_cache:
-            gn, gn32 = hit[1], hit[2]
-        else:
-            _GCACHE.clear()          # (drop the old copies before the new ones are allocated)
-            gn, gn32 = prep(g32)
-            if os.environ.get("PFR_MATCH_GCACHE", "1") != "0":
-                _GCACHE["entry"] = (gkey, gn, gn32, g)      # (holding g keeps its address from being recycled under the key)
-    elif normalize:
-        qn, _, _ = ops.l2norm_fwd(q32, T)
-        gn, _, _ = ops.l2norm_fwd(g32, T)
-        if rescore:
-            qn32, _, _ = ops.l2norm_fwd(q32, torch.float32)
-            gn32, _, _ = ops.l2norm_fwd(g32, torch.float32)
-    else:   # rows are used as given (card centroids)
-        qn, gn = (q32, g32) if T == torch.float32 else (ops.cast(q32, T), ops.cast(g32, T))
-        qn32, gn32 = q32, g32
+    qn, qn32 = _prep_rows(q32, T, rescore, normalize)
+    if prepared is not None:
+        gn, gn32 = prepared.gn, prepared.gn32
+    else:
+        gn, gn32 = _prep_rows(g.float().contiguous(), T, rescore, normalize)
     chunk = min(chunk, G)
     state = torch.empty(lib.pfr_topk_state_bytes(Q, kc), dtype=torch.uint8, device=q.device)
     self_idx = torch.arange(Q, dtype=torch.int32, device=q.device) if exclude_self else None
@@ -112,7 +123,6 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
         # the candidate lists of TWO fused chunks are folded into the running lists by one merge (expected candidates per query for two
         # chunks: <= 2 * kc, cap = 1536; an overflow is flagged and the match redone unfused): 18.4 -> 17.9 ms at 10 k x 1 M, same results;
         # every 3 / 4 chunks: 18.3 / 18.7 (the stale threshold lets more candidates through the filter epilogue)
-        merge_every = int(os.environ.get("PFR_MATCH_MERGE_EVERY", "2"))
         pending = 0
         for si, (c0, n, seg_fused) in enumerate(segs):
             if seg_fused:
@@ -359,13 +369,14 @@ def cosine_topk_sharded(q, g_local, k, g_offset, group=None, **kw):
         pad = k - kk
         sc = torch.cat([sc, torch.full((sc.shape[0], pad), -float("inf"), device=sc.device)], 1)
         idx = torch.cat([idx, torch.full((idx.shape[0], pad), -1, dtype=idx.dtype, device=idx.device)], 1)
-    gidx = torch.where(idx >= 0, idx.long() + int(g_offset), idx.long())
+    gidx = torch.where(idx >= 0, idx + int(g_offset), idx).int()
     world = dist.get_world_size(group)
-    all_sc = [torch.empty_like(sc) for _ in range(world)]
-    all_ix = [torch.empty_like(gidx) for _ in range(world)]
-    dist.all_gather(all_sc, sc.contiguous(), group=group)
-    dist.all_gather(all_ix, gidx.contiguous(), group=group)
-    S, I = torch.cat(all_sc, 1), torch.cat(all_ix, 1)
+    # ONE collective: (fp32 score bits, int32 global index) pairs of every rank, [world][Q][k][2] int32
+    mine = torch.stack([sc.contiguous().view(torch.int32), gidx], dim=2).contiguous()
+    everyone = torch.empty((world,) + tuple(mine.shape), dtype=torch.int32, device=mine.device)
+    dist.all_gather(list(everyone.unbind(0)), mine, group=group)     # (views of one buffer: gloo has no all_gather_into_tensor)
+    S = everyone[..., 0].contiguous().view(torch.float32).permute(1, 0, 2).reshape(sc.shape[0], world * k)
+    I = everyone[..., 1].permute(1, 0, 2).reshape(sc.shape[0], world * k).long()
     # merge: score descending, ties → lower global index
     key_i = torch.where(I >= 0, I, torch.full_like(I, 2 ** 62))
     order = torch.argsort(key_i, dim=1, stable=True)

@@ -399,3 +399,21 @@ def test_generic_ddp_rebinds_to_the_controller_built_after_the_tuners_gloo_world
                         "127.0.0.1", "--master-port", "29641", str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_is_around_it():
+    """`python bench.py --gpus N` (the driver's N = 1 form with another N) must start N ranks itself: the launcher path is
+    exercised here with the GPU-free self test — two ranks under torch.distributed.run on 127.0.0.1, ONE JSON line from rank 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--launcher-selftest"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec == {"launcher_selftest": True, "n_gpus": 2, "rank_sum": 1.0, "steps": 3, "warmup": 1}
+    # a rank count that disagrees with the launcher's world size is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], capture_output=True, text=True, timeout=300, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
