@@ -151,11 +151,12 @@ int pfr_conv2d_dgrad_bn_sub_ex(const void* dy, const void* wt, void* dx, int dty
  * or — S == NULL: wa_t is then ONE concatenated tensor wcat [K][C + K], row k = [A*W column k | S row k] — a single
  * pfr_conv1x1_dgrad2_bn(G, Z, wcat, bias) launch over both row sources (bias added in fp32 inside the accumulators; BatchNorm-backward
  * sums of the BN dZ feeds as pfr_conv2d_dgrad_bn with a recomputed ReLU mask; pfr_conv1x1_dgrad2_bn_parts = partial rows, 0 = not taken).
- * W = the fp32 master weights [C][K]; count = M rows. */
-int pfr_bn3_bwd_coef(const float* part, int nparts, const float* G1, const float* zsum, const float* W, const float* gamma,
+ * W [C][K] (wdtype PFR_BF16 / PFR_F32) = the weights the FORWARD convolution multiplied with (the bf16 shadow on the bf16 path): every term
+ * that reconstructs x = Z W^T must use the x that was actually normalised; count = M rows. */
+int pfr_bn3_bwd_coef(const float* part, int nparts, const float* G1, const float* zsum, const void* W, int wdtype, const float* gamma,
                      const float* invstd, int C, int K, float count, float* dgamma, float* dbeta, float* coef, int accumulate,
                      pfr_stream_t stream);
-int pfr_bn3_bwd_weights(const float* coef, const float* G1, const float* G2, const float* zsum, const float* W, int C, int K, float count,
+int pfr_bn3_bwd_weights(const float* coef, const float* G1, const float* G2, const float* zsum, const void* W, int wdtype, int C, int K, float count,
                         float* dW, void* wa_t, void* S, float* bias, int accumulate, pfr_stream_t stream);
 int pfr_conv1x1_dgrad2_bn_parts(int dtype, int N, int H, int W, int C1, int C2, int Cout);
 int pfr_conv1x1_dgrad2_bn(const void* g, const void* z, const void* wcat, const float* bias, void* dx, int dtype, int N, int H, int W,
@@ -165,14 +166,17 @@ int pfr_conv1x1_dgrad2_bn(const void* g, const void* z, const void* wcat, const 
  * of pfr_bn3_bwd_coef / pfr_bn3_bwd_weights.  out = Q*Q floats then Q floats; workspace = pfr_gram_ws_floats(M, Q) floats (0: geometry
  * not supported — pfr_conv2d_wgrad(x, x) + pfr_colsum give the same). */
 /* batch statistics of x = Z W^T from pfr_gram_colsum's output for Z (no pass over x): mean_c = W[c] . zbar, var_c = W[c] (G2/M - zbar zbar^T)
- * W[c]^T; part = ONE (mean, M2) partial row [2][C] for pfr_bn_finalize(nparts = 1, rows_per_part = M).  W: the bf16 weights [C][K]. */
-int pfr_bn_stats_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, float* part, pfr_stream_t stream);
+ * W[c]^T; part = ONE (mean, M2) partial row [2][C] for pfr_bn_finalize(nparts = 1, rows_per_part = M).  W: the bf16 weights [C][K].
+ * The subtraction cancels when a channel is nearly constant (|mean| >> std): the kernel bounds its own rounding error and, where that exceeds
+ * 1 % of var + eps, stores 1 to *cancel_flag (may be NULL; host-visible memory lets the caller fall back to a statistics pass over x). */
+int pfr_bn_stats_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, float* part, float eps, int* cancel_flag,
+                           pfr_stream_t stream);
 /* the same followed by pfr_bn_finalize(nparts = 1, rows_per_part = count) in one launch (results agree to the last bit or two; replaces torch.nn.BatchNorm2d's
  * training-mode statistics + running-stat update for a bottleneck's bn3: torchvision resnet.py Bottleneck.forward, third-party to /root/reference,
  * backbone built at configs/dog_fe/fe_dogs_config.py:102-103) */
 int pfr_bn_finalize_from_gram(const float* gram, const void* W, int dtype, int C, int K, float count, const float* gamma, const float* beta,
                               float eps, float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                              float* shift, pfr_stream_t stream);
+                              float* shift, int* cancel_flag, pfr_stream_t stream);
 long pfr_gram_ws_floats(long M, int Q);
 int pfr_gram_colsum(const void* x, int dtype, long M, int Q, float* out, float* workspace, pfr_stream_t stream);
 

@@ -27,6 +27,26 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 void pfr_set_error(const char* fmt, ...);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a host process that drives several GPUs must raise the
+// limit on each of them (a process-wide `static bool` set it on the first device only, and the > 64 KiB launch then failed
+// on the second).  `done` = one bit per device ordinal, set after the attribute call; two threads racing both make the (idempotent) call.
+#include <atomic>
+static inline bool pfr_lds_attr_needed(std::atomic<unsigned long long>& done, unsigned long long* bit) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  *bit = 1ull << (dev & 63);
+  return !(done.load(std::memory_order_acquire) & *bit);
+}
+#define PFR_MAX_LDS_ONCE(done, bytes, ...)                                                                          \
+  do {                                                                                                              \
+    unsigned long long bit_;                                                                                        \
+    if (pfr_lds_attr_needed(done, &bit_)) {                                                                         \
+      const void* fns_[] = {__VA_ARGS__};                                                                           \
+      for (const void* f_ : fns_) (void)hipFuncSetAttribute(f_, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+      done.fetch_or(bit_, std::memory_order_release);                                                               \
+    }                                                                                                               \
+  } while (0)
+
 // When non-null, the next launch of an entry point that supports it (pfr_bn_bwd_apply) attaches this event to its kernel as the
 // dispatch's own completion signal (hipExtLaunchKernel stopEvent) and clears it: the plan executor uses it for the fork that
 // follows, instead of a separate hipEventRecord whose marker packet delays the next kernel of the stream by ~7 us.

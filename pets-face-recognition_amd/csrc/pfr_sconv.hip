@@ -735,11 +735,8 @@ static int sconv_launch_ns(SconvParams& sp, const SconvPlan& pl, hipStream_t st)
 #define PFR_SCONV_GO(NSV)                                                                                       \
   do {                                                                                                          \
     auto kern = sconv_kernel<TP, NSV, STATS, EP>;                                                                     \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
+    static std::atomic<unsigned long long> attr_set{0};                                                         \
+    PFR_MAX_LDS_ONCE(attr_set, 160 * 1024, (const void*)kern);                                                  \
     hipLaunchKernelGGL(kern, grid, block, lds, st, sp);                                                         \
   } while (0)
   if (pl.ns >= 4) PFR_SCONV_GO(4);

@@ -411,13 +411,8 @@ int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) 
 #endif
   const int lds = 64 * 1152 + 4 * (2 * 8192 + 4096);
   const dim3 grid((unsigned)((sp.nblk + bpw - 1) / bpw)), block(256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sconv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)sconv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)sconv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_set{0};
+  PFR_MAX_LDS_ONCE(attr_set, 160 * 1024, (const void*)sconv3_kernel<true>, (const void*)sconv3_kernel<false>, (const void*)sconv3_kernel<false, true>);
   if (infer) hipLaunchKernelGGL((sconv3_kernel<false, true>), grid, block, lds, st, sp);
   else if (p.stats_part) hipLaunchKernelGGL(sconv3_kernel<true>, grid, block, lds, st, sp);
   else hipLaunchKernelGGL(sconv3_kernel<false>, grid, block, lds, st, sp);

@@ -850,8 +850,10 @@ static int swgrad_mode() {
 struct SwgradPlan { int gp, gq, wp, wq, wm, tilesP, tilesQ, nsplit; };
 // geometry-only decision (pfr_conv2d_wgrad_splits sees only M, Cout, KK: a 3x3 layer with the same (Cout, KK) merely gets room
 // for this many slabs; the launcher takes the streaming kernel only for 1x1 / stride-1 bf16 launches without a fused prologue)
-static bool swgrad_plan(int M, int P, int Q, SwgradPlan* sp) {
-  const int mode = swgrad_mode();
+// any_mode: the decision under mode 2 whatever the current mode is (workspace sizing: a plan built under one mode must have room for the
+// slabs of a launch under another — pfr_set_tuning can change the mode between the two)
+static bool swgrad_plan(int M, int P, int Q, SwgradPlan* sp, bool any_mode = false) {
+  const int mode = any_mode ? 2 : swgrad_mode();
   if (mode == 0 || P % 64 || Q % 64 || P < 64 || Q < 64 || P > 1024 || Q > 1024) return false;
   int gp, gq;
   if (P >= 128 && P >= Q) { gp = 2; gq = 1; } else if (Q >= 128) { gp = 1; gq = 2; } else { gp = 1; gq = 1; }
@@ -882,8 +884,8 @@ static bool swgrad_plan(int M, int P, int Q, SwgradPlan* sp) {
 template <int GP, int GQ, int NS>
 static void swgrad_go(const SwgradParams& sp, hipStream_t st) {
   constexpr int lds = 8 * NS * (GP + GQ) * 2048;
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)swgrad_kernel<GP, GQ, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  static std::atomic<unsigned long long> attr{0};
+  PFR_MAX_LDS_ONCE(attr, lds, (const void*)swgrad_kernel<GP, GQ, NS>);
   hipLaunchKernelGGL((swgrad_kernel<GP, GQ, NS>), dim3(256), dim3(512), lds, st, sp);
 }
 static int swgrad_launch(const WgradParams& p, const SwgradPlan& pl, float* slabs, hipStream_t st) {
@@ -1093,7 +1095,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // halo-staged 3x3 / stride-1 weight gradient (pfr_wgrad9.hip)
 int wgrad9_launch(const void* x, const void* dy, float* slabs, int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad,
                   int lddy, hipStream_t st);
-int wgrad9_max_splits(int Cout, int KK);
+int wgrad9_max_splits(int Cout, int KK);   // (mode-independent: the slabs the kernel WOULD write when enabled)
 
 static int wgrad_v3() {
   static const int v = getenv("PFR_WGRAD_V3") ? atoi(getenv("PFR_WGRAD_V3")) : 1;
@@ -1109,8 +1111,8 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_kernel<T, BP, BQ, true>), grid, dim3(256), 0, st, p);
   else if (p.v2 && sizeof(T) == 2 && wgrad_v3()) {
     constexpr int lds = PFR_WGRAD_NST * 32 * (BP + BQ) * 2;   // ring of NST stages of 32 rows
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)wgrad3_kernel<BP, BQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    static std::atomic<unsigned long long> attr{0};
+    PFR_MAX_LDS_ONCE(attr, lds, (const void*)wgrad3_kernel<BP, BQ>);
     hipLaunchKernelGGL((wgrad3_kernel<BP, BQ>), grid, dim3(256), lds, st, p);
   }
   else if (p.v2)
@@ -1180,11 +1182,12 @@ static int wgrad_tile_splits(int M, int Cout, int KK) {
   if (forced > 0) best = forced < maxs ? forced : maxs;
   return (int)best;
 }
-// the caller's workspace: room for the slabs of whichever kernel takes the launch
+// the caller's workspace: room for the slabs of whichever kernel takes the launch — under ANY setting of the tuning knobs, so that a
+// workspace sized when a plan was built is large enough for a launch after a later pfr_set_tuning("wgrad9" / "swgrad", ...)
 extern "C" int pfr_conv2d_wgrad_splits(int M, int Cout, int KK) {
   int best = wgrad_tile_splits(M, Cout, KK);
   SwgradPlan spl;
-  if (swgrad_plan(M, Cout, KK, &spl) && spl.nsplit > best) best = spl.nsplit;   // (the streaming 1x1 kernel's)
+  if (swgrad_plan(M, Cout, KK, &spl, true) && spl.nsplit > best) best = spl.nsplit;   // (the streaming 1x1 kernel's)
   if (wgrad9_max_splits(Cout, KK) > best) best = wgrad9_max_splits(Cout, KK);     // (the halo-staged 3x3 kernel's)
   return best;
 }
@@ -1236,8 +1239,8 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
     p.tilesP = (p.Cout + 255) / 256;
     p.tilesQ = (p.KK + 255) / 256;
     constexpr int lds = PFR_WGRAD_NST * 32 * (256 + 256) * 2;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)wgrad3_kernel<256, 256, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    static std::atomic<unsigned long long> attr{0};
+    PFR_MAX_LDS_ONCE(attr, lds, (const void*)wgrad3_kernel<256, 256, 8, 2>);
     hipLaunchKernelGGL((wgrad3_kernel<256, 256, 8, 2>), dim3((unsigned)(p.tilesP * p.tilesQ * p.splits)), dim3(512), lds, stream, p);
     PFR_CHECK_LAUNCH();
     rc = PFR_OK;
@@ -1275,12 +1278,12 @@ extern "C" int pfr_gram_colsum(const void* x, int dtype, long M, int Q, float* o
   const long nb = (M + 15) / 16, per = 256L * wm;
   gp.nit = (int)((nb + per - 1) / per);
   if (Q == 64) {
-    static bool attr = false;   // (LDS: the rings, then — reused — the wave-group sums: 4 waves x 6 tiles / 4 waves x 10 tiles of 4 KiB)
-    if (!attr) { hipFuncSetAttribute((const void*)gram_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static std::atomic<unsigned long long> attr{0};   // (LDS: the rings, then — reused — the wave-group sums: 4 waves x 6 tiles / 4 waves x 10 tiles of 4 KiB)
+    PFR_MAX_LDS_ONCE(attr, 160 * 1024, (const void*)gram_kernel<1, 4>);
     hipLaunchKernelGGL((gram_kernel<1, 4>), dim3(256), dim3(512), 160 * 1024, st, gp);
   } else {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)gram_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static std::atomic<unsigned long long> attr{0};
+    PFR_MAX_LDS_ONCE(attr, 160 * 1024, (const void*)gram_kernel<2, 3>);
     hipLaunchKernelGGL((gram_kernel<2, 3>), dim3(256), dim3(512), 160 * 1024, st, gp);
   }
   PFR_CHECK_LAUNCH();

@@ -367,7 +367,7 @@ static int wgrad9_mode() {
 
 // upper bound of the slabs a launch with this (Cout, KK) may write (the caller's workspace: pfr_conv2d_wgrad_splits)
 int wgrad9_max_splits(int Cout, int KK) {
-  if (!wgrad9_mode() || KK % 576 || Cout % 64) return 0;
+  if (KK % 576 || Cout % 64) return 0;     // (independent of wgrad9_mode(): workspace sizing must cover a later change of the mode)
   const int npairs = (Cout / 64) * (KK / 576);
   return npairs <= 256 ? 256 / npairs : 0;
 }
@@ -399,8 +399,8 @@ int wgrad9_launch(const void* x, const void* dy, float* slabs, int N, int H, int
   {                                                                                                                          \
     constexpr int end = 3 * 16384 + 1024 + 3 * (128 / PWV + 2) * PWV * 128 + 1024;                                           \
     constexpr int lds = end > RED ? end : RED;                                                                               \
-    static bool attr = false;                                                                                                \
-    if (!attr) { hipFuncSetAttribute((const void*)wgrad9_kernel<PWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
+    static std::atomic<unsigned long long> attr{0};                                                                                                \
+    PFR_MAX_LDS_ONCE(attr, lds, (const void*)wgrad9_kernel<PWV>); \
     hipLaunchKernelGGL((wgrad9_kernel<PWV>), grid, dim3(512), lds, st, p);                                                   \
   }
   if (pw == 8) PFR_W9_GO(8) else if (pw == 16) PFR_W9_GO(16) else if (pw == 32) PFR_W9_GO(32) else PFR_W9_GO(64)

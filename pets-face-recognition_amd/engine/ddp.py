@@ -141,17 +141,26 @@ class FlatDDP:
             for t in tensors:
                 dist.broadcast(t, 0, group=self.group)
             return
-        # through the C-ABI communicator: the other ranks contribute zeros to a SUM all-reduce (x + 0 + ... + 0 = x exactly)
+        # through the C-ABI communicator: the other ranks contribute zeros to a SUM all-reduce (x + 0 + ... + 0 = x exactly).  The
+        # exchange runs on a TEMPORARY buffer and is copied back only after it completed: a failed or timed-out collective
+        # must not leave a rank with zeroed parameters.  The two communicators (this one and torch.distributed's) are never in flight
+        # together: the device is drained before the first and after the last pfr collective, so a torch collective issued next —
+        # e.g. sync_buffers' broadcast of num_batches_tracked — is ordered after them on every rank.
+        dev = self.eng.grad.device
+        torch.cuda.synchronize(dev)
+        staged = []
         for t in tensors:
             if t.dtype not in (torch.float32, torch.bfloat16):
                 dist.broadcast(t, 0, group=self.group)
+                torch.cuda.synchronize(dev)
                 continue
-            c = t if t.is_contiguous() else t.contiguous()
-            if self.comm.rank != 0:
-                c.zero_()
-            self.comm.allreduce_(c, average=False)
-            if c is not t:
-                t.copy_(c)
+            tmp = t.detach().clone().contiguous() if self.comm.rank == 0 else torch.zeros(t.shape, dtype=t.dtype, device=t.device)
+            self.comm.allreduce_(tmp, average=False)
+            staged.append((t, tmp))
+        torch.cuda.synchronize(dev)          # raises here if a collective failed: nothing has been overwritten yet
+        for t, tmp in staged:
+            t.copy_(tmp)
+        torch.cuda.synchronize(dev)
 
     def detach(self):
         """unhook from the model (the trainer builds a new FlatDDP when the model got a new engine)"""

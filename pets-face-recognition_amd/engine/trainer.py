@@ -43,7 +43,7 @@ class Trainer:
     def __init__(self, gpus=0, default_root_dir=None, strategy=None, max_epochs=1, logger=False, enable_checkpointing=False,
                  callbacks=None, num_sanity_val_steps=0, limit_train_batches=None, limit_val_batches=None,
                  check_val_every_n_epoch=1, log_every_n_steps=50, benchmark=None, fast_dev_run=False, prefetch_batches=2,
-                 resume_from_checkpoint=None, **_ignored):
+                 resume_from_checkpoint=None, resume_weights_only=False, **_ignored):
         self.gpus, self.root, self.strategy = gpus, default_root_dir, strategy
         self.max_epochs = 1 if fast_dev_run else max_epochs
         self.logger = logger if logger else None
@@ -59,8 +59,9 @@ class Trainer:
         self.global_step = 0
         self.ddp = None
         self.resume_from_checkpoint = resume_from_checkpoint
+        self.resume_weights_only = resume_weights_only   # a bare state dict without its .trainer sidecar restarts at epoch 0 instead of raising
         # batches copied to the device ahead of the step on a copy stream (data_loading/prefetch.py); 0: plain .to() per batch
-        self.prefetch_batches = int(os.environ.get('PFR_PREFETCH', prefetch_batches))
+        self.prefetch_batches = int(prefetch_batches)
         self.train_img_s = None      # end-to-end images/s of the last fit() (loader + copy + step), first 5 steps excluded
 
     # ------------------------------------------------------------------
@@ -119,18 +120,38 @@ class Trainer:
         path = Path(path)
         if not path.is_file():
             raise FileNotFoundError(f"resume_from_checkpoint: no checkpoint at {path}")
-        ckpt = torch.load(str(path), map_location='cpu')
+        # torch >= 2.6 unpickles with weights_only=True by default: fine for this trainer's own files (tensors, dicts, lists, numbers),
+        # not for a pytorch-lightning checkpoint (callbacks, AttributeDict hyper-parameters, ...).  The checkpoint is the user's own file,
+        # as it is for PL's `resume_from_checkpoint`: try the safe load first, fall back to the full unpickler and say so.
+        def load(p_):
+            try:
+                return torch.load(str(p_), map_location='cpu', weights_only=True)
+            except Exception as e:   # noqa: BLE001  (pickle.UnpicklingError and friends)
+                print(f'resume_from_checkpoint: {Path(p_).name} holds more than tensors ({type(e).__name__}); loading it with the full unpickler')
+                return torch.load(str(p_), map_location='cpu', weights_only=False)
+        ckpt = load(path)
         if isinstance(ckpt, dict) and 'state_dict' in ckpt:
             sd, loop = ckpt['state_dict'], ckpt
         else:
             sd = ckpt
             side = Path(str(path) + '.trainer')
-            loop = torch.load(str(side), map_location='cpu') if side.is_file() else {}
+            if side.is_file():
+                loop = load(side)
+            elif self.resume_weights_only:
+                loop = {}
+            else:
+                raise FileNotFoundError(f"resume_from_checkpoint: {path.name} is a bare state dict and its loop state {side.name} is missing "
+                                        f"(epoch, optimizer, LR schedule); pass Trainer(resume_weights_only=True) to restart at epoch 0 from these weights")
         controller.load_state_dict(sd, strict=True)
-        for o, st in zip(optims, loop.get('optimizer_states', [])):
-            o.load_state_dict(st)
-        for s_, st in zip(scheds, loop.get('lr_schedulers', [])):
-            s_.load_state_dict(st)
+        if loop:
+            ost, lst = loop.get('optimizer_states', []), loop.get('lr_schedulers', [])
+            if len(ost) != len(optims) or len(lst) != len(scheds):
+                raise ValueError(f"resume_from_checkpoint: the checkpoint holds {len(ost)} optimizer / {len(lst)} scheduler states, "
+                                 f"configure_optimizers() built {len(optims)} / {len(scheds)}")
+            for o, st in zip(optims, ost):
+                o.load_state_dict(st)
+            for s_, st in zip(scheds, lst):
+                s_.load_state_dict(st)
         self.global_step = int(loop.get('global_step', 0))
         if 'epoch' not in loop:
             print(f'resume_from_checkpoint: {path.name} carries no loop state — weights only, starting at epoch 0')

@@ -157,6 +157,10 @@ class FEEngine:
         # pass over conv3: the statistics of the EXACT convolution (~1e-6 from those of its bf16-rounded values), -0.3 ms/step;
         # PFR_BNFREE_GRAMSTATS=0 keeps the statistics pass, whose forward is bit-identical to the stored form
         self.gram_stats = os.environ.get("PFR_BNFREE_GRAMSTATS", "1") != "0"
+        # ... unless a channel's variance comes out of a cancellation the fp32 Gram matrix cannot resolve (|mean| >> std): the kernel bounds
+        # its rounding error per channel and reports through this host-pinned word; the engine then goes back to the statistics pass
+        # (checked without a synchronisation at the start of every forward pass, so the fallback takes effect a step or two later)
+        self.gram_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.ws_main = None             # split-K workspace of weight-gradient launches on the MAIN stream (self.ws belongs to the side stream)
         self.grad_ready_hook = None     # callable(lo, hi): flat-grad range [lo, hi) is final (DDP bucket hook)
         self.hook_syncs_side = False    # True: the hook makes ITS stream wait for self.side (the main stream then never waits at a mark)
@@ -634,7 +638,7 @@ class FEEngine:
                             ops.append((lib.pfr_bn_finalize_from_gram, (gram.data_ptr(), c.w.data_ptr(), self.did, c.Cout, c.Cin, float(rows3),
                                                                         bn.gamma.data_ptr(), bn.beta.data_ptr(), float(bn.eps), float(bn.momentum),
                                                                         bn.rm.data_ptr(), bn.rv.data_ptr(), bn.coef[0].data_ptr(), bn.coef[1].data_ptr(),
-                                                                        bn.coef[2].data_ptr(), bn.coef[3].data_ptr())))
+                                                                        bn.coef[2].data_ptr(), bn.coef[3].data_ptr(), self.gram_flag.data_ptr())))
                         else:
                             self._bn_fwd(ops, bn, None, 1, rows3, train, rows3)
                     else:
@@ -899,12 +903,14 @@ class FEEngine:
                 if f["side"] is not None:
                     ops.append(("wait", (f["side"],)))                                          # G2, zsum (side stream, issued long ago)
                 part3, np3 = p3[0]
-                Wm = self.master.data_ptr() + 4 * c3.off
-                ops.append((lib.pfr_bn3_bwd_coef, (part3.data_ptr(), np3, bnf_G1.data_ptr(), f["zsum"].data_ptr(), Wm, bn3.gamma.data_ptr(),
+                # W = the bf16 weights the forward convolution multiplied with: every term that reconstructs x = z2·Wᵀ (dγ, S, the B-term of
+                # dW) must be built from the x that was actually normalised, not from the fp32 masters
+                Wm = c3.w.data_ptr()
+                ops.append((lib.pfr_bn3_bwd_coef, (part3.data_ptr(), np3, bnf_G1.data_ptr(), f["zsum"].data_ptr(), Wm, self.did, bn3.gamma.data_ptr(),
                                                    bn3.coef[1].data_ptr(), C3, K3, rows3, bn3.dgamma.data_ptr(), bn3.dbeta.data_ptr(),
                                                    bnf_coef.data_ptr(), acc)))
                 np2 = lib.pfr_conv1x1_dgrad2_bn_parts(self.did, zs[0], zs[1], zs[2], C3, K3, K3) if os.environ.get("PFR_BNFREE_2SRC", "1") != "0" else 0
-                ops.append((lib.pfr_bn3_bwd_weights, (bnf_coef.data_ptr(), bnf_G1.data_ptr(), f["G2"].data_ptr(), f["zsum"].data_ptr(), Wm,
+                ops.append((lib.pfr_bn3_bwd_weights, (bnf_coef.data_ptr(), bnf_G1.data_ptr(), f["G2"].data_ptr(), f["zsum"].data_ptr(), Wm, self.did,
                                                       C3, K3, rows3, c3.g.data_ptr(), bnf_wat.data_ptr(), 0 if np2 > 0 else bnf_S.data_ptr(),
                                                       bnf_bias.data_ptr(), acc)))
                 release(part3)
@@ -1062,7 +1068,14 @@ class FEEngine:
         blocks take the BN-input-free form).  When a pfr_set_tuning call changed a knob since the plans were built — another engine,
         a test, a host sweep — this engine's own mode is re-asserted and every plan no forward pass still owns is rebuilt."""
         ep = lib.pfr_tuning_epoch()
-        if ep == self._tuning_epoch:
+        stale = False
+        if self.gram_stats and int(self.gram_flag[0]) != 0:
+            import warnings
+            warnings.warn("pfr: bn3 statistics from the Gram matrix lost precision to cancellation (a nearly constant conv3 channel); "
+                          "falling back to the statistics pass over conv3's output for the rest of the run")
+            self.gram_stats = False
+            stale = True
+        if ep == self._tuning_epoch and not stale:
             return
         lib.pfr_set_tuning(b"bnb", self.fuse_bnb)
         self._tuning_epoch = lib.pfr_tuning_epoch()

@@ -980,7 +980,8 @@ def test_batchnorm_statistics_from_the_gram_matrix(M, K, C):
     gram = torch.empty(K * K + K, dtype=torch.float32, device=DEV)
     lib.pfr_gram_colsum(Z.data_ptr(), 1, M, K, gram.data_ptr(), ws.data_ptr(), st)
     part = torch.empty(1, 2, C, dtype=torch.float32, device=DEV)
-    lib.pfr_bn_stats_from_gram(gram.data_ptr(), W.data_ptr(), 1, C, K, float(M), part.data_ptr(), st)
+    flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+    lib.pfr_bn_stats_from_gram(gram.data_ptr(), W.data_ptr(), 1, C, K, float(M), part.data_ptr(), 1e-5, flag.data_ptr(), st)
     coef = o.bn_finalize(part, M, M, None, None, 1e-5, 0.1, None, None)
     torch.cuda.synchronize()
     x = Z.double() @ W.double().t()
@@ -995,11 +996,48 @@ def test_batchnorm_statistics_from_the_gram_matrix(M, K, C):
     two = o.bn_finalize(part, M, M, gm, bt, 1e-5, 0.1, rm1, rv1)
     one = [torch.empty(C, dtype=torch.float32, device=DEV) for _ in range(4)]
     lib.pfr_bn_finalize_from_gram(gram.data_ptr(), W.data_ptr(), 1, C, K, float(M), gm.data_ptr(), bt.data_ptr(), 1e-5, 0.1, rm2.data_ptr(),
-                                  rv2.data_ptr(), one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), one[3].data_ptr(), st)
+                                  rv2.data_ptr(), one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), one[3].data_ptr(), flag.data_ptr(), st)
     torch.cuda.synchronize()
+    assert int(flag[0]) == 0     # healthy statistics: the cancellation guard stays silent
     for a, b in zip(two, one):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)      # (shift = beta - mean * scale cancels: absolute tolerance)
     assert torch.allclose(rm1, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv1, rv2, rtol=1e-5, atol=1e-6)
+
+
+def test_gram_statistics_report_a_cancelled_variance():
+    """var_c = W_c (G2/M - zbar zbar^T) W_c^T is an E[x^2] - E[x]^2 form.  A conv3 channel that is nearly constant (|mean| >> std)
+    loses its variance to fp32 rounding; the kernel must SAY so (host-visible flag -> the engine falls back to the statistics pass), and
+    must stay silent on ordinary channels.  Here channel 0 of x is 5 + 0.03 * {0, 1} (bf16-exact), mean^2 / var ~ 1e5."""
+    from pets_face_recognition_amd._hip import lib
+    M, K, C = 50176, 64, 256
+    g = torch.Generator().manual_seed(11)
+    Z = torch.relu(torch.randn(M, K, generator=g) + 0.5)
+    Z[:, 0] = 5.0 + 0.03125 * (torch.rand(M, generator=g) < 0.5).float()
+    Z = Z.bfloat16().to(DEV)
+    W = (torch.randn(C, K, generator=g) / K ** 0.5)
+    W[0] = 0.0
+    W[0, 0] = 1.0                      # x[:, 0] = Z[:, 0]
+    W = W.bfloat16().to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.pfr_gram_ws_floats(M, K), dtype=torch.float32, device=DEV)
+    gram = torch.empty(K * K + K, dtype=torch.float32, device=DEV)
+    lib.pfr_gram_colsum(Z.data_ptr(), 1, M, K, gram.data_ptr(), ws.data_ptr(), st)
+    part = torch.empty(1, 2, C, dtype=torch.float32, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+    lib.pfr_bn_stats_from_gram(gram.data_ptr(), W.data_ptr(), 1, C, K, float(M), part.data_ptr(), 1e-5, flag.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(flag[0]) == 1
+    # the other channels are still right
+    x = Z.double() @ W.double().t()
+    var = x.var(0, unbiased=False)
+    assert ((part[0, 1, 1:].double() / M - var[1:]).abs() / var[1:]).max().item() < 1e-4
+    # the same data without the constant channel: silent
+    W2 = W.clone()
+    W2[0] = W2[1]
+    flag[0] = 0
+    lib.pfr_bn_stats_from_gram(gram.data_ptr(), W2.data_ptr(), 1, C, K, float(M), part.data_ptr(), 1e-5, flag.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(flag[0]) == 0
 
 
 W9_CASES = [
