@@ -37,11 +37,19 @@ typedef void* pfr_stream_t; /* hipStream_t */
 const char* pfr_last_error(void);
 int pfr_version(void);
 int pfr_device_arch(char* buf, int buflen);
-/* Run-time tuning knobs (the values the PFR_* environment variables set at start-up), for A/B sweeps inside one process and
- * for pinning a kernel choice: "igemm_p" 0 = one tile per workgroup only, 1 = heuristic (default), 2 = persistent kernel
- * whenever the geometry is eligible; "igemm_ptile" -1 heuristic / 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64 (rows x couts).
- * Results do not depend on the knobs (same accumulation order); statistics-partial granularity follows pfr_conv2d_mtile. */
+/* Run-time tuning knobs — ONE table (csrc/pfr_api.hip); the library itself reads NO environment variable.  For A/B sweeps inside one
+ * process and for pinning a kernel choice.  Keys (default):
+ *   "igemm_p" (1) persistent GEMM kernel 0 never / 1 heuristic / 2 whenever eligible;  "igemm_ptile" (-1) its tile 0:128x128 1:64x128
+ *   2:128x64 3:64x64 (rows x couts);  "igemm_pkch" (8) its k-step in 16-byte chunks;  "igemm_ppf" (0) its prefetch variants;
+ *   "igemm_tile" (-1) / "igemm_kch" (0) / "igemm_big" (1): tile, k-step and 8-wave tiles of the one-tile-per-workgroup kernel;
+ *   "sconv" (1) streaming 1x1 kernel 0 / 1 heuristic / 2 whenever eligible;  "sconv3" (1) halo-staged 3x3 64->64 kernel;
+ *   "bnb" (0) BatchNorm-backward sums in the data-gradient epilogue: 1 tile kernels, 2 streaming kernels (the engines set 2);
+ *   "swgrad" (1), "wgrad_big" (0), "wgrad_tile" (-1), "wgrad_splits" (0), "wgrad9" (1: the 56x56 class, 2: every geometry): weight gradients;
+ *   "attn_mfma" (1) window attention on MFMA.
+ * Results do not depend on the knobs (same accumulation order per kernel family; alternatives are pinned bit-for-bit or to the oracle by the
+ * tests); statistics-partial granularity follows pfr_conv2d_mtile.  pfr_get_tuning reads a knob back. */
 int pfr_set_tuning(const char* key, int value);
+int pfr_get_tuning(const char* key, int* value);
 /* bumped by every pfr_set_tuning call that CHANGES a knob: launch plans that baked a kernel choice in (statistics-partial granularity,
  * partial-row counts) are rebuilt by their owners when the epoch they were built under is over */
 int pfr_tuning_epoch(void);

@@ -84,6 +84,11 @@ class _Lib:
                 raise PfrError(f"libpfr_hip.so does not export {name} declared in include/pfr_hip.h") from e
             fn.restype = restype
             fn.argtypes = argtypes
+        # start-up values of the library's tuning knobs: PFR_TUNING="wgrad9=2,sconv=0" -> pfr_set_tuning (the library reads no environment)
+        for item in filter(None, (os.environ.get("PFR_TUNING") or "").replace(";", ",").split(",")):
+            k, _, v = item.partition("=")
+            if self._dll.pfr_set_tuning(k.strip().encode(), int(v)) != 0:
+                raise PfrError(f"PFR_TUNING: {self._dll.pfr_last_error().decode()}")
 
     def __getattr__(self, name):
         if name.startswith("_"):

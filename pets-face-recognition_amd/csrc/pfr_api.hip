@@ -27,3 +27,30 @@ extern "C" int pfr_device_arch(char* buf, int buflen) {
   buf[buflen - 1] = 0;
   return PFR_OK;
 }
+
+// ---- tuning knobs (pfr_common.h: PfrKnob) ----
+static const struct { const char* name; int def; } kKnobs[KNOB_COUNT] = {
+  {"igemm_p", 1}, {"igemm_ptile", -1}, {"igemm_pkch", 8}, {"igemm_ppf", 0}, {"igemm_tile", -1}, {"igemm_kch", 0}, {"igemm_big", 1},
+  {"sconv", 1}, {"sconv3", 1}, {"bnb", 0}, {"swgrad", 1}, {"wgrad_big", 0}, {"wgrad_tile", -1}, {"wgrad_splits", 0}, {"wgrad9", 1},
+  {"attn_mfma", 1},
+};
+int g_pfr_knob[KNOB_COUNT] = {1, -1, 8, 0, -1, 0, 1, 1, 1, 0, 1, 0, -1, 0, 1, 1};
+static int g_tuning_epoch = 0;
+extern "C" int pfr_tuning_epoch(void) { return g_tuning_epoch; }
+extern "C" int pfr_set_tuning(const char* key, int value) {
+  PFR_CHECK_ARG(key, "pfr_set_tuning: null key");
+  for (int k = 0; k < KNOB_COUNT; ++k)
+    if (!strcmp(kKnobs[k].name, key)) {
+      if (g_pfr_knob[k] != value) { g_pfr_knob[k] = value; ++g_tuning_epoch; }
+      return PFR_OK;
+    }
+  pfr_set_error("pfr_set_tuning: unknown key %s", key);
+  return PFR_ERR_ARG;
+}
+extern "C" int pfr_get_tuning(const char* key, int* value) {
+  PFR_CHECK_ARG(key && value, "pfr_get_tuning: null pointer");
+  for (int k = 0; k < KNOB_COUNT; ++k)
+    if (!strcmp(kKnobs[k].name, key)) { *value = g_pfr_knob[k]; return PFR_OK; }
+  pfr_set_error("pfr_get_tuning: unknown key %s", key);
+  return PFR_ERR_ARG;
+}

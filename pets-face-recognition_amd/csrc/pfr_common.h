@@ -27,6 +27,31 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 void pfr_set_error(const char* fmt, ...);
 
+// Run-time tuning knobs: ONE table (pfr_api.hip), set through pfr_set_tuning(name, value) — the library reads no environment
+// variables; a host that wants start-up values passes them through that call (the Python host maps PFR_TUNING="name=v,name=v" onto it).
+// Every CHANGE bumps pfr_tuning_epoch(): launch plans bake kernel choices in and are rebuilt by the engines when the epoch moved.
+enum PfrKnob {
+  KNOB_IGEMM_P,       // persistent GEMM kernel: 0 never, 1 heuristic (default), 2 whenever eligible
+  KNOB_IGEMM_PTILE,   // its tile: -1 heuristic, 0:128x128 1:64x128 2:128x64 3:64x64
+  KNOB_IGEMM_PKCH,    // its k-step: 8 = 128-byte rows when C allows (default), 4 = 64-byte rows
+  KNOB_IGEMM_PPF,     // its fragment-prefetch / loader-wave variants (0 default; 1-3: bit-identical alternatives kept for the A/B)
+  KNOB_IGEMM_TILE,    // tile kernel: -1 heuristic, 0..5 force a tile (tools/tile_sweep.py)
+  KNOB_IGEMM_KCH,     // tile kernel k-step: 0 heuristic, 4 / 8 forced
+  KNOB_IGEMM_BIG,     // 8-wave 256-row tiles: 1 allowed (default), 0 never
+  KNOB_SCONV,         // streaming 1x1 kernel: 0 off, 1 heuristic (default), 2 whenever eligible
+  KNOB_SCONV3,        // halo-staged 3x3 64->64 kernel: 1 on (default)
+  KNOB_BNB,           // BatchNorm-backward sums in the data-gradient epilogue: 0 off (library default), 1 tile kernels, 2 streaming kernels (what the engine sets)
+  KNOB_SWGRAD,        // streaming 1x1 weight gradient: 0 never, 1 where measured faster (default), 2 wherever the geometry allows
+  KNOB_WGRAD_BIG,     // 256x256 8-wave weight-gradient tiles: 0 off (default), 1 heuristic, 2 forced
+  KNOB_WGRAD_TILE,    // weight-gradient tile: -1 heuristic (tools/tile_sweep.py)
+  KNOB_WGRAD_SPLITS,  // force the split count of the tile weight gradient (0: model)
+  KNOB_WGRAD9,        // halo-staged 3x3 weight gradient: 0 off, 1 the 56x56 class (default), 2 every geometry
+  KNOB_ATTN_MFMA,     // window attention on MFMA for bf16 / head_dim 32: 1 (default), 0 = the register-blocked fp32-style kernels
+  KNOB_COUNT
+};
+extern int g_pfr_knob[KNOB_COUNT];
+static inline int pfr_knob(int k) { return g_pfr_knob[k]; }
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a host process that drives several GPUs must raise the
 // limit on each of them (a process-wide `static bool` set it on the first device only, and the > 64 KiB launch then failed
 // on the second).  `done` = one bit per device ordinal, set after the attribute call; two threads racing both make the (idempotent) call.

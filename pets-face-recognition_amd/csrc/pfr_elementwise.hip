@@ -188,8 +188,6 @@ struct ColGeom {
 };
 static ColGeom col_geom(int C, int kp, size_t rows, size_t target = 512) {
   ColGeom g;
-  static const int tgt_env = getenv("PFR_BN_TARGET") ? atoi(getenv("PFR_BN_TARGET")) : 0;   // experiment: workgroups per streaming launch
-  if (tgt_env > 0) target = (size_t)tgt_env;
 
   g.cpr = C / kp;
   int cw = 1;

@@ -55,25 +55,19 @@ struct IgemmParams {
 int igemm_p_launch(IgemmParams& p, int dtype, int out_dtype, int bq, int bp, hipStream_t st);
 int igemm_p_enabled();
 int igemm_p_forced_tile();
-// weight-stationary streaming kernel for HBM-bound 1x1 convolutions (pfr_sconv.hip): PFR_SCONV / pfr_set_tuning("sconv"): 0 off,
+// weight-stationary streaming kernel for HBM-bound 1x1 convolutions (pfr_sconv.hip): pfr_set_tuning("sconv"): 0 off,
 // 1 heuristic (default), 2 whenever eligible.  sconv_try_launch returns 1 when it does not take the launch; sconv_mtile the rows per
 // statistics partial of a post-op-free 1x1 launch it WOULD take (0: not its geometry) — both decide on geometry alone.
 int sconv_mode();
-void sconv_set_mode(int v);
 int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
 int sconv_mtile(int M, int N, int K, long in_rows, int dtype, int out_dtype);
 // halo-staged weight-stationary 3x3 kernel for 64 -> 64 channels (pfr_sconv3.hip); same conventions as sconv_*
 bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int dtype,
                  int out_dtype, int* bpw);
 int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
-void swgrad_set_mode(int v);   // pfr_wgrad.hip: streaming 1x1 weight gradient (0 off, 1 heuristic, 2 forced)
 int num_cus();               // pfr_igemm_p.hip: CUs of the current device (256 when it cannot be asked)
-void wgrad9_set_mode(int v);   // pfr_wgrad9.hip: halo-staged 3x3 / stride-1 weight gradient (0 off, 1 the 56x56 class, 2 every geometry)
-void wgrad_set_big(int v);   // pfr_wgrad.hip: 256x256 8-wave weight-gradient tiles (0 off, 1 heuristic, 2 forced)
 int sconv_bnb_mode();
-void sconv_set_bnb_mode(int v);
 int sconv_bnb_parts(int M, int N, int K, int dtype);
-void sconv3_set_enabled(int v);
 // parity-class mode of the persistent kernel: data gradient of a stride-2 conv (input dilation 1 << 1) over even output sizes
 static inline bool igemm_pclass_ok(const IgemmParams& p) {
   return p.idil_log2 == 1 && p.ostride == 1 && (p.OH % 2) == 0 && (p.OW % 2) == 0 && !p.stats_part;

@@ -702,10 +702,9 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
       }
     }
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
-      static const bool epre_on = !(getenv("PFR_IGEMM_EPRE") && getenv("PFR_IGEMM_EPRE")[0] == '0');
       // (measured: −10 % on the data-gradient joins of ResNet-50 = +0.5 % on the step; the GELU-backward GEMMs of Swin-T gain 4 % in
       // isolation but the step does not, and a plain forward residual add is 3 % SLOWER with it — both keep the plain kernel)
-      if (fast && epre_on && (p.res_mask || p.accumulate) && p.act != 3 && p.Cout % 8 == 0 && p.ldy % 8 == 0) {
+      if (fast && (p.res_mask || p.accumulate) && p.act != 3 && p.Cout % 8 == 0 && p.ldy % 8 == 0) {
         hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, false, true, KCH, NW, WP, NST, false, false, true>), grid, block, 0, st, p);
         PFR_CHECK_LAUNCH();
         return PFR_OK;
@@ -722,7 +721,7 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
 // (K = 64 … 256) run better with 64-byte rows and more resident workgroups.
 template <typename T, typename TO, int BQ, int BP>
 static int launch_tile(IgemmParams& p, hipStream_t st) {
-  static const int kch = getenv("PFR_IGEMM_KCH") ? atoi(getenv("PFR_IGEMM_KCH")) : 0;   // tuning: force 64-/128-byte k-steps
+  const int kch = pfr_knob(KNOB_IGEMM_KCH);   // tuning: force 64-/128-byte k-steps
   if (kch == 4) return launch_tile_k<T, TO, BQ, BP, 4, 4, 2>(p, st);
   if (kch == 8 && p.C % (8 * DT<T>::KPACK) == 0) return launch_tile_k<T, TO, BQ, BP, 8, 4, 2>(p, st);
   if (p.K >= 512 && p.C % (8 * DT<T>::KPACK) == 0) return launch_tile_k<T, TO, BQ, BP, 8, 4, 2>(p, st);
@@ -734,7 +733,7 @@ static int launch_tile(IgemmParams& p, hipStream_t st) {
 // Returns the m-tile height (also what the caller sizes stats_part with) and the variant id.
 enum { TILE_128x128, TILE_64x128, TILE_128x64, TILE_64x64, TILE_256x256, TILE_256x128 };
 static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) {
-  static const int forced = getenv("PFR_IGEMM_TILE") ? atoi(getenv("PFR_IGEMM_TILE")) : -1;   // tuning: tools/tile_sweep.py
+  const int forced = pfr_knob(KNOB_IGEMM_TILE);   // tuning: tools/tile_sweep.py
   if (forced >= 0) {
     const bool big_ok = dtype == PFR_BF16 && out_dtype == PFR_BF16 && K >= 64 && (K % 64) == 0;
     if ((forced == TILE_256x256 || forced == TILE_256x128) && !big_ok) { /* fall through to the heuristic */ }
@@ -743,8 +742,7 @@ static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) 
       return forced;
     }
   }
-  const char* force = getenv("PFR_IGEMM_BIG");
-  const bool allow_big = !(force && force[0] == '0');
+  const bool allow_big = pfr_knob(KNOB_IGEMM_BIG) != 0;
   // (8-wave tiles for K < 512 and 64-row tiles for the short-K layers were measured: no gain / slower)
   if (allow_big && dtype == PFR_BF16 && out_dtype == PFR_BF16 && K >= 512 && (K % 64) == 0) {
     const long t256 = (long)((M + 255) / 256);
@@ -1087,7 +1085,7 @@ static int launch_filter_k(IgemmParams& p, hipStream_t st) {
   p.tilesM = (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
   const int total = p.tilesM * p.tilesN;
-  static const bool persist = !(getenv("PFR_MATCH_PERSIST") && getenv("PFR_MATCH_PERSIST")[0] == '0');
+  const bool persist = true;   // (one tile per workgroup lost its A/B: profiles/r04_tile_variants.txt)
   const int slots = num_cus() * (NW == 8 ? 1 : 2);
   const dim3 grid((unsigned)(persist && total > slots ? slots : total)), block(NW * 64);
   hipLaunchKernelGGL((igemm_kernel<T, float, BQ, BP, false, true, KCH, NW, WP, 2, true>), grid, block, 0, st, p);

@@ -717,48 +717,8 @@ int num_cus() {
   return n;
 }
 
-static int g_p_mode = -1, g_p_tile = -2, g_p_kch = -1, g_p_pf = -1;
-int igemm_p_enabled() {
-  if (g_p_mode < 0) g_p_mode = getenv("PFR_IGEMM_P") ? atoi(getenv("PFR_IGEMM_P")) : 1;
-  return g_p_mode;
-}
-int igemm_p_forced_tile() {
-  if (g_p_tile < -1) g_p_tile = getenv("PFR_IGEMM_PTILE") ? atoi(getenv("PFR_IGEMM_PTILE")) : -1;
-  return g_p_tile;
-}
-// run-time tuning knobs (what the PFR_* environment variables set at start-up), for A/B sweeps inside one process:
-//   "igemm_p": 0 never / 1 heuristic / 2 whenever eligible;  "igemm_ptile": -1 heuristic, 0:128x128 1:64x128 2:128x64 3:64x64
-// every CHANGE of a knob bumps the epoch: launch plans bake kernel choices in (statistics-partial granularity, partial-row counts
-// of the fused BatchNorm sums), so the engines rebuild their plans when the epoch they were built under is over (pfr_tuning_epoch)
-static int g_tuning_epoch = 0;
-extern "C" int pfr_tuning_epoch(void) { return g_tuning_epoch; }
-static int set_tuning_impl(const char* key, int value) {
-  if (!strcmp(key, "igemm_p")) { g_p_mode = value; return PFR_OK; }
-  if (!strcmp(key, "igemm_ptile")) { g_p_tile = value; return PFR_OK; }
-  if (!strcmp(key, "igemm_pkch")) { g_p_kch = value; return PFR_OK; }
-  if (!strcmp(key, "igemm_ppf")) { g_p_pf = value; return PFR_OK; }
-  if (!strcmp(key, "sconv")) { sconv_set_mode(value); return PFR_OK; }
-  if (!strcmp(key, "sconv3")) { sconv3_set_enabled(value); return PFR_OK; }
-  if (!strcmp(key, "wgrad_big")) { wgrad_set_big(value); return PFR_OK; }
-  if (!strcmp(key, "bnb")) { sconv_set_bnb_mode(value); return PFR_OK; }
-  if (!strcmp(key, "swgrad")) { swgrad_set_mode(value); return PFR_OK; }
-  if (!strcmp(key, "wgrad9")) { wgrad9_set_mode(value); return PFR_OK; }
-  pfr_set_error("pfr_set_tuning: unknown key %s", key);
-  return PFR_ERR_ARG;
-}
-extern "C" int pfr_set_tuning(const char* key, int value) {
-  PFR_CHECK_ARG(key, "pfr_set_tuning: null key");
-  static struct { char key[16]; int value; } seen[16];
-  static int nseen = 0;
-  const int rc = set_tuning_impl(key, value);
-  if (rc != PFR_OK) return rc;
-  int i = 0;
-  for (; i < nseen; ++i)
-    if (!strcmp(seen[i].key, key)) break;
-  if (i == nseen && nseen < 16) { strncpy(seen[nseen].key, key, 15); seen[nseen].key[15] = 0; seen[nseen].value = value - 1; ++nseen; }
-  if (i < 16 && seen[i].value != value) { seen[i].value = value; ++g_tuning_epoch; }
-  return PFR_OK;
-}
+int igemm_p_enabled() { return pfr_knob(KNOB_IGEMM_P); }
+int igemm_p_forced_tile() { return pfr_knob(KNOB_IGEMM_PTILE); }
 
 template <typename T, typename TO, int BQ, int BP>
 static int launch_p(IgemmParams& p, hipStream_t st) {
@@ -775,16 +735,15 @@ static int launch_p(IgemmParams& p, hipStream_t st) {
   const int total = p.tilesM * p.tilesN;
   const int grid = total < 2 * num_cus() ? total : 2 * num_cus();
   const dim3 g((unsigned)grid), blk(256);
-  if (g_p_kch < 0) g_p_kch = getenv("PFR_IGEMM_PKCH") ? atoi(getenv("PFR_IGEMM_PKCH")) : 8;   // 128-byte k-steps when C allows
-  const bool k8 = g_p_kch == 8 && p.C % (8 * DT<T>::KPACK) == 0;
+  const bool k8 = pfr_knob(KNOB_IGEMM_PKCH) == 8   /* 128-byte k-steps when C allows */ && p.C % (8 * DT<T>::KPACK) == 0;
   if constexpr (sizeof(TO) == 2) {
     // whole tiles, no post-ops, 32-bit byte offsets: the lean epilogue
     const bool post = p.bias || p.accumulate || p.out_relu || p.residual || p.act;
     const int mrows = p.pclass ? p.mclass : p.M;
     const bool lean = !post && mrows % BQ == 0 && p.Cout % BP == 0 && (p.ldy * (int)sizeof(TO)) % 16 == 0 &&
-                      (size_t)p.M * p.ldy * sizeof(TO) < ((size_t)1 << 31) && !getenv("PFR_IGEMM_P_NOLEAN");
+                      (size_t)p.M * p.ldy * sizeof(TO) < ((size_t)1 << 31);
     if (lean) {
-      if (g_p_pf < 0) g_p_pf = getenv("PFR_IGEMM_PPF") ? atoi(getenv("PFR_IGEMM_PPF")) : 0;
+      const int g_p_pf = pfr_knob(KNOB_IGEMM_PPF);
       if (g_p_pf == 3) {
         hipLaunchKernelGGL((igemm_p_kernel<T, TO, BQ, BP, 4, 4, true, false, true>), g, dim3(320), 0, st, p, total);
       } else if (g_p_pf == 2 && p.C % (8 * DT<T>::KPACK) == 0) {

@@ -93,7 +93,6 @@ extern "C" int pfr_plan_run(void* plan, int begin, int end, pfr_stream_t main_st
   hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
   const bool use_side = ss != nullptr;
   static const int apply_thunk = pfr_plan_thunk_index("pfr_bn_bwd_apply");
-  static const bool attach_ok = !(getenv("PFR_EVENT_ATTACH") && getenv("PFR_EVENT_ATTACH")[0] == '0');
   int attached = -1;
   for (int i = begin; i < end; ++i) {
     const PlanOp& op = p->ops[i];
@@ -101,7 +100,7 @@ extern "C" int pfr_plan_run(void* plan, int begin, int end, pfr_stream_t main_st
       case 0:
       case 1: {
         // a main-stream launch directly followed by a fork: let the kernel's own completion signal be the fork event
-        if (op.kind == 0 && use_side && attach_ok && op.thunk == apply_thunk && i + 1 < end && p->ops[i + 1].kind == 2) {
+        if (op.kind == 0 && use_side && op.thunk == apply_thunk && i + 1 < end && p->ops[i + 1].kind == 2) {
           pfr_tls_stop_event = p->events[p->ops[i + 1].ev];
           attached = i + 1;
         }

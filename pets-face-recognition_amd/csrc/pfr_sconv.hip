@@ -675,15 +675,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int g_sconv_mode = -1;   // PFR_SCONV / pfr_set_tuning("sconv"): 0 off, 1 heuristic (default), 2 whenever eligible
-int sconv_mode() {
-  if (g_sconv_mode < 0) {
-    const char* e = getenv("PFR_SCONV");
-    g_sconv_mode = e ? atoi(e) : 1;
-  }
-  return g_sconv_mode;
-}
-void sconv_set_mode(int v) { g_sconv_mode = v; }
+int sconv_mode() { return pfr_knob(KNOB_SCONV); }   // pfr_set_tuning("sconv"): 0 off, 1 heuristic (default), 2 whenever eligible
 
 // panel width for (N, K): the widest of 256 / 128 / 64 couts that divides N and keeps the panel within 64 KiB
 static int sconv_panel(int N, int K, long limit = 65536) {
@@ -710,8 +702,7 @@ bool sconv_plan(int M, int N, int K, long in_rows, int dtype, int out_dtype, Sco
   // re-reading x once per panel (from L2: the panels of a row range run on one XCD) must stay cheaper than what the tile kernels do
   if (mode == 1) {
     // (measured, tools/sconv_bench.py: K = 512 with 4 panels 81 vs 94 us for the tile kernel, with 16 panels 68-72 vs 76-78)
-    static const int maxp = getenv("PFR_SCONV_MAXPANELS") ? atoi(getenv("PFR_SCONV_MAXPANELS")) : 16;
-    static const int maxk = getenv("PFR_SCONV_MAXK") ? atoi(getenv("PFR_SCONV_MAXK")) : 512;
+    constexpr int maxp = 16, maxk = 512;
     if (npanels > maxp || (!k2 && K > maxk) || (K < 512 && npanels > 8)) return false;
     if (M < 256 * 64) return false;    // too few rows per workgroup for a pipeline
   }
@@ -786,7 +777,7 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.bnx2 = p.bnb_x[1]; sp.bn_coef2 = p.bnb_coef[1]; sp.bn_part2 = p.bnb_part[1];
   sp.store_masked = bnb ? (p.bnb_flags & 1) : 0;
   sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
-  static const bool il_on = !(getenv("PFR_SCONV_INTERLEAVE") && getenv("PFR_SCONV_INTERLEAVE")[0] == '0');
+  constexpr bool il_on = true;   // block-interleaved row assignment (+5-7 %: profiles/r03_stream_probe.txt)
   sp.interleave = (il_on && p.M % 32 == 0 && (p.M / 32) % pl.nranges == 0 && (long)pl.R * pl.nranges == p.M) ? 1 : 0;
   sp.xbytes = (int)((long)p.N * p.H * p.W * p.K * 2);
   sp.div_ohow = p.div_ohow; sp.div_ow = p.div_ow;
@@ -805,14 +796,9 @@ int sconv_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   return p.stats_part ? sconv_launch_ns<4, true>(sp, pl, st) : sconv_launch_ns<4, false>(sp, pl, st);
 }
 
-// pfr_conv2d_dgrad_bn through the streaming kernel: PFR_FUSE_BNB / pfr_set_tuning("bnb"): 1 = tile kernels (round-2 form),
+// pfr_conv2d_dgrad_bn through the streaming kernel: pfr_set_tuning("bnb"): 1 = tile kernels (round-2 form),
 // 2 = streaming kernels only (geometries they do not take keep the separate pfr_bn_bwd_reduce pass)
-static int g_bnb_mode = -1;
-int sconv_bnb_mode() {
-  if (g_bnb_mode < 0) { const char* e = getenv("PFR_FUSE_BNB"); g_bnb_mode = e ? atoi(e) : 0; }
-  return g_bnb_mode;
-}
-void sconv_set_bnb_mode(int v) { g_bnb_mode = v; }
+int sconv_bnb_mode() { return pfr_knob(KNOB_BNB); }
 // partial rows (= row ranges) the streaming kernel leaves for a 1x1 data gradient + BN sums of this geometry, 0 when it does not take it
 int sconv_bnb_parts(int M, int N, int K, int dtype) {
   SconvPlan pl;
@@ -848,7 +834,7 @@ static void tail_params(SconvParams& sp, const SconvPlan& pl, const void* x, con
   sp.M = N * H * W; sp.K = C; sp.N = Cout;
   sp.H = H; sp.W = W; sp.OH = H; sp.OW = W; sp.ostride = 1;
   sp.npanels = pl.npanels; sp.nranges = pl.nranges; sp.R = pl.R; sp.npw = pl.np;
-  static const bool il_on = !(getenv("PFR_SCONV_INTERLEAVE") && getenv("PFR_SCONV_INTERLEAVE")[0] == '0');
+  constexpr bool il_on = true;   // block-interleaved row assignment (+5-7 %: profiles/r03_stream_probe.txt)
   sp.interleave = (il_on && sp.M % 32 == 0 && (sp.M / 32) % pl.nranges == 0 && (long)pl.R * pl.nranges == sp.M) ? 1 : 0;
   sp.xbytes = (int)((long)sp.M * C * 2);
   sp.div_ohow = make_fastdiv((uint32_t)(H * W)); sp.div_ow = make_fastdiv((uint32_t)W);

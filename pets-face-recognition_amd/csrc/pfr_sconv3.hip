@@ -373,12 +373,10 @@ __global__ __launch_bounds__(256, 1) void sconv3_kernel(Sconv3Params p) {
 
 // ------------------------------------------------------------------------------------------------ host side
 // geometry-only eligibility: 3x3, stride 1, pad 1, 64 -> 64 channels, bf16, W % 8 == 0, H % 4 == 0 (PFR_SCONV / "sconv" tuning: 0 off)
-static int g_sconv3_on = -1;   // PFR_SCONV3 / pfr_set_tuning("sconv3"): 0 keeps the tile kernel for the 3x3 layers
-void sconv3_set_enabled(int v) { g_sconv3_on = v; }
+// pfr_set_tuning("sconv3"): 0 keeps the tile kernel for the 3x3 layers
 bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int dtype,
                  int out_dtype, int* bpw) {
-  if (g_sconv3_on < 0) { const char* e = getenv("PFR_SCONV3"); g_sconv3_on = e ? atoi(e) : 1; }
-  if (!g_sconv3_on) return false;
+  if (!pfr_knob(KNOB_SCONV3)) return false;
   if (sconv_mode() == 0 || dtype != PFR_BF16 || out_dtype != PFR_BF16) return false;
   if (R != 3 || S != 3 || stride != 1 || pad != 1 || idil_log2 != 0 || C != 64 || Cout != 64) return false;
   if (OH != H || OW != W || (W & 7) || (H & 3) || (long)N * H * W * 128 >= ((long)1 << 31)) return false;

@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void wi
 }
 
 static bool wa_use_mfma(int dtype, int hd, int w) {
-  static const bool off = getenv("PFR_ATTN_MFMA") && getenv("PFR_ATTN_MFMA")[0] == '0';
+  const bool off = pfr_knob(KNOB_ATTN_MFMA) == 0;
   return !off && dtype == PFR_BF16 && hd == 32 && w * w <= 64;
 }
 

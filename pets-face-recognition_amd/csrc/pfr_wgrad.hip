@@ -840,13 +840,8 @@ __global__ __launch_bounds__(512, 1) void swgrad_kernel(SwgradParams p) {
   }
 }
 
-// PFR_SWGRAD / pfr_set_tuning("swgrad"): 0 never, 1 where measured faster (default), 2 wherever the geometry allows
-static int g_swgrad = -1;
-void swgrad_set_mode(int v) { g_swgrad = v; }
-static int swgrad_mode() {
-  if (g_swgrad < 0) { const char* e = getenv("PFR_SWGRAD"); g_swgrad = e ? atoi(e) : 1; }
-  return g_swgrad;
-}
+// pfr_set_tuning("swgrad"): 0 never, 1 where measured faster (default), 2 wherever the geometry allows
+static int swgrad_mode() { return pfr_knob(KNOB_SWGRAD); }
 struct SwgradPlan { int gp, gq, wp, wq, wm, tilesP, tilesQ, nsplit; };
 // geometry-only decision (pfr_conv2d_wgrad_splits sees only M, Cout, KK: a 3x3 layer with the same (Cout, KK) merely gets room
 // for this many slabs; the launcher takes the streaming kernel only for 1x1 / stride-1 bf16 launches without a fused prologue)
@@ -1097,10 +1092,7 @@ int wgrad9_launch(const void* x, const void* dy, float* slabs, int N, int H, int
                   int lddy, hipStream_t st);
 int wgrad9_max_splits(int Cout, int KK);   // (mode-independent: the slabs the kernel WOULD write when enabled)
 
-static int wgrad_v3() {
-  static const int v = getenv("PFR_WGRAD_V3") ? atoi(getenv("PFR_WGRAD_V3")) : 1;
-  return v;
-}
+static int wgrad_v3() { return 1; }   // (the round-2 kernel without the VALU-free stage loop lost its A/B: profiles/HISTORY.md)
 
 template <typename T, int BP, int BQ>
 static int launch_wgrad(WgradParams& p, hipStream_t st) {
@@ -1126,21 +1118,16 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
 static void wgrad_tiles(int Cout, int KK, int* bp, int* bq) {
   *bp = Cout >= 128 ? 128 : 64;
   *bq = KK >= 128 ? 128 : 64;
-  static const int forced = getenv("PFR_WGRAD_TILE") ? atoi(getenv("PFR_WGRAD_TILE")) : -1;   // tuning: tools/tile_sweep.py
+  const int forced = pfr_knob(KNOB_WGRAD_TILE);   // tuning: tools/tile_sweep.py
   if (forced >= 0) { *bp = (forced & 1) ? 64 : 128; *bq = (forced & 2) ? 64 : 128; }
 }
 
-// 8-wave 256x256 tiles (wgrad3_kernel<256, 256, 8, 2>; bf16, no fused prologue).  PFR_WGRAD_BIG / pfr_set_tuning("wgrad_big"):
+// 8-wave 256x256 tiles (wgrad3_kernel<256, 256, 8, 2>; bf16, no fused prologue).  pfr_set_tuning("wgrad_big"):
 // 0 never (default), 1 whole-tile geometries, 2 wherever the geometry allows.  MEASURED (tools/wgrad_bench.py,
 // profiles/r03_wgrad_tiles.txt): half the operand bytes per MFMA, yet 0.84-0.89x on most ResNet-50 / Swin-T geometries and at
 // best 1.06-1.18x on three — one 8-wave workgroup per CU behind ONE barrier per 32-row stage hides less latency than two
 // independent 4-wave workgroups; the kernel is bound by that hand-over, not by LDS or L2 bandwidth.
-static int g_wgrad_big = -1;
-void wgrad_set_big(int v) { g_wgrad_big = v; }
-static int wgrad_big_mode() {
-  if (g_wgrad_big < 0) { const char* e = getenv("PFR_WGRAD_BIG"); g_wgrad_big = e ? atoi(e) : 0; }
-  return g_wgrad_big;
-}
+static int wgrad_big_mode() { return pfr_knob(KNOB_WGRAD_BIG); }
 static bool wgrad_big_geom(int M, int Cout, int KK) {
   const int mode = wgrad_big_mode();
   if (mode == 0 || Cout < 256 || KK < 256 || Cout % 8 || KK % 8) return false;
@@ -1165,7 +1152,7 @@ static int wgrad_tile_splits(int M, int Cout, int KK) {
   const long tiles = (long)((Cout + bp - 1) / bp) * ((KK + bq - 1) / bq);
   const long maxs = (M + 255) / 256;       // at least 256 reduction rows per split
   const long slab = (long)Cout * KK * 4;
-  static const long slab_mb = getenv("PFR_WGRAD_SLAB_MB") ? atol(getenv("PFR_WGRAD_SLAB_MB")) : 48;
+  constexpr long slab_mb = 48;
   long cap = (slab_mb << 20) / slab;
   if (cap > maxs) cap = maxs;
   if (cap < 1) cap = 1;
@@ -1178,7 +1165,7 @@ static int wgrad_tile_splits(int M, int Cout, int KK) {
     const double t = t_pass * (double)(rounds * slots) / (double)w + (double)s * slab * 2.0 / 4.0e12;
     if (t < best_t * 0.999) { best_t = t; best = s; }
   }
-  static const int forced = getenv("PFR_WGRAD_FORCE_SPLITS") ? atoi(getenv("PFR_WGRAD_FORCE_SPLITS")) : 0;   // tuning sweeps
+  const int forced = pfr_knob(KNOB_WGRAD_SPLITS);   // tuning sweeps (a host that raises it re-queries pfr_conv2d_wgrad_splits: epoch)
   if (forced > 0) best = forced < maxs ? forced : maxs;
   return (int)best;
 }
@@ -1211,7 +1198,7 @@ extern "C" int pfr_conv2d_wgrad(const void* x, const void* dy, float* dw, float*
   p.splits = wgrad_tile_splits(p.M, Cout, p.KK);
   const int ws_splits = pfr_conv2d_wgrad_splits(p.M, Cout, p.KK);
   { const int ohow = OH * OW, r1 = 32 % ohow; p.adv_q1 = 32 / ohow; p.adv_q2 = r1 / OW; p.adv_r2 = r1 % OW; }
-  { const char* e = getenv("PFR_WGRAD_V2"); p.v2 = (!pro_scale && !(e && e[0] == '0')) ? 1 : 0; }
+  p.v2 = pro_scale ? 0 : 1;
   const int bmr = p.v2 ? (dtype == PFR_BF16 ? 64 : 32) : PFR_WGRAD_MUL * (dtype == PFR_BF16 ? 32 : 16);
   p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
   int mchunk = (p.M + p.splits - 1) / p.splits;

@@ -358,12 +358,7 @@ __global__ __launch_bounds__(512, 1) void wgrad9_kernel(Wg9Params p) {
 // CU for the whole launch, all of the LDS, 8 x 228 VGPRs — keep the main stream's small dependent launches waiting for a CU, and the
 // step LOSES 0.4-0.6 % with mode 2 (leaving 16-64 CUs unused gets that back, no more); at 56x56, where the tile kernel is slowest, the
 // two effects cancel (+0.1 %).  Interleaved A/B in profiles/r04_wgrad9.txt.
-static int g_wgrad9 = -1;
-void wgrad9_set_mode(int v) { g_wgrad9 = v; }
-static int wgrad9_mode() {
-  if (g_wgrad9 < 0) { const char* e = getenv("PFR_WGRAD9"); g_wgrad9 = e ? atoi(e) : 1; }
-  return g_wgrad9;
-}
+static int wgrad9_mode() { return pfr_knob(KNOB_WGRAD9); }
 
 // upper bound of the slabs a launch with this (Cout, KK) may write (the caller's workspace: pfr_conv2d_wgrad_splits)
 int wgrad9_max_splits(int Cout, int KK) {

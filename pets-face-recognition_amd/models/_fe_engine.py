@@ -119,9 +119,9 @@ class FEEngine:
         self.plans = {}
         self.side = None          # side stream of the weight-gradient launches (see build_plan)
         self.side_events = []
-        self.fold_eval = os.environ.get("PFR_FOLD_BN", "1") != "0"   # inference: BN folded into the convs
+        self.fold_eval = True     # inference: BN folded into the convs (36 k -> 56 k img/s; the unfolded eval plan stays for tests)
         self.fold_w = None
-        self.fold_cache = os.environ.get("PFR_FOLD_CACHE", "1") != "0"   # inference: re-fold only when the parameters changed
+        self.fold_cache = True    # inference: re-fold only when the parameters changed
         self.fold_state = None
         self.graph_eval = os.environ.get("PFR_GRAPH_EVAL", "0") == "1"   # opt-in: inference plans replayed as hipGraphs
         self.wt_fork = self.wt_ready = None
@@ -143,7 +143,7 @@ class FEEngine:
         self.fuse_bnb = int(os.environ.get("PFR_FUSE_BNB", "2") or 0)
         lib.pfr_set_tuning(b"bnb", self.fuse_bnb)
         self._tuning_epoch = lib.pfr_tuning_epoch()
-        self._bnb_min_rows = int(os.environ.get("PFR_BNB_MIN_ROWS", "0"))   # experiment: keep the separate pass for small tensors
+        self._bnb_min_rows = 0
         # (retired in round 4 after losing their A/B, evidence under profiles/: reduce + finalize in one launch — r03_finalize_fusion.txt;
         #  the stem's max-pool gradient gathered inside the BN-backward passes — neutral; a CU-masked side stream — r03_cumask_sweep.txt;
         #  weight gradients handed to the side stream in groups — r03_wgrad_batch.txt)
@@ -261,8 +261,7 @@ class FEEngine:
         # Used on the bf16 (throughput) path.  The fp32 (parity) path keeps the plain 7x7 form: the space-to-depth sums are
         # just as exact (tests/test_kernels_gpu.py::test_stem_space_to_depth_exact), but their different rounding order moves
         # a handful of ReLU / max-pool near-ties, which the end-to-end fp32 gradient and loss-trace tests are sensitive to.
-        want = os.environ.get("PFR_STEM_S2D", "auto")
-        if (st.R, st.S, st.stride, st.pad) == (7, 7, 2, 3) and (want == "1" or (want == "auto" and self.dtype == torch.bfloat16)):
+        if (st.R, st.S, st.stride, st.pad) == (7, 7, 2, 3) and self.dtype == torch.bfloat16:
             q = _Conv()
             q.name = st.name + "(s2d)"
             q.Cout, q.Cin, q.R, q.S, q.stride, q.pad = st.Cout, (4 * st.Cin + self.kp - 1) // self.kp * self.kp, 4, 4, 1, 2
@@ -576,8 +575,7 @@ class FEEngine:
                 continue
             if ndown is not None:
                 dc = ndown[0]
-                if (down is not None or dc.R != 1 or dc.stride != 2 or nxs[1] % 2 or nxs[2] % 2
-                        or os.environ.get("PFR_BNB_SUB", "1") == "0"):
+                if (down is not None or dc.R != 1 or dc.stride != 2 or nxs[1] % 2 or nxs[2] % 2):
                     continue
             out[k] = npart
         return out
@@ -725,7 +723,7 @@ class FEEngine:
         # ("wait", k): main waits for wgrad k (emitted before a pooled buffer it read is handed out again, before every
         # grad-ready mark and at the end).  The pool is FIFO so that a re-used buffer is the one released longest ago.
         pool = {}
-        lag = int(os.environ.get("PFR_POOL_LAG", "32"))
+        lag = 32
         pending = {}   # data_ptr -> index of the last side-stream wgrad that reads this buffer
         nside = [0]
 
@@ -909,7 +907,7 @@ class FEEngine:
                 ops.append((lib.pfr_bn3_bwd_coef, (part3.data_ptr(), np3, bnf_G1.data_ptr(), f["zsum"].data_ptr(), Wm, self.did, bn3.gamma.data_ptr(),
                                                    bn3.coef[1].data_ptr(), C3, K3, rows3, bn3.dgamma.data_ptr(), bn3.dbeta.data_ptr(),
                                                    bnf_coef.data_ptr(), acc)))
-                np2 = lib.pfr_conv1x1_dgrad2_bn_parts(self.did, zs[0], zs[1], zs[2], C3, K3, K3) if os.environ.get("PFR_BNFREE_2SRC", "1") != "0" else 0
+                np2 = lib.pfr_conv1x1_dgrad2_bn_parts(self.did, zs[0], zs[1], zs[2], C3, K3, K3)
                 ops.append((lib.pfr_bn3_bwd_weights, (bnf_coef.data_ptr(), bnf_G1.data_ptr(), f["G2"].data_ptr(), f["zsum"].data_ptr(), Wm, self.did,
                                                       C3, K3, rows3, c3.g.data_ptr(), bnf_wat.data_ptr(), 0 if np2 > 0 else bnf_S.data_ptr(),
                                                       bnf_bias.data_ptr(), acc)))
@@ -972,7 +970,7 @@ class FEEngine:
                 # (the in-place form — the shortcut writes all of dxin first, the main branch adds to it — measured slower, retired in round 4)
                 npart3 = 0
                 if (nxt is not None and self.fuse_bnb == 2 and nxt[3] is None and dc.R == 1 and dc.stride == 2
-                        and xshape[1] % 2 == 0 and xshape[2] % 2 == 0 and os.environ.get("PFR_BNB_SUB", "1") != "0"):
+                        and xshape[1] % 2 == 0 and xshape[2] % 2 == 0):
                     npart3 = dgrad_parts(dyshape, c0, xshape)
                 if npart3 > 0:
                     # the shortcut's gradient densely on its own grid (a plain GEMM), then the main branch's streaming join adds it at

@@ -44,7 +44,7 @@ class SwinEngine:
         self.plans = {}
         self.side = None          # side stream of the weight-gradient / column-sum launches (see build_plan)
         self.side_events = []
-        self.fuse_gelu = os.environ.get("PFR_FUSE_GELU", "1") != "0"
+        self.fuse_gelu = True
         self.wt_fork = self.wt_ready = None
         self.wt_pending = False
         self.hook_syncs_side = False
@@ -53,8 +53,8 @@ class SwinEngine:
         self.c_plan = os.environ.get("PFR_C_PLAN", "1") != "0"
         # buffers per (shape, dtype) class of the backward pool before one that a side-stream op still reads is re-used (HBM is
         # plentiful; a shallow pool makes the main stream wait for the side stream at almost every layer)
-        self.pool_depth = int(os.environ.get("PFR_POOL_DEPTH", "48"))
-        self.ln_dxsum = os.environ.get("PFR_LN_DXSUM", "1") == "1"   # bias gradients from the LayerNorm-backward pass that produced their input
+        self.pool_depth = 48
+        self.ln_dxsum = True   # bias gradients from the LayerNorm-backward pass that produced their input
         self.side_stream_enabled = os.environ.get("PFR_SIDE_STREAM", "1") != "0"
         self.grad_ready_hook = None
         self._adopt(model)

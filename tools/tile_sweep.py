@@ -1,6 +1,6 @@
 """Tile-choice sweep for the conv / GEMM launches of a train step.
    1. python bench.py --detail gpurun_out/detail.json ...      (lists the distinct launch geometries of a step)
-   2. python tools/tile_sweep.py gpurun_out/detail.json       (re-runs itself once per forced tile: PFR_IGEMM_TILE is read once)
+   2. python tools/tile_sweep.py gpurun_out/detail.json       (re-runs itself once per forced tile: PFR_TUNING=igemm_tile=<id>)
 Prints, per geometry, the cold time of every tile variant and of the built-in heuristic."""
 import sys, os, re, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -64,7 +64,7 @@ if __name__ == "__main__":
     for tid, name in tiles.items():
         env = dict(os.environ)
         if tid >= 0:
-            env["PFR_WGRAD_TILE" if WGRAD else "PFR_IGEMM_TILE"] = str(tid)
+            env["PFR_TUNING"] = ("wgrad_tile=" if WGRAD else "igemm_tile=") + str(tid)
         o = subprocess.run([sys.executable, __file__, sys.argv[1], "--worker"] + (["--wgrad"] if WGRAD else []), env=env,
                            capture_output=True, text=True).stdout
         line = [l for l in o.splitlines() if l.startswith("RESULT ")]
