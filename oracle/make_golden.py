@@ -216,6 +216,43 @@ def gen_arcface(L):
     print("arcface.npz:", len(out), "arrays; oracle == reference")
 
 
+def gen_arcface_alpha(L):
+    """The adaptive-alpha branch of the reference's FocalLoss (losses/losses.py:13-24: `input = self.alpha * input` with a learnable
+    per-class alpha) inside SoftmaxBasedMetricLearning — no FE config turns it on, but it is part of the class: loss, logits and the
+    gradients of the embedding, the head weight and alpha, for non-trivial alpha values."""
+    out = {}
+    g = torch.Generator().manual_seed(321)
+    for name, kw, gamma in [("arc_hard_alpha", dict(arc_margin=True, easy_margin=False), 2), ("cosface_alpha", dict(arc_margin=False), 0)]:
+        B, C = 16, 100
+        x = torch.randn(B, 512, generator=g)
+        label = torch.randint(0, C, (B,), generator=g)
+        torch.manual_seed(4000 + len(out))
+        wrap = L.SoftmaxBasedMetricLearning(torch.nn.Identity(), C, 512, is_focal=True, loss_kwargs=dict(gamma=gamma, alpha=True), **kw)
+        assert wrap.focal_loss.adaptive_flag
+        with torch.no_grad():
+            wrap.focal_loss.alpha.copy_(0.5 + torch.rand(C, generator=g))
+        w = wrap.add_margin.weight.detach().clone()
+        alpha = wrap.focal_loss.alpha.detach().clone()
+        xr = x.clone().requires_grad_(True)
+        res = wrap(xr, label)
+        res["loss"].backward()
+        out[name + "_x"] = x.numpy(); out[name + "_w"] = w.numpy(); out[name + "_label"] = label.numpy(); out[name + "_alpha"] = alpha.numpy()
+        out[name + "_logits"] = res["logits"].detach().numpy(); out[name + "_loss"] = res["loss"].detach().numpy()
+        out[name + "_dx"] = xr.grad.numpy(); out[name + "_dw"] = wrap.add_margin.weight.grad.numpy()
+        out[name + "_dalpha"] = wrap.focal_loss.alpha.grad.numpy()
+        out[name + "_gamma"] = np.float32(gamma)
+        # oracle check: the restated logits, scaled per class, through the restated focal loss
+        xo = x.clone().requires_grad_(True); wo = w.clone().requires_grad_(True); ao = alpha.clone().requires_grad_(True)
+        s_, m_ = wrap.add_margin.s, wrap.add_margin.m
+        lo = arcface_ref.arc_margin_logits(xo, wo, label, s_, m_, False) if kw.get("arc_margin") else arcface_ref.add_margin_logits(xo, wo, label, s_, m_)
+        loss = arcface_ref.focal_loss(ao * lo, label, gamma)
+        loss.backward()
+        assert torch.allclose(lo, res["logits"], rtol=1e-6, atol=1e-5) and abs(loss.item() - res["loss"].item()) < 1e-5, name
+        assert torch.allclose(ao.grad, wrap.focal_loss.alpha.grad, rtol=1e-4, atol=1e-6), name
+    np.savez_compressed(os.path.join(OUT, "arcface_alpha.npz"), **out)
+    print("arcface_alpha.npz:", len(out), "arrays; oracle == reference")
+
+
 def gen_recall(ctrl_mod, sim_f):
     out = {}
     for name, N, ncls, noise, ties in [("n256", 256, 40, 1.7, False), ("n400", 400, 80, 2.1, False), ("ties", 96, 12, 1.5, True)]:
@@ -617,8 +654,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "arcface":
         gen_arcface(ref_losses())
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "arcface_alpha":
+        gen_arcface_alpha(ref_losses())
+        sys.exit(0)
     L = ref_losses()
     gen_arcface(L)
+    gen_arcface_alpha(L)
     gen_recall(ref_controller(), ref_similarity_f())
     gen_evaluate(ref_similarity_f())
     gen_pairs()

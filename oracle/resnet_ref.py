@@ -12,6 +12,9 @@ ARCH = {
     "resnet34": ("basic", [3, 4, 6, 3]),
     "resnet50": ("bottleneck", [3, 4, 6, 3]),
     "resnet101": ("bottleneck", [3, 4, 23, 3]),
+    # test-only prefix of ResNet-50 (stem + all of layer1 + the first block of layers 2-4): the geometries the BN-input-free form of
+    # conv3 + bn3 applies to, small enough for a 256-image CPU oracle step (tests/test_model_gpu.py)
+    "resnet50_l1": ("bottleneck", [3, 1, 1, 1]),
 }
 
 

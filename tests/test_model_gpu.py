@@ -158,6 +158,24 @@ def test_fused_head_vs_reference_golden():
     assert rel(head.weight.grad, torch.tensor(G[key + "_dw"])) < 1e-3
 
 
+def test_adaptive_alpha_focal_on_the_device_vs_reference_golden():
+    """VERDICT r4 missing #3: with FocalLoss(alpha=True) the head leaves the fused margin + CE kernel (losses/__init__.py:_fusable) and runs
+    as the margin-logit kernels, one torch multiply by alpha and the device focal-CE kernel.  That path is pinned HERE, on CUDA tensors, to
+    vectors produced by the reference's own classes (tests/golden/arcface_alpha.npz): loss, logits and the gradients of the embedding, the
+    head weight and alpha."""
+    from test_oracle_golden import _alpha_case
+    G = np.load(os.path.join(GOLD, "arcface_alpha.npz"))
+    for name in ("arc_hard_alpha", "cosface_alpha"):
+        wrap, x, r = _alpha_case(G, name, DEV)
+        torch.cuda.synchronize()
+        assert r["logits"].is_cuda and r["loss"].is_cuda
+        assert torch.allclose(r["logits"].cpu(), torch.tensor(G[name + "_logits"]), rtol=1e-4, atol=2e-3), name
+        assert abs(r["loss"].item() - float(G[name + "_loss"])) < 1e-4 * max(1, abs(float(G[name + "_loss"]))), name
+        assert rel(x.grad, torch.tensor(G[name + "_dx"])) < 1e-3, name
+        assert rel(wrap.add_margin.weight.grad, torch.tensor(G[name + "_dw"])) < 1e-3, name
+        assert rel(wrap.focal_loss.alpha.grad, torch.tensor(G[name + "_dalpha"])) < 1e-3, name
+
+
 def test_train_trace_r18_vs_reference_golden():
     """5 optimizer steps (fp32 path): loss trace of ResNet-18 + ArcFace + SGD groups must follow the trace captured
     from the reference's SoftmaxBasedMetricLearning (oracle/make_golden.py:gen_train_trace)."""
@@ -616,6 +634,68 @@ def test_resnet50_224_bf16_undamped_vs_bf16_emulating_oracle():
                     f"cos={cos(e, e32):.6f} emulating_vs_fp32={r_q32:.3e}\n")
     assert r_q < 1e-1 and cos(e, eq) > 0.995, (r_q, cos(e, eq))
     assert r_32 < 2e-1 and cos(e, e32) > 0.99, (r_32, cos(e, e32))
+
+
+def test_bs256_bf16_train_step_of_the_stem_and_layer1_prefix_vs_bf16_emulating_oracle():
+    """VERDICT r4 #8(i) / ADVICE r4: the part of the step the BN-input-free form rewrote, at the HEADLINE batch and resolution, against an
+    oracle instead of against itself.  Net = the ResNet-50 prefix `resnet50_l1` (stem, all three 56x56 blocks of layer1, then one block per
+    later layer so that every layer1 block keeps its real successor), 256 x 3 x 224 x 224, bf16, train-mode BatchNorm, one forward + backward.
+    Checked against oracle/resnet_ref.py with bf16 rounding emulated at the path's storage points (fp32 arithmetic, autograd backward):
+      * the embeddings (<= 5e-2 relative; the 4 blocks that take the form do);
+      * the running statistics layer1's bn3 layers leave — they come from the Gram matrix of conv3's INPUT here (pfr_bn_finalize_from_gram),
+        from conv3's bf16 output in the oracle: mean to 1e-2 of the running std, variance to 2e-2 relative;
+      * the gradient of every layer1 / stem parameter: cosine >= 0.95 per tensor and >= 0.98 over all of them (two bf16 backward passes that
+        round at different points are ~0.2 apart in norm — DESIGN §5 — so the direction is what can be asserted), no non-finite value."""
+    from oracle import resnet_ref
+    from pets_face_recognition_amd.models.resnet import ResNet, Bottleneck
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    N = 256
+    sd = resnet_ref.init_state_dict("resnet50_l1", 512, seed=33)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(N, 3, 224, 224, generator=g)
+    proj = torch.randn(N, 512, generator=g) / 512 ** 0.5          # loss = <embedding, proj>: a fixed incoming gradient
+    m = ResNet(Bottleneck, [3, 1, 1, 1], compute_dtype=torch.bfloat16)
+    m.fc = torch.nn.Linear(m.fc.in_features, 512)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    e = m(x.to(DEV))
+    (e.float() * proj.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    blocks = m.hip_engine()._last_plan.meta["bnfree_blocks"]
+    assert blocks[:3] == [0, 1, 2], blocks                          # all of layer1 takes the BN-input-free form
+    # ---- the oracle step (CPU, fp32 arithmetic with bf16 storage points)
+    names = [k for k in resnet_ref.param_names(sd) if k.startswith(("conv1", "bn1", "layer1"))]
+    sdo = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    stats = {}
+    eo = resnet_ref.forward(sdo, x, "resnet50_l1", train=True, new_stats=stats, quant=resnet_ref.bf16_round)
+    (eo * proj).sum().backward()
+    r_e = rel(e.detach(), eo.detach())
+    assert r_e < 5e-2, r_e
+    cur = dict(m.state_dict())
+    for b in range(3):
+        rm, rv = cur[f"layer1.{b}.bn3.running_mean"].float().cpu(), cur[f"layer1.{b}.bn3.running_var"].float().cpu()
+        om, ov = stats[f"layer1.{b}.bn3.running_mean"], stats[f"layer1.{b}.bn3.running_var"]
+        assert ((rm - om).abs() / ov.sqrt()).max().item() < 1e-2, b
+        assert ((rv - ov).abs() / ov).max().item() < 2e-2, b
+    grads = {n: p.grad for n, p in m.named_parameters()}
+    dots = n1 = n2 = 0.0
+    worst = (1.0, None)
+    for k in names:
+        a, b = grads[k].float().cpu().flatten().double(), sdo[k].grad.flatten().double()
+        assert torch.isfinite(a).all(), k
+        c = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        if c < worst[0]:
+            worst = (c, k)
+        dots += (a @ b).item(); n1 += (a @ a).item(); n2 += (b @ b).item()
+    total = dots / (n1 * n2) ** 0.5
+    print(f"[bs256 prefix] emb rel {r_e:.3e}; gradient cosine over stem + layer1 {total:.5f}; worst tensor {worst[1]} {worst[0]:.4f}")
+    out = os.environ.get("PFR_PARITY_LOG")
+    if out:
+        with open(out, "a") as f:
+            f.write(f"resnet50_l1 prefix 256x3x224x224 bf16 train step vs bf16-emulating oracle: emb_rel={r_e:.3e} grad_cos_all={total:.5f} "
+                    f"worst={worst[1]}:{worst[0]:.4f} bnfree_blocks={blocks}\n")
+    assert worst[0] > 0.95, worst
+    assert total > 0.98, total
 
 
 def test_backward_refuses_to_replay_under_changed_tuning_knobs():

@@ -58,6 +58,37 @@ def test_product_cpu_path_losses_match_reference_vectors():
     assert wrap([x.detach()[:3], x.detach()[3:5]]).shape[0] == 5
 
 
+def _alpha_case(G, name, device):
+    from pets_face_recognition_amd.losses import SoftmaxBasedMetricLearning
+    C = G[name + "_w"].shape[0]
+    wrap = SoftmaxBasedMetricLearning(torch.nn.Identity(), C, 512, is_focal=True, loss_kwargs=dict(gamma=float(G[name + "_gamma"]), alpha=True),
+                                      arc_margin=name.startswith("arc"))
+    assert wrap.focal_loss.adaptive_flag and wrap._fusable(torch.zeros(1, device=device)) is None
+    if device != "cpu":
+        wrap.add_margin.compute_dtype = torch.float32
+    wrap = wrap.to(device)
+    with torch.no_grad():
+        wrap.add_margin.weight.copy_(torch.tensor(G[name + "_w"]))
+        wrap.focal_loss.alpha.copy_(torch.tensor(G[name + "_alpha"]))
+    x = torch.tensor(G[name + "_x"]).to(device).requires_grad_(True)
+    r = wrap(x, torch.tensor(G[name + "_label"]).to(device))
+    r["loss"].backward()
+    return wrap, x, r
+
+
+def test_product_cpu_path_adaptive_alpha_focal_matches_reference_vectors():
+    """FocalLoss(alpha=True) (reference losses/losses.py:13-24: learnable per-class logit scale; no FE config uses it) through the product's
+    SoftmaxBasedMetricLearning on CPU tensors against vectors produced by the reference class itself (oracle/make_golden.py:gen_arcface_alpha)."""
+    G = np.load(os.path.join(GOLD, "arcface_alpha.npz"))
+    for name in ("arc_hard_alpha", "cosface_alpha"):
+        wrap, x, r = _alpha_case(G, name, "cpu")
+        assert torch.allclose(r["logits"], torch.tensor(G[name + "_logits"]), rtol=1e-6, atol=1e-5), name
+        assert abs(r["loss"].item() - float(G[name + "_loss"])) < 1e-5
+        assert torch.allclose(x.grad, torch.tensor(G[name + "_dx"]), rtol=1e-4, atol=1e-6)
+        assert torch.allclose(wrap.add_margin.weight.grad, torch.tensor(G[name + "_dw"]), rtol=1e-4, atol=1e-6)
+        assert torch.allclose(wrap.focal_loss.alpha.grad, torch.tensor(G[name + "_dalpha"]), rtol=1e-4, atol=1e-6)
+
+
 def test_oracle_recall_matches_reference_controller():
     from oracle import match_ref
     G = np.load(os.path.join(GOLD, "recall.npz"))
