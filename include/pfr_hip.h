@@ -45,7 +45,7 @@ int pfr_device_arch(char* buf, int buflen);
  *   "sconv" (1) streaming 1x1 kernel 0 / 1 heuristic / 2 whenever eligible;  "sconv3" (1) halo-staged 3x3 64->64 kernel;
  *   "bnb" (0) BatchNorm-backward sums in the data-gradient epilogue: 1 tile kernels, 2 streaming kernels (the engines set 2);
  *   "swgrad" (1), "wgrad_big" (0), "wgrad_tile" (-1), "wgrad_splits" (0), "wgrad9" (1: the 56x56 class, 2: every geometry): weight gradients;
- *   "attn_mfma" (1) window attention on MFMA.
+ *   "attn_mfma" (1) window attention on MFMA;  "match_order" (1) L2-blocked tile order of the persistent filter GEMM of the gallery match.
  * Results do not depend on the knobs (same accumulation order per kernel family; alternatives are pinned bit-for-bit or to the oracle by the
  * tests); statistics-partial granularity follows pfr_conv2d_mtile.  pfr_get_tuning reads a knob back. */
 int pfr_set_tuning(const char* key, int value);

@@ -29,6 +29,11 @@ struct IgemmParams {
   int res_sub;                     // streaming join only: `residual` is compact [N][OH/2][OW/2][Cout], added at even (oh, ow)
   const unsigned char* res_mask;   // optional bit mask of `residual` ([M][ldy / KPACK] bytes, pfr_bn_act_mask): masked-out elements add 0
   int cap, col0, self_excl;   // act 4: list capacity, gallery index of column 0, skip column == row (all-vs-all evaluation)
+  // act 4, persistent launch: L2-blocked tile order.  fo_qg > 0: the workgroups of one XCD (block b runs on XCD b % 8 — speed only) own a
+  // contiguous range of gallery (column) tiles and walk it in super-steps of fo_qg query tiles x fo_gg gallery tiles (fo_qg * fo_gg =
+  // workgroups per XCD), query group outermost: what an XCD works on at any time is a few MB of operands that stay in its L2, instead
+  // of 256 different gallery tiles chip-wide per step (each gallery tile was then fetched from HBM / MALL once per query tile).
+  int fo_qg = 0, fo_gg = 0;
   FastDiv div_ohow, div_ow;
   int tilesM, tilesN;
   // parity-class mode (data gradient of a stride-2 conv, FAST path): output rows are processed per (oh%2, ow%2) class so

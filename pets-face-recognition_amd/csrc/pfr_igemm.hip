@@ -74,9 +74,34 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   // FILT launches are persistent (one workgroup per CU walks the tiles: a 256x256x512 match tile is 8 k-steps, and a fresh workgroup
   // per tile left a launch gap after every one of them); all other launches have one tile per workgroup and run the body once.
   const uint32_t ntile = (uint32_t)(p.tilesM * p.tilesN);
-  for (uint32_t tt = blockIdx.x; tt < ntile; tt += gridDim.x) {
-  const uint32_t t = FILT ? tt : xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = t % p.tilesN, tm = t / p.tilesN;
+  // tile of this workgroup at iteration `it` (FILT: persistent; otherwise one iteration).  -> false: past the end; tm_ < 0: an idle slot
+  // of the blocked order (ragged group), skipped
+  auto tile_at = [&](uint32_t it, int& tm_, int& tn_) -> bool {
+    if (FILT && p.fo_qg > 0) {
+      const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      const int n_lo = (int)((long)xcd * p.tilesN / 8), n_hi = (int)((long)(xcd + 1) * p.tilesN / 8);
+      const int ngg = (p.tilesN + 7) / 8 + p.fo_gg - 1;          // gallery groups per XCD, the same count on every XCD (ragged tails idle)
+      const int ng = ngg / p.fo_gg, nq = (p.tilesM + p.fo_qg - 1) / p.fo_qg;
+      if (it >= (uint32_t)(ng * nq)) return false;
+      const int q = it / ng, j = it - q * ng;
+      tm_ = q * p.fo_qg + slot / p.fo_gg;
+      tn_ = n_lo + j * p.fo_gg + slot % p.fo_gg;
+      if (tm_ >= p.tilesM || tn_ >= n_hi) tm_ = -1;
+      return true;
+    }
+    const uint32_t tt_ = blockIdx.x + it * gridDim.x;
+    if (tt_ >= ntile) return false;
+    const uint32_t t_ = FILT ? tt_ : xcd_remap(blockIdx.x, gridDim.x);
+    tn_ = t_ % p.tilesN;
+    tm_ = t_ / p.tilesN;
+    return true;
+  };
+  bool prefetched = false;   // FILT: k-step 0 of this tile went out under the previous tile's epilogue
+  for (uint32_t it = 0;; ++it) {
+  int tm, tn;
+  if (!tile_at(it, tm, tn)) break;
+  if (tm < 0) continue;
+  if (!FILT && it > 0) break;
   const int n0 = tn * BP;
   const int cls = p.pclass ? tm / p.tpc : 0;
   const int ph = cls >> 1, pw = cls & 1;
@@ -307,7 +332,8 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   const int nk = nk_all;
   const int npre = nk < NST - 1 ? nk : NST - 1;
   TSTAMP(1);
-  for (int s0 = 0; s0 < npre; ++s0) gload(s0, !(FILT && s0 == 0 && tt != blockIdx.x));   // (FILT: k-step 0 of a later tile went out under the previous tile's epilogue)
+  for (int s0 = 0; s0 < npre; ++s0) gload(s0, !(FILT && s0 == 0 && prefetched));   // (FILT: k-step 0 of a later tile went out under the previous tile's epilogue)
+  prefetched = false;
   wait_pending(npre - 1);
   if constexpr (PRO) {
     __syncthreads();  // coefficients visible
@@ -357,9 +383,10 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
     // the first k-step of this workgroup's NEXT tile goes out now, under the compare loops (every wave is past the k-loop's last
     // barrier: ring slot 0 is free); the thresholds above were requested first, so waiting for them does not wait for the DMA
     if constexpr (FAST) {
-      const uint32_t tnx = tt + gridDim.x;
-      if (tnx < ntile) {
-        const int n0n = (int)(tnx % p.tilesN) * BP, m0n = (int)(tnx / p.tilesN) * BQ;
+      int tmx, tnx;
+      if (tile_at(it + 1, tmx, tnx) && tmx >= 0) {
+        prefetched = true;
+        const int n0n = tnx * BP, m0n = tmx * BQ;
 #pragma unroll
         for (int j = 0; j < PCH; ++j) {
           const int row = n0n + (j * NW + wave) * RPI + rsub;
@@ -1088,6 +1115,15 @@ static int launch_filter_k(IgemmParams& p, hipStream_t st) {
   const bool persist = true;   // (one tile per workgroup lost its A/B: profiles/r04_tile_variants.txt)
   const int slots = num_cus() * (NW == 8 ? 1 : 2);
   const dim3 grid((unsigned)(persist && total > slots ? slots : total)), block(NW * 64);
+  p.fo_qg = p.fo_gg = 0;
+  if ((int)grid.x == slots && slots % 8 == 0 && pfr_knob(KNOB_MATCH_ORDER)) {
+    // L2-blocked order (IgemmParams::fo_qg): super-steps of qg query tiles x gg gallery tiles per XCD
+    const int wpx = slots / 8;
+    int qg = 1;
+    while (qg * 2 <= 8 && qg * 2 <= p.tilesM && wpx % (qg * 2) == 0) qg *= 2;
+    p.fo_qg = qg;
+    p.fo_gg = wpx / qg;
+  }
   hipLaunchKernelGGL((igemm_kernel<T, float, BQ, BP, false, true, KCH, NW, WP, 2, true>), grid, block, 0, st, p);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
