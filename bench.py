@@ -693,18 +693,22 @@ def main():
                 "by_entry_point_ms": {k: round(v[1] / nprof, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
     cpu = None
     extra = None
-    if dist is not None and world > 1:
+    ms_leg = None
+    if dist is not None:      # N > 1 — or the DDP path forced at one rank (PFR_FORCE_DDP=1): the same code on the 1-GPU box
         dist.barrier()
         del ml, opt, ddp
+        ml = opt = None
         torch.cuda.empty_cache()
         if not args.no_extras:
             ms_leg = match_sharded_leg(device, rank, world, dist)
-            if rank == 0:
+            if rank == 0 and world > 1:
                 extra = {"match_sharded": ms_leg}
     if rank == 0 and world == 1 and not args.no_extras and args.arch == "resnet50" and args.dtype == "bf16":
         del ml, opt
         torch.cuda.empty_cache()
         extra = extras(args, device)
+        if ms_leg is not None:
+            extra["match_sharded"] = ms_leg
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_thread_sweep(args)
         if cpu is not None and args.arch == "resnet50" and not args.no_extras:

@@ -45,6 +45,7 @@ int pfr_device_arch(char* buf, int buflen);
  *   "sconv" (1) streaming 1x1 kernel 0 / 1 heuristic / 2 whenever eligible;  "sconv3" (1) halo-staged 3x3 64->64 kernel;
  *   "bnb" (0) BatchNorm-backward sums in the data-gradient epilogue: 1 tile kernels, 2 streaming kernels (the engines set 2);
  *   "swgrad" (1), "wgrad_big" (0), "wgrad_tile" (-1), "wgrad_splits" (0), "wgrad9" (1: the 56x56 class, 2: every geometry): weight gradients;
+ *   "bnb_tile3" (0) with bnb = 2: the 3x3 / stride-1 data gradients on the 256-row tile kernel leave the BatchNorm-backward sums too;
  *   "attn_mfma" (1) window attention on MFMA;  "match_order" (1) L2-blocked tile order of the persistent filter GEMM of the gallery match.
  * Results do not depend on the knobs (same accumulation order per kernel family; alternatives are pinned bit-for-bit or to the oracle by the
  * tests); statistics-partial granularity follows pfr_conv2d_mtile.  pfr_get_tuning reads a knob back. */
@@ -357,9 +358,11 @@ int pfr_match_scores_filter(const void* q, const void* g, int dtype, int Q, int 
 int pfr_topk_merge(const void* cand, int cap, int rows, int K, void* state, pfr_stream_t stream);
 int pfr_topk_flags(const void* state, int rows, int K, int* out_host, pfr_stream_t stream);
 int pfr_topk_finish(const void* state, int rows, int K, float* out_scores, int* out_idx, pfr_stream_t stream);
-/* exact fp32 re-scoring of KC candidates per query (q, g: L2-normalised fp32 rows), keeps the best K */
-int pfr_topk_rescore(const float* q, const float* g, int rows, int D, const int* cand, int KC, int K, float* out_scores,
-                     int* out_idx, pfr_stream_t stream);
+/* exact fp32 re-scoring of KC candidates per query, keeps the best K.  q: L2-normalised fp32 rows; g: L2-normalised fp32 rows (g_scale
+ * NULL), or the RAW gallery rows with g_scale[i] = 1 / max(|g_i|, eps) (pfr_l2norm_dual's inv_norm output): the score is <q, g_i> * g_scale[i]
+ * and no normalised fp32 copy of the gallery has to exist (2 GB less written per 1 M x 512 match) */
+int pfr_topk_rescore(const float* q, const float* g, const float* g_scale, int rows, int D, const int* cand, int KC, int K,
+                     float* out_scores, int* out_idx, pfr_stream_t stream);
 /* out[p] = (cos(emb[idx_a[p]], emb[idx_b[p]]) + 1) / 2, norms clamped at eps (F.cosine_similarity) */
 int pfr_pair_similarity(const float* emb, int D, const long* idx_a, const long* idx_b, int P, float eps, float* out,
                         pfr_stream_t stream);

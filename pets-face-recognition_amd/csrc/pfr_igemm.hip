@@ -913,7 +913,18 @@ extern "C" int pfr_conv2d_dgrad_join(const void* dy, const void* wt, void* dx, i
 extern "C" int pfr_conv2d_dgrad_bn_parts(int dtype, int N, int H, int W, int C, int Cout, int R, int S, int idil_log2, int OH,
                                          int OW) {
   const int kp = dtype == PFR_BF16 ? 8 : 4;
-  if (sconv_bnb_mode() == 2) {   // streaming kernels only: 1x1 / stride 1 data gradients they take (one BN; see pfr_sconv.hip)
+  if (sconv_bnb_mode() == 2) {   // streaming kernels: 1x1 / stride 1 data gradients they take (one BN; see pfr_sconv.hip) ...
+    if (R == 3 && S == 3 && idil_log2 == 0 && OH == H && OW == W && pfr_knob(KNOB_BNB_TILE3) && dtype == PFR_BF16 && C % 64 == 0 &&
+        Cout % 64 == 0) {
+      // ... and (round 5, "bnb_tile3") the 3x3 / stride-1 data gradients on the 8-wave 256-row TILE kernel: MFMA-bound launches whose
+      // epilogue has the slack for one more row stream (the BN input of the tile's own rows), replacing a reduce pass over (g, x).
+      // Not the 64 -> 64 layers the halo-staged kernel takes (it has no such epilogue and is 1.7x the tile kernel there).
+      int bpw, bq;
+      if (sconv3_geom(N, H, W, C, Cout, R, S, 1, 1, 0, OH, OW, dtype, dtype, &bpw)) return 0;
+      const int M = N * OH * OW;
+      const int v = pick_tile(M, Cout, R * S * C, dtype, dtype, &bq);
+      return (v == TILE_256x256 || v == TILE_256x128) ? (M + bq - 1) / bq : 0;
+    }
     if (R != 1 || S != 1 || idil_log2 != 0 || OH != H || OW != W) return 0;
     return sconv_bnb_parts(N * OH * OW, Cout, C, dtype);
   }

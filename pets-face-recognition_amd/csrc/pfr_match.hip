@@ -362,7 +362,8 @@ extern "C" int pfr_topk_finish(const void* state, int rows, int K, float* out_sc
 
 // exact fp32 re-scoring of candidate lists: score = <q[r], g[idx]> on the fp32 (normalised) rows, then re-sort and keep K.
 // one workgroup per query; a wave computes one dot product at a time.
-__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q, const float* __restrict__ g, int D,
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q, const float* __restrict__ g,
+                                                      const float* __restrict__ g_scale, int D,
                                                       const int* __restrict__ cand, int KC, int K,
                                                       float* __restrict__ out_scores, int* __restrict__ out_idx) {
   __shared__ unsigned long long list[512];
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
       a = fmaf(x[0], y[0], a); a = fmaf(x[1], y[1], a); a = fmaf(x[2], y[2], a); a = fmaf(x[3], y[3], a);
     }
     a = wave_sum(a);
+    if (g_scale) a *= g_scale[gi];      // g = the RAW gallery rows, g_scale = 1 / max(|g_i|, eps): no normalised fp32 copy of the gallery
     if (lane == 0) list[c] = ((unsigned long long)fkey(a) << 32) | (uint32_t)(~(uint32_t)gi);
   }
   __syncthreads();
@@ -399,11 +401,11 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
   }
 }
 
-extern "C" int pfr_topk_rescore(const float* q, const float* g, int rows, int D, const int* cand, int KC, int K,
+extern "C" int pfr_topk_rescore(const float* q, const float* g, const float* g_scale, int rows, int D, const int* cand, int KC, int K,
                                 float* out_scores, int* out_idx, hipStream_t st) {
   PFR_CHECK_ARG(q && g && cand && out_scores && out_idx, "pfr_topk_rescore: null pointer");
   PFR_CHECK_ARG(D % 4 == 0 && KC <= 512 && K <= KC, "pfr_topk_rescore: need D %% 4 == 0, K <= KC <= 512");
-  hipLaunchKernelGGL(rescore_kernel, dim3(rows), dim3(256), 0, st, q, g, D, cand, KC, K, out_scores, out_idx);
+  hipLaunchKernelGGL(rescore_kernel, dim3(rows), dim3(256), 0, st, q, g, g_scale, D, cand, KC, K, out_scores, out_idx);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

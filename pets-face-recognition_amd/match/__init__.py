@@ -27,7 +27,7 @@ class PreparedGallery:
     gallery buffer that was refilled needs a new handle.  1 M x 512: 1 GB (bf16) + 2 GB (fp32)."""
 
     def __init__(self, gn, gn32, compute_dtype, rescore, normalized):
-        self.gn, self.gn32 = gn, gn32
+        self.gn, self.gn32, self.gscale = gn, gn32, None
         self.compute_dtype, self.rescore, self.normalized = compute_dtype, rescore, normalized
         self.shape, self.device = tuple(gn.shape), gn.device
 
@@ -35,15 +35,23 @@ class PreparedGallery:
         return self.shape[0]
 
 
-def _prep_rows(x32, T, rescore, normalize):
-    """rows of an fp32 matrix -> (GEMM operand in T, fp32 copy for the re-scoring or None)"""
+def _prep_rows(x32, T, rescore, normalize, borrow=False):
+    """rows of an fp32 matrix -> (GEMM operand in T, fp32 rows for the re-scoring or None[, their per-row scale]).
+    borrow=True (one-shot match): the re-scoring reads the caller's RAW rows times 1 / |row| instead of a normalised fp32 copy
+    (1 M x 512: 2 GB less written); -> (operand, raw rows, inverse norms)"""
     D = x32.shape[1]
     if normalize and T == torch.bfloat16 and D % 4 == 0 and D <= 2048:
-        # one pass per matrix: bf16 GEMM operand + (when re-scoring) the fp32 copy
+        # one pass per matrix: bf16 GEMM operand + (when re-scoring) the fp32 copy or the inverse norms
         xb = torch.empty(x32.shape, dtype=torch.bfloat16, device=x32.device)
+        if borrow and rescore:
+            inv = torch.empty(x32.shape[0], dtype=torch.float32, device=x32.device)
+            lib.pfr_l2norm_dual(x32.data_ptr(), xb.data_ptr(), 0, inv.data_ptr(), x32.shape[0], D, 1e-12, _stream())
+            return xb, x32, inv
         xf = torch.empty(x32.shape, dtype=torch.float32, device=x32.device) if rescore else None
         lib.pfr_l2norm_dual(x32.data_ptr(), xb.data_ptr(), 0 if xf is None else xf.data_ptr(), 0, x32.shape[0], D, 1e-12, _stream())
-        return xb, xf
+        return (xb, xf, None) if borrow else (xb, xf)
+    if borrow:
+        return _prep_rows(x32, T, rescore, normalize) + (None,)
     if normalize:
         xn, _, _ = ops.l2norm_fwd(x32, T)
         xf = ops.l2norm_fwd(x32, torch.float32)[0] if rescore else None
@@ -95,9 +103,9 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     q32 = q.float().contiguous()
     qn, qn32 = _prep_rows(q32, T, rescore, normalize)
     if prepared is not None:
-        gn, gn32 = prepared.gn, prepared.gn32
+        gn, gn32, gscale = prepared.gn, prepared.gn32, None      # (a handle owns a normalised copy: the caller may refill its buffer)
     else:
-        gn, gn32 = _prep_rows(g.float().contiguous(), T, rescore, normalize)
+        gn, gn32, gscale = _prep_rows(g.float().contiguous(), T, rescore, normalize, borrow=True)
     chunk = min(chunk, G)
     state = torch.empty(lib.pfr_topk_state_bytes(Q, kc), dtype=torch.uint8, device=q.device)
     self_idx = torch.arange(Q, dtype=torch.int32, device=q.device) if exclude_self else None
@@ -149,8 +157,8 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     if rescore:
         sc2 = torch.empty((Q, k), dtype=torch.float32, device=q.device)
         idx2 = torch.empty((Q, k), dtype=torch.int32, device=q.device)
-        lib.pfr_topk_rescore(qn32.data_ptr(), gn32.data_ptr(), Q, D, idx.data_ptr(), kc, k, sc2.data_ptr(), idx2.data_ptr(),
-                             _stream())
+        lib.pfr_topk_rescore(qn32.data_ptr(), gn32.data_ptr(), 0 if gscale is None else gscale.data_ptr(), Q, D, idx.data_ptr(), kc, k,
+                             sc2.data_ptr(), idx2.data_ptr(), _stream())
         return sc2, idx2
     return sc[:, :k].contiguous(), idx[:, :k].contiguous()
 
