@@ -1,8 +1,11 @@
 """fp32-vs-bf16 TRAINING equivalence (VERDICT r2 weak #1b): ResNet-18 + ArcFace on the separable synthetic set through
 `main.py --config`, ~300 optimizer steps in each compute dtype with identical seeds / data order; compares the loss curves and the
 final validation ROC AUC / accuracy / Recall@K the drop-in evaluation prints.  Writes profiles/<tag>_train_equiv.json.
-usage: python tools/train_equiv.py [tag] [noise] [arch] [n_train_ids] [n_val_ids] [photos] [epochs]
-  round 4: python tools/train_equiv.py r04_r50 1.0 resnet50 200 256 8 8   -> ResNet-50, 2048 validation images"""
+usage: python tools/train_equiv.py [tag] [noise] [arch] [n_train_ids] [n_val_ids] [photos] [epochs] [init_lr] [warmup_epochs] [dtypes]
+  round 4: python tools/train_equiv.py r04_r50 1.0 resnet50 200 256 8 8   -> ResNet-50, 2048 validation images
+  round 5 (VERDICT r4 #8ii: a recipe that LEARNS — lower base rate, linear warm-up over the first epochs, >= 2000 steps):
+           python tools/train_equiv.py r05_r50 1.0 resnet50 200 256 8 40 0.003 5
+  dtypes = "bf16" runs one precision only (recipe search; no comparison is written)"""
 import json, os, re, subprocess, sys, tempfile, textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,9 +16,14 @@ n_train_ids = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 n_val_ids = int(sys.argv[5]) if len(sys.argv) > 5 else 40
 photos = int(sys.argv[6]) if len(sys.argv) > 6 else 8
 epochs = int(sys.argv[7]) if len(sys.argv) > 7 else 12
+init_lr = float(sys.argv[8]) if len(sys.argv) > 8 else 0.01
+warmup = int(sys.argv[9]) if len(sys.argv) > 9 else 0
+only = sys.argv[10] if len(sys.argv) > 10 else ""
 common = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic")
 runs = {}
 for name, dt in (("f32", "torch.float32"), ("bf16", "torch.bfloat16")):
+    if only and name != only:
+        continue
     with tempfile.TemporaryDirectory() as td:
         cfg = os.path.join(td, f"equiv_{name}.py")
         open(cfg, "w").write(textwrap.dedent(f"""
@@ -24,6 +32,16 @@ for name, dt in (("f32", "torch.float32"), ("bf16", "torch.bfloat16")):
             from _common import make as _make
             _make(globals(), arch={arch!r}, n_train_ids={n_train_ids}, n_val_ids={n_val_ids}, photos={photos}, image_size=64, train_bs=32,
                   test_bs=64, device='cuda:0', n_epochs={epochs}, n_pairs=400, compute_dtype={dt}, seed=3, noise={noise})
+            init_lr = {init_lr}
+            _opt0 = optimizer
+            def optimizer(model_):
+                # the config's three parameter groups (fe_dogs_config.py:123-133) at base rate init_lr, with a linear warm-up over the first
+                # epochs in front of the reference's MultiStepLR decay (scaled to this run's length)
+                opts, scheds = _opt0(model_)       # (reads init_lr above through the live config, as main.py's lr finder would set it)
+                ms = ({int(epochs * 0.7)}, {int(epochs * 0.9)})
+                wu = {warmup}
+                f = lambda e: (min(1.0, (e + 1) / wu) if wu else 1.0) * (0.1 ** sum(e >= m for m in ms))
+                return opts, [torch.optim.lr_scheduler.LambdaLR(opts[0], f)]
         """))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", cfg], cwd=td, capture_output=True, text=True,
                            timeout=3000)
@@ -36,6 +54,11 @@ for name, dt in (("f32", "torch.float32"), ("bf16", "torch.bfloat16")):
             series.setdefault(m.group(2), []).append(float(m.group(3)))    # one value per validation epoch
         runs[name] = {"logged_losses": losses, "per_epoch": series}
 
+if only:
+    r_ = runs[only]
+    print(json.dumps({"recipe": dict(init_lr=init_lr, warmup=warmup, epochs=epochs, noise=noise), "dtype": only,
+                      "losses_every_4th": r_["logged_losses"][::4], "per_epoch_last3": {k: v[-3:] for k, v in r_["per_epoch"].items()}}))
+    raise SystemExit(0)
 a, b = runs["f32"], runs["bf16"]
 n = min(len(a["logged_losses"]), len(b["logged_losses"]))
 # the loss collapses over a few dozen steps once the classes separate (single-batch values on that cliff are chaotic in ANY
@@ -53,7 +76,7 @@ for k in sorted(set(a["per_epoch"]) & set(b["per_epoch"])):
     met_ok = met_ok and (d[-1] >= -tol[k] if k.startswith("Recall") else abs(d[-1]) <= tol[k])
 steps_per_epoch = n_train_ids * photos // 32
 out = {"workload": f"{arch} + ArcFace({n_train_ids} ids), synthetic 64x64 (pattern + noise * N(0,1)), bs 32, {epochs} epochs x {steps_per_epoch} steps, "
-                   f"FusedSGD, seed 3, main.py --config; validation on {n_val_ids * photos} images of {n_val_ids} held-out ids",
+                   f"FusedSGD (base rate {init_lr}, {warmup} warm-up epochs), seed 3, main.py --config; validation on {n_val_ids * photos} images of {n_val_ids} held-out ids",
        "steps": epochs * steps_per_epoch, "loss_f32": a["logged_losses"][:n], "loss_bf16": b["logged_losses"][:n],
        "loss_tolerance": "logged single-batch losses within 5 % over the first half of training and 20 % everywhere", "max_rel_loss_diff": round(max(rel), 4), "noise": noise, "loss_within_tolerance": bool(loss_ok),
        "validation_per_epoch": per_epoch, "metric_tolerances": tol, "within_tolerance": bool(loss_ok and met_ok)}
