@@ -44,7 +44,7 @@ int pfr_device_arch(char* buf, int buflen);
  *   "igemm_tile" (-1) / "igemm_kch" (0) / "igemm_big" (1): tile, k-step and 8-wave tiles of the one-tile-per-workgroup kernel;
  *   "sconv" (1) streaming 1x1 kernel 0 / 1 heuristic / 2 whenever eligible;  "sconv3" (1) halo-staged 3x3 64->64 kernel;
  *   "bnb" (0) BatchNorm-backward sums in the data-gradient epilogue: 1 tile kernels, 2 streaming kernels (the engines set 2);
- *   "swgrad" (1), "wgrad_big" (0), "wgrad_tile" (-1), "wgrad_splits" (0), "wgrad9" (1: the 56x56 class, 2: every geometry): weight gradients;
+ *   "swgrad" (1), "wgrad_big" (0), "wgrad_tile" (-1), "wgrad_splits" (0), "wgrad9" (1: the 56x56 class, 2: every geometry), "wgrad9_slots" (256 workgroups per launch): weight gradients;
  *   "bnb_tile3" (0) with bnb = 2: the 3x3 / stride-1 data gradients on the 256-row tile kernel leave the BatchNorm-backward sums too;
  *   "attn_mfma" (1) window attention on MFMA;  "match_order" (1) L2-blocked tile order of the persistent filter GEMM of the gallery match.
  * Results do not depend on the knobs (same accumulation order per kernel family; alternatives are pinned bit-for-bit or to the oracle by the

@@ -46,6 +46,7 @@ enum PfrKnob {
   KNOB_WGRAD_TILE,    // weight-gradient tile: -1 heuristic (tools/tile_sweep.py)
   KNOB_WGRAD_SPLITS,  // force the split count of the tile weight gradient (0: model)
   KNOB_WGRAD9,        // halo-staged 3x3 weight gradient: 0 off, 1 the 56x56 class (default), 2 every geometry
+  KNOB_WGRAD9_SLOTS,  // workgroups of a halo-staged weight-gradient launch (256 = one per CU; fewer leaves CUs to the main stream)
   KNOB_ATTN_MFMA,     // window attention on MFMA for bf16 / head_dim 32: 1 (default), 0 = the register-blocked fp32-style kernels
   KNOB_BNB_TILE3,     // with bnb = 2: the 3x3 / stride-1 data gradients on the 256-row tile kernel leave the BatchNorm-backward sums too
   KNOB_MATCH_ORDER,   // persistent filter GEMM of the gallery match: 1 = L2-blocked tile order per XCD (default), 0 = linear order
