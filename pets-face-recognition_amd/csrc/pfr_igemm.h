@@ -70,6 +70,8 @@ int sconv_mtile(int M, int N, int K, long in_rows, int dtype, int out_dtype);
 bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int dtype,
                  int out_dtype, int* bpw);
 int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
+// streaming Linear kernel for K = 96 * j (pfr_slin.hip): returns 1 when it does not take the launch
+int slin_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
 int num_cus();               // pfr_igemm_p.hip: CUs of the current device (256 when it cannot be asked)
 int sconv_bnb_mode();
 int sconv_bnb_parts(int M, int N, int K, int dtype);

@@ -814,6 +814,10 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
   // granularity is what pfr_gemm_act_mtile reports (the alternative kernels decide on flags pfr_conv2d_mtile cannot see).
   const bool stats_postop = p.stats_part && (p.bias || p.act || p.accumulate || p.residual || p.out_relu);
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+    {
+      const int rc = slin_try_launch(p, dtype, out_dtype, st);
+      if (rc != 1) return rc;
+    }
     if (!stats_postop) {
       int rc = sconv3_try_launch(p, dtype, out_dtype, st);
       if (rc != 1) return rc;

@@ -272,3 +272,55 @@ def test_swin_backward_under_the_persistent_gemm_and_plan_invalidation():
         assert torch.equal(g0, g1)
     finally:
         lib.pfr_set_tuning(b"igemm_p", 1)
+
+
+SLIN_CASES = [
+    # rows, K, N, bias, residual: Swin stage-1 / stage-2 Linear shapes (scaled rows), ragged row counts, every panel width (64 / 96 / 192)
+    (8192, 96, 96, True, True), (8192 + 17, 96, 288, True, False), (6000, 288, 96, False, False), (8192, 96, 384, True, False),
+    (5000, 384, 96, True, True), (4096 + 5, 192, 192, True, True), (4100, 192, 576, True, False), (4096, 576, 192, False, False),
+    (4096, 192, 768, True, False), (4097, 768, 192, True, True), (4096, 384, 384, True, True), (31 * 133, 96, 64, True, False),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K,N,has_bias,has_res", SLIN_CASES)
+def test_streaming_linear_kernel_bit_identical(rows, K, N, has_bias, has_res):
+    """csrc/pfr_slin.hip (round 5): the weight-stationary streaming Linear kernel for K = 96 j must give the tile kernel's bits — same k
+    order inside and across the MFMAs, same epilogue arithmetic (round to bf16, add residual and bias in fp32, round) — for the plain,
+    bias, residual forms, the fused GELU (act 2: pre-activation AND activation) and GELU backward (act 3) of pfr_gemm_act."""
+    from pets_face_recognition_amd._hip import lib, ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = torch.randn(rows, 1, 1, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, 1, 1, K, generator=g) / K ** 0.5).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV) if has_bias else None
+    res = torch.randn(rows, 1, 1, N, generator=g).bfloat16().to(DEV) if has_res else None
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    try:
+        for mode in (0, 2):
+            lib.pfr_set_tuning(b"slin", mode)
+            y, _ = ops.conv2d_fwd(x, w, bias=bias, residual=res)
+            r = [y.clone()]
+            if not has_res:
+                # fused GELU forward: y2 = pre-activation, y = gelu(y2); then GELU backward on a data gradient of the same shape
+                bz = bias if bias is not None else torch.zeros(N, device=DEV)
+                h1 = torch.empty(rows, N, dtype=torch.bfloat16, device=DEV)
+                h2 = torch.empty(rows, N, dtype=torch.bfloat16, device=DEV)
+                lib.pfr_gemm_act(x.data_ptr(), w.data_ptr(), h2.data_ptr(), 1, rows, K, N, bz.data_ptr(), 2, h1.data_ptr(), st)
+                dz = torch.empty(rows, N, dtype=torch.bfloat16, device=DEV)
+                lib.pfr_gemm_act(x.data_ptr(), w.data_ptr(), dz.data_ptr(), 1, rows, K, N, 0, 3, h1.data_ptr(), st)
+                r += [h1, h2, dz]
+            torch.cuda.synchronize()
+            out[mode] = r
+    finally:
+        lib.pfr_set_tuning(b"slin", 1)
+    for a, b_ in zip(out[0], out[2]):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, b_)
+    # and against fp32 torch (the tile kernel is pinned to it elsewhere; this guards the test itself against comparing two no-ops)
+    ref = x.view(rows, K).float() @ w.view(N, K).float().t()
+    if res is not None:
+        ref = ref + res.view(rows, N).float()
+    if bias is not None:
+        ref = ref + bias
+    assert rel(out[2][0].view(rows, N), ref) < 1e-2
