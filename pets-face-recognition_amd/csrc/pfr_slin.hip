@@ -73,35 +73,9 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
   const int pn = q8 % p.npanels, r = (q8 / p.npanels) * 8 + xcd;
   const int n0 = pn * NP;
 
-  // ---- weight panel -> LDS (once); rows past N are zero.  Four unconditional loads in flight per thread.
-  {
-    const int cpr = K >> 3;                    // 16-byte pieces per weight row
-    const int total = NP * cpr;
-    for (int i0 = tid; i0 < total; i0 += 4 * NTHR) {
-      u32x4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * NTHR < total ? i0 + u * NTHR : total - 1;
-        const int n = i / cpr, c16 = i - n * cpr;
-        const int nn = n0 + n < p.N ? n0 + n : p.N - 1;
-        v[u] = *reinterpret_cast<const u32x4*>(p.w + (size_t)nn * K + c16 * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * NTHR;
-        if (i < total) {
-          const int n = i / cpr, c16 = i - n * cpr;
-          *reinterpret_cast<u32x4*>(smem + n * WSTR + c16 * 16) = n0 + n < p.N ? v[u] : (u32x4){0u, 0u, 0u, 0u};
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (r >= p.nranges) return;
 
   const int bstride = p.nranges * NW;
   int blk = r * NW + wave;
-  if (blk >= p.nblk) return;
   const int frow = lane & 31, fhalf = lane >> 5;
   const char* const wl = smem + frow * WSTR + fhalf * 16;      // this lane's weight-fragment base (tile t adds t*32*WSTR)
   const char* const xl = xw + frow * XSTR + fhalf * 16;        // this lane's x-fragment base inside a chunk buffer
@@ -273,8 +247,36 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
     return nxt < p.nblk ? nxt : -1;
   };
   u32x4 RS0[NR], RS1[NR];
+  const bool idle = r >= p.nranges || blk >= p.nblk;     // (a workgroup / wave without rows still helps to copy the panel)
+  if (idle) blk = 0;
+  // the first block's operands are requested BEFORE the weight panel is copied: their round trip runs under the copy and its barrier
   rload(RS0, blk);
   gload(blk, 0);
+  // ---- weight panel -> LDS (once); rows past N are zero.  Four unconditional loads in flight per thread.
+  {
+    const int cpr = K >> 3;                    // 16-byte pieces per weight row
+    const int total = NP * cpr;
+    for (int i0 = tid; i0 < total; i0 += 4 * NTHR) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NTHR < total ? i0 + u * NTHR : total - 1;
+        const int n = i / cpr, c16 = i - n * cpr;
+        const int nn = n0 + n < p.N ? n0 + n : p.N - 1;
+        v[u] = *reinterpret_cast<const u32x4*>(p.w + (size_t)nn * K + c16 * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NTHR;
+        if (i < total) {
+          const int n = i / cpr, c16 = i - n * cpr;
+          *reinterpret_cast<u32x4*>(smem + n * WSTR + c16 * 16) = n0 + n < p.N ? v[u] : (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (idle) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
   blk = block(blk, RS0, RS1, true);
   while (blk >= 0) {
     blk = block(blk, RS1, RS0, false);
@@ -312,15 +314,16 @@ int slin_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   constexpr int XBUF = 32 * 208;                   // a wave's chunk buffer
   const int force = pfr_knob(KNOB_SLIN_NP);        // experiments: force the panel width (0: the widest that fits)
   int np = 0;
-  for (int c : {192, 96, 64}) {
-    if (force && c != force) continue;
+  // (warm, back-to-back, tools/slin_np.py: the 96-cout panel with 8 waves beats the 192-cout panel with 4 on every shape — 41 -> 28 us at
+  //  192 -> 192, 113 -> 101 us at 96 -> 384 — although x is then read once per panel from L2; N = 192 runs best as three 64-cout panels)
+  for (int c : {96, 64, 192}) {
+    if (force ? c != force : (c == 192 || (c == 96 && N == 192))) continue;
     if (N % c == 0 && ((c * (K * 2 + 16) + 127) & ~127) + (c == 192 ? 4 : 8) * XBUF <= 160 * 1024) { np = c; break; }
   }
   if (!np) return 1;
   // Measured inside the Swin-T step (warm operands, tools/swin_ab.sh + bench.py --detail, profiles/r05_slin.txt): the 8-wave forms
-  // (64- / 96-cout panels) without an activation win 15-25 % over the tile kernel; the 4-wave 192-cout-panel form and the fused-GELU
-  // forms (their epilogue is vector-ALU work the tile kernel spreads over twice the waves) lose 10-30 %.  Mode 1 takes the former only.
-  if (mode == 1 && (np == 192 || p.act != 0)) return 1;
+  // (64- / 96-cout panels) win 15-25 % over the tile kernel; the 4-wave 192-cout-panel form loses 10-30 % and is kept for experiments only.
+  if (mode == 1 && p.act != 0 && K != 96) return 1;      // (fused GELU at K = 192: 133 vs 130 us for the tile kernel; at K = 96: 183 vs 222)
   const int nw = np == 192 ? 4 : 8;
   const int lds = ((np * (K * 2 + 16) + 127) & ~127) + nw * XBUF;
   const int npanels = N / np;
