@@ -412,6 +412,13 @@ int pfr_gemm_act(const void* x, const void* w, void* y, int dtype, long M, int K
  * dtype, dtype, 0)): a bias gradient (column sum of y) without another pass over y (pfr_colsum_final_batch, mt > 0) */
 int pfr_gemm_act_colstats(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
                           void* y2, float* stats_part, pfr_stream_t stream);
+/* act 3 (y = (x wT) * gelu'(y2), no bias) + plain column SUMS of the stored y: sums_part [parts][N] fp32 with parts =
+ * pfr_gemm_act_colsum_parts(M, K, N, dtype); every partial row holds the column sums over a disjoint set of rows (their total = the bias
+ * gradient of the Linear layer in front: pfr_colsum_final_batch with mt = 0).  Provided by the streaming Linear kernel (csrc/pfr_slin.hip)
+ * for its geometries only: parts == 0 -> pfr_gemm_act_colstats.  The answer depends on the "slin" knobs (pfr_tuning_epoch). */
+int pfr_gemm_act_colsum_parts(long M, int K, int N, int dtype);
+int pfr_gemm_act_colsums(const void* x, const void* w, void* y, int dtype, long M, int K, int N, void* y2, float* sums_part,
+                         pfr_stream_t stream);
 
 /* ---- gradient all-reduce over RCCL / xGMI (csrc/pfr_comm.hip) ---------------------------------------------
  * For hosts that bind this library directly; replaces DistributedDataParallel's bucket all-reduce (utils/__init__.py:114-119).

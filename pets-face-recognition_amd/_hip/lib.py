@@ -120,7 +120,7 @@ class _Lib:
 
 
 # queries that return a value rather than an error code
-_NO_CHECK = {"pfr_version", "pfr_conv1x1_dgrad2_bn_parts", "pfr_tuning_epoch", "pfr_gram_ws_floats", "pfr_conv1x1_tail_mtile", "pfr_bn_stats_rows_per_part", "pfr_bn_finalize_ws_floats", "pfr_topk_state_bytes", "pfr_layernorm_bwd_blocks", "pfr_window_bias_table_floats", "pfr_colsum_ws_floats", "pfr_conv2d_mtile", "pfr_gemm_act_mtile", "pfr_conv2d_dgrad_bn_parts", "pfr_plan_thunk_index", "pfr_plan_size", "pfr_plan_run", "pfr_conv2d_wgrad_splits", "pfr_colreduce_blocks", "pfr_match_ws_bytes", "pfr_pair_curve_ws_bytes", "pfr_augment_ws_bytes", "pfr_colsum_parts", "pfr_layernorm_bwd_dxsum_ok"}
+_NO_CHECK = {"pfr_version", "pfr_conv1x1_dgrad2_bn_parts", "pfr_tuning_epoch", "pfr_gram_ws_floats", "pfr_conv1x1_tail_mtile", "pfr_bn_stats_rows_per_part", "pfr_bn_finalize_ws_floats", "pfr_topk_state_bytes", "pfr_layernorm_bwd_blocks", "pfr_window_bias_table_floats", "pfr_colsum_ws_floats", "pfr_conv2d_mtile", "pfr_gemm_act_mtile", "pfr_conv2d_dgrad_bn_parts", "pfr_plan_thunk_index", "pfr_plan_size", "pfr_plan_run", "pfr_conv2d_wgrad_splits", "pfr_colreduce_blocks", "pfr_match_ws_bytes", "pfr_pair_curve_ws_bytes", "pfr_augment_ws_bytes", "pfr_colsum_parts", "pfr_layernorm_bwd_dxsum_ok", "pfr_gemm_act_colsum_parts"}
 
 lib = _Lib()
 

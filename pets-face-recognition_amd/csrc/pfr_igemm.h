@@ -72,6 +72,8 @@ bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride,
 int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
 // streaming Linear kernel for K = 96 * j (pfr_slin.hip): returns 1 when it does not take the launch
 int slin_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
+int slin_colsum_parts(IgemmParams& p, int dtype);
+int slin_colsum_launch(IgemmParams& p, int dtype, float* colsum, hipStream_t st);
 int num_cus();               // pfr_igemm_p.hip: CUs of the current device (256 when it cannot be asked)
 int sconv_bnb_mode();
 int sconv_bnb_parts(int M, int N, int K, int dtype);

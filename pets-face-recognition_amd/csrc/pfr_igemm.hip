@@ -1087,6 +1087,39 @@ extern "C" int pfr_gemm_act_colstats(const void* x, const void* w, void* y, int 
   PFR_CHECK_ARG(stats_part, "pfr_gemm_act_colstats: null stats_part");
   return gemm_act_impl(x, w, y, dtype, M, K, N, bias, act, y2, stats_part, stream);
 }
+// GELU backward on a data gradient (act 3) + plain column SUMS of the stored output for the bias gradient of the layer in front (replaces
+// the fc1.bias gradient of the reference's FeedForward, models/swin.py:39-52, without a pass over the widest gradient tensor): sums_part
+// [parts][N] fp32, parts = pfr_gemm_act_colsum_parts(M, K, N, dtype); each partial row = column sums over a disjoint set of rows
+// (pfr_colsum_final_batch with mt = 0 adds them up).  Provided by the streaming Linear kernel only: parts == 0 -> use pfr_gemm_act_colstats.
+static void gemm_act_params(IgemmParams& p, const void* x, const void* w, void* y, long M, int K, int N, const float* bias, int act, void* y2) {
+  p.x = x; p.w = w; p.y = y;
+  p.N = (int)M; p.H = 1; p.W = 1; p.C = K;
+  p.R = 1; p.S = 1; p.OH = 1; p.OW = 1; p.ostride = 1; p.pad = 0; p.idil_log2 = 0;
+  p.Cout = N; p.ldy = N;
+  p.M = (int)M; p.K = K;
+  p.stats_part = nullptr; p.bias = bias; p.residual = nullptr; p.accumulate = 0; p.out_relu = 0;
+  p.pro_scale = nullptr; p.pro_shift = nullptr; p.pro_relu = 0;
+  p.act = act; p.y2 = y2; p.ccnt = nullptr; p.cap = 0; p.col0 = 0; p.self_excl = 0; p.res_mask = nullptr; p.res_sub = 0;
+  p.bnb_mask = nullptr;
+  for (int q = 0; q < 2; ++q) { p.bnb_x[q] = nullptr; p.bnb_coef[q] = nullptr; p.bnb_part[q] = nullptr; }
+}
+extern "C" int pfr_gemm_act_colsum_parts(long M, int K, int N, int dtype) {
+  if (dtype != PFR_BF16 || M <= 0 || M >= (1L << 31) || K % 8 || N % 8) return 0;
+  IgemmParams p;
+  int dummy = 0;
+  gemm_act_params(p, &dummy, &dummy, &dummy, M, K, N, nullptr, 3, &dummy);
+  return slin_colsum_parts(p, dtype);
+}
+extern "C" int pfr_gemm_act_colsums(const void* x, const void* w, void* y, int dtype, long M, int K, int N, void* y2, float* sums_part,
+                                    hipStream_t stream) {
+  PFR_CHECK_ARG(x && w && y && y2 && sums_part, "pfr_gemm_act_colsums: null pointer");
+  PFR_CHECK_ARG(pfr_gemm_act_colsum_parts(M, K, N, dtype) > 0, "pfr_gemm_act_colsums: geometry not taken (pfr_gemm_act_colsum_parts == 0): use pfr_gemm_act_colstats");
+  IgemmParams p;
+  gemm_act_params(p, x, w, y, M, K, N, nullptr, 3, y2);
+  const int rc = slin_colsum_launch(p, dtype, sums_part, stream);
+  if (rc == 1) { pfr_set_error("pfr_gemm_act_colsums: the streaming kernel did not take the launch"); return PFR_ERR_UNSUPPORTED; }
+  return rc;
+}
 static int gemm_act_impl(const void* x, const void* w, void* y, int dtype, long M, int K, int N, const float* bias, int act,
                          void* y2, float* stats_part, hipStream_t stream) {
   PFR_CHECK_ARG(x && w && y && y2, "pfr_gemm_act: null pointer");

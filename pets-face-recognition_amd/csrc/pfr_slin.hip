@@ -32,6 +32,7 @@ struct SlinParams {
   const bf16_t* res;      // [M][N] or nullptr
   bf16_t* y2;             // act 2: pre-activation out; act 3: pre-activation in
   int act;                // 0 | 2 | 3 (IgemmParams::act)
+  float* colsum;          // GELU backward only: [nranges][N] column sums of the stored y over each range's rows (pfr_gemm_act_colsums), or nullptr
   int npanels, nranges, nblk;
   int dbg;                // timing experiments (pfr_set_tuning("slin_dbg")): 1 no output stores, 2 no x loads after the first, 4 no MFMAs, 8 plain stores without the EXP_CNT wait
 };
@@ -100,6 +101,12 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
       for (int e = 0; e < 4; ++e) { bia[q][e] = b0[e]; bia[q][4 + e] = b1[e]; }
     }
   }
+  // column sums of the stored output (pfr_gemm_act_colsums): per lane, the 8 couts of each of its cout-piece patterns
+  float cs[NBP][8];
+#pragma unroll
+  for (int q = 0; q < NBP; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[q][e] = 0.f;
   // chunk c of block bk -> registers.  UNCONDITIONAL loads from clamped rows and nothing that reads the registers before the LDS write
   // of the next iteration: rows past M compute garbage that is never stored.
   u32x4 R[6];
@@ -239,6 +246,11 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
 #pragma unroll
           for (int e = 0; e < 8; ++e) { float cdf, pdf; gelu_cdf_pdf(z[e], cdf, pdf); f[e] *= cdf + z[e] * pdf; }
           v = Chunk<bf16_t>::pack(f);
+          if (p.colsum) {          // (sums see the value as stored; rows past M and couts past N add nothing)
+            Chunk<bf16_t>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[h * NBQ + q % NBQ][e] += ok ? f[e] : 0.f;
+          }
         }
         if (p.dbg & 8) __builtin_amdgcn_raw_buffer_store_b128(v, yrsrc, (int)off, 0, 0);
         else if (!(p.dbg & 1)) buffer_store_b128_sync(v, yrsrc, off, 0);
@@ -276,18 +288,63 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
     }
   }
   __syncthreads();
-  if (idle) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-  blk = block(blk, RS0, RS1, true);
-  while (blk >= 0) {
-    blk = block(blk, RS1, RS0, false);
-    if (blk < 0) break;
-    blk = block(blk, RS0, RS1, false);
+  if (idle) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (EP != SLIN_GELU_BWD || !p.colsum || r >= p.nranges) return;     // (a rowless wave of a working range still joins the column sums)
+  } else {
+    blk = block(blk, RS0, RS1, true);
+    while (blk >= 0) {
+      blk = block(blk, RS1, RS0, false);
+      if (blk < 0) break;
+      blk = block(blk, RS0, RS1, false);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (EP == SLIN_GELU_BWD) {
+    if (p.colsum) {
+      // lanes -> columns inside the wave (scratch: the wave's LDS tile), waves -> workgroup, one partial row per range: fixed order, no atomics
+      float* const scr = reinterpret_cast<float*>(xw);             // [64 lanes][8]
+      float* const tab = reinterpret_cast<float*>(xw + 2048);      // [NP] column sums of this wave
+      for (int i = lane; i < NP; i += 64) tab[i] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NBP; ++q) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) scr[lane * 8 + e] = cs[q][e];
+        // cout piece of lane l under pattern q: (q / NBQ) * CPH + ((q % NBQ) * 64 + l) % CPH; lane j < CPH gathers piece j of this half
+        if (lane < CPH) {
+          const int first = ((lane - (q % NBQ) * 64) % CPH + CPH) % CPH;      // smallest lane holding piece `lane`
+          float a[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = 0.f;
+          for (int l = first; l < 64; l += CPH)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += scr[l * 8 + e];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tab[((q / NBQ) * CPH + lane) * 8 + e] += a[e];
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < NP; i += NTHR) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += reinterpret_cast<const float*>(smem + wbytes + w * XBUF + 2048)[i];
+        if (n0 + i < p.N) p.colsum[(size_t)r * p.N + n0 + i] = a;
+      }
+    }
+  }
 }
 
 // "slin" knob: 0 off, 1 where the geometry is HBM-bound (M >= 65536 rows: Swin stages 1-2 at batch 128), 2 whenever eligible
-int slin_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
+static int slin_launch(IgemmParams& p, int dtype, int out_dtype, float* colsum, int* parts_only, hipStream_t st);
+int slin_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) { return slin_launch(p, dtype, out_dtype, nullptr, nullptr, st); }
+// pfr_gemm_act_colsums: GELU backward + column sums of the stored output, one partial row per row range (0 partial rows: not this kernel's launch)
+int slin_colsum_parts(IgemmParams& p, int dtype) {
+  int parts = 0;
+  return slin_launch(p, dtype, dtype, nullptr, &parts, nullptr) == PFR_OK ? parts : 0;
+}
+int slin_colsum_launch(IgemmParams& p, int dtype, float* colsum, hipStream_t st) { return slin_launch(p, dtype, dtype, colsum, nullptr, st); }
+// parts_only != nullptr: no launch, *parts_only = the row ranges (= column-sum partial rows) the launch would have
+static int slin_launch(IgemmParams& p, int dtype, int out_dtype, float* colsum, int* parts_only, hipStream_t st) {
   const int mode = pfr_knob(KNOB_SLIN);
   if (!mode || dtype != PFR_BF16 || out_dtype != PFR_BF16) return 1;
   if (p.R != 1 || p.S != 1 || p.pad != 0 || p.idil_log2 != 0 || p.ostride != 1 || p.ldy != p.Cout) return 1;
@@ -337,6 +394,9 @@ int slin_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st) {
   sp.nblk = (M + 31) / 32;
   if (nranges * nw > sp.nblk) nranges = ((sp.nblk + nw - 1) / nw + 7) / 8 * 8;
   sp.npanels = npanels; sp.nranges = nranges; sp.dbg = pfr_knob(KNOB_SLIN_DBG);
+  sp.colsum = colsum;
+  if (parts_only) { *parts_only = nranges; return PFR_OK; }
+  if (colsum && ep != SLIN_GELU_BWD) return 1;
   const dim3 grid((unsigned)(npanels * nranges)), block((unsigned)(nw * 64));
 #define PFR_SLIN_GO(NTV, EPV)                                                              \
   do {                                                                                     \

@@ -422,12 +422,19 @@ class SwinEngine:
                 if self.fuse_gelu:   # dh1 = (dz·W2) ∘ gelu'(h1) in the data-gradient GEMM's epilogue
                     # ... which also leaves the per-m-tile column means of dh1: fc1's bias gradient = sum_t rows_t * mean_t, merged
                     # with the other deferred column sums -- no second pass over the widest gradient tensor of the block
-                    mt = lib.pfr_gemm_act_mtile(rows, C, 4 * C, did)
-                    nt = (rows + mt - 1) // mt
-                    stp = A((nt, 2, 4 * C), torch.float32)
-                    bwd.append((lib.pfr_gemm_act_colstats, (dz.data_ptr(), b["fc2"].wt.data_ptr(), dh2.data_ptr(), did, rows, C, 4 * C, 0,
-                                                            3, sv["h1"].data_ptr(), stp.data_ptr())))
-                    pend_cs.append((stp, b["fc1"].dbias, nt, 4 * C, mt, rows))
+                    nsum = lib.pfr_gemm_act_colsum_parts(rows, C, 4 * C, did)
+                    if nsum > 0:     # streaming Linear kernel (csrc/pfr_slin.hip): plain column sums per row range
+                        stp = A((nsum, 4 * C), torch.float32)
+                        bwd.append((lib.pfr_gemm_act_colsums, (dz.data_ptr(), b["fc2"].wt.data_ptr(), dh2.data_ptr(), did, rows, C, 4 * C,
+                                                               sv["h1"].data_ptr(), stp.data_ptr())))
+                        pend_cs.append((stp, b["fc1"].dbias, nsum, 4 * C, 0, 0))
+                    else:
+                        mt = lib.pfr_gemm_act_mtile(rows, C, 4 * C, did)
+                        nt = (rows + mt - 1) // mt
+                        stp = A((nt, 2, 4 * C), torch.float32)
+                        bwd.append((lib.pfr_gemm_act_colstats, (dz.data_ptr(), b["fc2"].wt.data_ptr(), dh2.data_ptr(), did, rows, C, 4 * C, 0,
+                                                                3, sv["h1"].data_ptr(), stp.data_ptr())))
+                        pend_cs.append((stp, b["fc1"].dbias, nt, 4 * C, mt, rows))
                 else:
                     dgrad_lin(bwd, dz, rows, b["fc2"], dh2)
                     bwd.append((lib.pfr_gelu_bwd, (sv["h1"].data_ptr(), dh2.data_ptr(), dh2.data_ptr(), did, rows * 4 * C)))

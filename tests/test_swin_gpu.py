@@ -324,3 +324,44 @@ def test_streaming_linear_kernel_bit_identical(rows, K, N, has_bias, has_res):
     if bias is not None:
         ref = ref + bias
     assert rel(out[2][0].view(rows, N), ref) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K,N", [(8192 + 9, 96, 384), (4096, 96, 96), (5000, 192, 768), (4100, 96, 288)])
+def test_streaming_linear_gelu_backward_with_column_sums(rows, K, N):
+    """pfr_gemm_act_colsums (round 5): GELU backward on the data gradient + plain column sums of the stored output, one partial row per row
+    range of the streaming Linear kernel — the bias gradient of the Linear in front without a pass over the gradient.  The output must be
+    the tile kernel's bits (pfr_gemm_act, act 3); the partial rows must add up to the fp32 column sum of the STORED bf16 output."""
+    from pets_face_recognition_amd._hip import lib
+    g = torch.Generator().manual_seed(rows + N)
+    x = torch.randn(rows, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(DEV)
+    z = torch.randn(rows, N, generator=g).bfloat16().to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        lib.pfr_set_tuning(b"slin", 0)
+        assert lib.pfr_gemm_act_colsum_parts(rows, K, N, 1) == 0
+        ref = torch.empty(rows, N, dtype=torch.bfloat16, device=DEV)
+        lib.pfr_gemm_act(x.data_ptr(), w.data_ptr(), ref.data_ptr(), 1, rows, K, N, 0, 3, z.data_ptr(), st)
+        lib.pfr_set_tuning(b"slin", 2)
+        parts = lib.pfr_gemm_act_colsum_parts(rows, K, N, 1)
+        assert parts > 0
+        y = torch.empty(rows, N, dtype=torch.bfloat16, device=DEV)
+        sums = torch.full((parts, N), float("nan"), dtype=torch.float32, device=DEV)
+        lib.pfr_gemm_act_colsums(x.data_ptr(), w.data_ptr(), y.data_ptr(), 1, rows, K, N, z.data_ptr(), sums.data_ptr(), st)
+        torch.cuda.synchronize()
+    finally:
+        lib.pfr_set_tuning(b"slin", 1)
+    assert torch.equal(y, ref)
+    assert torch.isfinite(sums).all()                      # every partial row was written
+    want = y.float().sum(0)
+    got = sums.sum(0)
+    assert ((got - want).abs() / (want.abs() + y.float().abs().sum(0) * 1e-5 + 1e-6)).max().item() < 1e-3
+    # through the batched final merge the engine uses (mt = 0: plain partial rows)
+    import struct
+    out = torch.zeros(N, dtype=torch.float32, device=DEV)
+    raw = struct.pack("<QQiiiiii", sums.data_ptr(), out.data_ptr(), parts, N, 0, 0, 0, 0)
+    tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(DEV)
+    lib.pfr_colsum_final_batch(tab.data_ptr(), 1, N, st)
+    torch.cuda.synchronize()
+    assert torch.allclose(out, got, rtol=1e-5, atol=1e-4)
