@@ -302,33 +302,30 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
   }
   if constexpr (EP == SLIN_GELU_BWD) {
     if (p.colsum) {
-      // lanes -> columns inside the wave (scratch: the wave's LDS tile), waves -> workgroup, one partial row per range: fixed order, no atomics
-      float* const scr = reinterpret_cast<float*>(xw);             // [64 lanes][8]
-      float* const tab = reinterpret_cast<float*>(xw + 2048);      // [NP] column sums of this wave
-      for (int i = lane; i < NP; i += 64) tab[i] = 0.f;
+      // every lane's sums go to the wave's LDS tile as [pattern][lane][8]; after the barrier thread i < NP adds up column i over all waves,
+      // patterns and the lanes that held its cout piece under that pattern: fixed order, no atomics.  (NBP * 2 KB <= the 6.5 KB tile: the
+      // 64- / 96-cout panels; the host does not offer the 192-cout panel with column sums.)
+      static_assert(NT == 6 || NBP * 2048 <= XBUF, "column-sum scratch must fit the wave's LDS tile");
+      if constexpr (NT != 6) {
+        float* const scr = reinterpret_cast<float*>(xw);
 #pragma unroll
-      for (int q = 0; q < NBP; ++q) {
+        for (int q = 0; q < NBP; ++q)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) scr[lane * 8 + e] = cs[q][e];
-        // cout piece of lane l under pattern q: (q / NBQ) * CPH + ((q % NBQ) * 64 + l) % CPH; lane j < CPH gathers piece j of this half
-        if (lane < CPH) {
-          const int first = ((lane - (q % NBQ) * 64) % CPH + CPH) % CPH;      // smallest lane holding piece `lane`
-          float a[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] = 0.f;
-          for (int l = first; l < 64; l += CPH)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += scr[l * 8 + e];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) tab[((q / NBQ) * CPH + lane) * 8 + e] += a[e];
+          for (int e = 0; e < 8; ++e) scr[(q * 64 + lane) * 8 + e] = cs[q][e];
+        __syncthreads();
+        for (int i = tid; i < NP; i += NTHR) {
+          const int piece = i >> 3, e = i & 7;
+          float a = 0.f;
+          for (int w = 0; w < NW; ++w) {
+            const float* const sw = reinterpret_cast<const float*>(smem + wbytes + w * XBUF);
+            for (int q = 0; q < NBP; ++q) {
+              // lanes l with (q * 64 + l) % CPH == piece
+              const int first = ((piece - q * 64) % CPH + CPH) % CPH;
+              for (int l = first; l < 64; l += CPH) a += sw[(q * 64 + l) * 8 + e];
+            }
+          }
+          if (n0 + i < p.N) p.colsum[(size_t)r * p.N + n0 + i] = a;
         }
-      }
-      __syncthreads();
-      for (int i = tid; i < NP; i += NTHR) {
-        float a = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) a += reinterpret_cast<const float*>(smem + wbytes + w * XBUF + 2048)[i];
-        if (n0 + i < p.N) p.colsum[(size_t)r * p.N + n0 + i] = a;
       }
     }
   }
@@ -395,8 +392,8 @@ static int slin_launch(IgemmParams& p, int dtype, int out_dtype, float* colsum, 
   if (nranges * nw > sp.nblk) nranges = ((sp.nblk + nw - 1) / nw + 7) / 8 * 8;
   sp.npanels = npanels; sp.nranges = nranges; sp.dbg = pfr_knob(KNOB_SLIN_DBG);
   sp.colsum = colsum;
-  if (parts_only) { *parts_only = nranges; return PFR_OK; }
-  if (colsum && ep != SLIN_GELU_BWD) return 1;
+  if (parts_only) { if (np == 192) return 1; *parts_only = nranges; return PFR_OK; }
+  if (colsum && (ep != SLIN_GELU_BWD || np == 192)) return 1;
   const dim3 grid((unsigned)(npanels * nranges)), block((unsigned)(nw * 64));
 #define PFR_SLIN_GO(NTV, EPV)                                                              \
   do {                                                                                     \

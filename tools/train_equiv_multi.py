@@ -3,7 +3,8 @@
 which 64 x 64 images never reach), 40 epochs x 50 steps = 2000 optimizer steps, base rate 0.005 with 5 warm-up epochs.
 Variants: fp32 | bf16 (default: BN-input-free form + Gram statistics) | bf16 with PFR_BNFREE=0 (stored form), each with TWO data-order /
 initialisation seeds: the seed-to-seed spread of one precision is the yardstick for the gap between precisions.
-usage: python tools/train_equiv_multi.py [tag] [epochs] [image_size] [n_val_ids]   -> gpurun_out/<tag>_train_equiv_multi.json"""
+usage: python tools/train_equiv_multi.py [tag] [epochs] [image_size] [n_val_ids] [seeds, e.g. 3,4] [variants, e.g. f32,bf16]
+       -> gpurun_out/<tag>_train_equiv_multi.json (rewritten after every run: a run is 12-17 minutes at 224 x 224, loader-bound)"""
 import json, os, re, subprocess, sys, tempfile, textwrap, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,10 +12,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 224
 n_val = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+seeds = tuple(int(v) for v in sys.argv[5].split(",")) if len(sys.argv) > 5 else (3, 4)
+only = sys.argv[6].split(",") if len(sys.argv) > 6 else None
 common = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic")
 VARIANTS = [("f32", "torch.float32", {}), ("bf16", "torch.bfloat16", {}), ("bf16_stored", "torch.bfloat16", {"PFR_BNFREE": "0"})]
 runs = {}
-for seed in (3, 4):
+if only:
+    VARIANTS = [v for v in VARIANTS if v[0] in only]
+for seed in seeds:
     for name, dt, env in VARIANTS:
         with tempfile.TemporaryDirectory() as td:
             cfg = os.path.join(td, f"equiv_{name}.py")
@@ -45,15 +50,20 @@ for seed in (3, 4):
                 series.setdefault(m.group(2), []).append(float(m.group(3)))
             runs[f"{name}_s{seed}"] = {"logged_losses": losses, "per_validation": series, "seconds": round(time.time() - t0, 1)}
             print(f"{name}_s{seed}: {time.time() - t0:.0f} s, final " + ", ".join(f"{k} {v[-1]:.4f}" for k, v in series.items()), flush=True)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            json.dump({"runs": runs}, open(os.path.join(ROOT, "gpurun_out", f"{tag}_train_equiv_multi.json"), "w"), indent=1)
 final = {k: {m: v[-1] for m, v in r["per_validation"].items()} for k, r in runs.items()}
 metrics = sorted(next(iter(final.values())))
 summary = {}
 for m in metrics:
-    per = {v: [final[f"{v}_s{s}"][m] for s in (3, 4)] for v, _, _ in VARIANTS}
-    mean = {v: sum(x) / 2 for v, x in per.items()}
-    summary[m] = {"per_variant_seed3_seed4": per, "mean": {v: round(x, 4) for v, x in mean.items()},
-                  "seed_spread": {v: round(abs(x[0] - x[1]), 4) for v, x in per.items()},
-                  "bf16_minus_f32": round(mean["bf16"] - mean["f32"], 4), "bf16_minus_bf16_stored": round(mean["bf16"] - mean["bf16_stored"], 4)}
+    per = {v: [final[f"{v}_s{s}"][m] for s in seeds] for v, _, _ in VARIANTS}
+    mean = {v: sum(x) / len(x) for v, x in per.items()}
+    summary[m] = {"per_variant_and_seed": per, "seeds": list(seeds), "mean": {v: round(x, 4) for v, x in mean.items()},
+                  "seed_spread": {v: round(max(x) - min(x), 4) for v, x in per.items()}}
+    if "bf16" in mean and "f32" in mean:
+        summary[m]["bf16_minus_f32"] = round(mean["bf16"] - mean["f32"], 4)
+    if "bf16" in mean and "bf16_stored" in mean:
+        summary[m]["bf16_minus_bf16_stored"] = round(mean["bf16"] - mean["bf16_stored"], 4)
 out = {"workload": f"resnet50 + ArcFace(200 ids), synthetic {size}x{size} (pattern + N(0,1) noise), bs 32, {epochs} epochs x 50 steps, FusedSGD base rate 0.005, "
                    f"5 warm-up epochs, decay at 70 % / 90 %, main.py --config; validation on {n_val * 8} images of {n_val} held-out ids",
        "steps": epochs * 50, "final_validation": summary, "runs": runs}
