@@ -13,7 +13,8 @@ epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 224
 n_val = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 seeds = tuple(int(v) for v in sys.argv[5].split(",")) if len(sys.argv) > 5 else (3, 4)
-only = sys.argv[6].split(",") if len(sys.argv) > 6 else None
+only = sys.argv[6].split(",") if len(sys.argv) > 6 and sys.argv[6] != "all" else None
+workers = int(sys.argv[7]) if len(sys.argv) > 7 else 0      # loader workers (0 = the seed-3 record's setting; the data order does not depend on it)
 common = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic")
 VARIANTS = [("f32", "torch.float32", {}), ("bf16", "torch.bfloat16", {}), ("bf16_stored", "torch.bfloat16", {"PFR_BNFREE": "0"})]
 runs = {}
@@ -28,7 +29,7 @@ for seed in seeds:
                 sys.path.insert(0, {common!r})
                 from _common import make as _make
                 _make(globals(), arch='resnet50', n_train_ids=200, n_val_ids={n_val}, photos=8, image_size={size}, train_bs=32,
-                      test_bs=64, device='cuda:0', n_epochs={epochs}, n_pairs=400, compute_dtype={dt}, seed={seed}, noise=1.0)
+                      test_bs=64, device='cuda:0', n_epochs={epochs}, n_pairs=400, compute_dtype={dt}, seed={seed}, noise=1.0, workers={workers})
                 init_lr = 0.005
                 trainer_kwargs = dict(trainer_kwargs, check_val_every_n_epoch={max(1, epochs // 8)})
                 _opt0 = optimizer
