@@ -51,7 +51,6 @@ enum PfrKnob {
   KNOB_BNB_TILE3,     // with bnb = 2: the 3x3 / stride-1 data gradients on the 256-row tile kernel leave the BatchNorm-backward sums too
   KNOB_SLIN,          // streaming Linear kernel (pfr_slin.hip; K a multiple of 96): 0 off, 1 M >= 65536 rows (default), 2 whenever eligible
   KNOB_SLIN_NP,       // experiments: force its weight-panel width (0 auto, 64 / 96 / 192)
-  KNOB_SLIN_DBG,      // timing experiments of the streaming Linear kernel (wrong results): see SlinParams::dbg
   KNOB_MATCH_ORDER,   // persistent filter GEMM of the gallery match: 1 = L2-blocked tile order per XCD (default), 0 = linear order
   KNOB_COUNT
 };

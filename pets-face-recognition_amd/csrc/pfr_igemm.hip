@@ -401,6 +401,41 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
         }
       }
     }
+    // Fast path (round 5; the common case of every fused chunk): the tile's columns all exist, nothing is excluded and every threshold
+    // of this wave is the key of a POSITIVE score — for those the float order IS the key order, so the exact test is ONE compare per score
+    // (the generic loop below spends ~10 vector instructions per score on key conversion and the column tests before it may branch).
+    // Winners are counted first; a (lane, row) then takes all its slots with ONE atomic (the per-winner atomics were ~28 serialised
+    // round trips per wave and tile) and writes them in a second pass.  Candidate ORDER inside a list is irrelevant (pfr_topk_merge sorts
+    // by key).  Rows past M carry the key 0xFFFFFFFF = NaN as a float: no score compares greater.
+    bool fastw = n0 + BP <= p.Cout && !p.self_excl;
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) fastw = fastw && __all(tks[j] > 0x80000000u);
+    if (fastw) {
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        const int m = m0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
+        const float thr = fkey_inv(tks[j]);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < TP; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cnt += acc[i][j][r] > thr ? 1 : 0;
+        if (cnt > 0) {
+          int slot = atomicAdd(&p.ccnt[m], cnt);
+          unsigned long long* const row = cand + (size_t)m * p.cap;
+#pragma unroll
+          for (int i = 0; i < TP; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (acc[i][j][r] > thr) {
+                const int col = n0 + wp * (BP / WP) + i * 32 + acc_row(r, lane);
+                if (slot < p.cap) row[slot] = ((unsigned long long)fkey(acc[i][j][r]) << 32) | (uint32_t)(~(uint32_t)(p.col0 + col));
+                ++slot;
+              }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
       const int m = m0 + wq * (BQ / WQ) + j * 32 + (lane & 31);

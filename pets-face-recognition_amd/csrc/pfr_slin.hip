@@ -34,7 +34,6 @@ struct SlinParams {
   int act;                // 0 | 2 | 3 (IgemmParams::act)
   float* colsum;          // GELU backward only: [nranges][N] column sums of the stored y over each range's rows (pfr_gemm_act_colsums), or nullptr
   int npanels, nranges, nblk;
-  int dbg;                // timing experiments (pfr_set_tuning("slin_dbg")): 1 no output stores, 2 no x loads after the first, 4 no MFMAs, 8 plain stores without the EXP_CNT wait
 };
 
 // EP (epilogue): what the read-back pass does — a template parameter, because the operands it needs (residual rows, the GELU
@@ -159,8 +158,7 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const u32x4 wf = *reinterpret_cast<const u32x4*>(wb + t * 32 * WSTR + s * 32);
-        if (!(p.dbg & 4))
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf), acc[t], 0, 0, 0);
       }
     }
   };
@@ -252,8 +250,7 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
             for (int e = 0; e < 8; ++e) cs[h * NBQ + q % NBQ][e] += ok ? f[e] : 0.f;
           }
         }
-        if (p.dbg & 8) __builtin_amdgcn_raw_buffer_store_b128(v, yrsrc, (int)off, 0, 0);
-        else if (!(p.dbg & 1)) buffer_store_b128_sync(v, yrsrc, off, 0);
+        buffer_store_b128_sync(v, yrsrc, off, 0);
       }
     }
     return nxt < p.nblk ? nxt : -1;
@@ -390,7 +387,7 @@ static int slin_launch(IgemmParams& p, int dtype, int out_dtype, float* colsum, 
   sp.bias = p.bias; sp.res = (const bf16_t*)p.residual; sp.y2 = (bf16_t*)p.y2; sp.act = p.act;
   sp.nblk = (M + 31) / 32;
   if (nranges * nw > sp.nblk) nranges = ((sp.nblk + nw - 1) / nw + 7) / 8 * 8;
-  sp.npanels = npanels; sp.nranges = nranges; sp.dbg = pfr_knob(KNOB_SLIN_DBG);
+  sp.npanels = npanels; sp.nranges = nranges;
   sp.colsum = colsum;
   if (parts_only) { if (np == 192) return 1; *parts_only = nranges; return PFR_OK; }
   if (colsum && (ep != SLIN_GELU_BWD || np == 192)) return 1;

@@ -364,3 +364,31 @@ def test_controller_evaluate_on_gpu_equals_reference_evaluate(name):
     for k in m:
         if k.startswith("Recall@K="):
             assert m2[k] == m[k], (name, k)
+
+
+@pytest.mark.gpu
+def test_prepared_gallery_handle_equals_the_one_shot_match():
+    """match.prepare_gallery (round 5): reuse of the normalised gallery is an EXPLICIT handle — same top-k as the one-shot call
+    (which re-scores from the raw rows x 1/|row|), for several query batches; a handle built for other settings is refused; refilling the
+    caller's gallery buffer in place does not change what the handle returns (it owns its copies) but changes the one-shot result."""
+    from pets_face_recognition_amd.match import cosine_topk, prepare_gallery
+    from pets_face_recognition_amd._hip import PfrError
+    g = torch.Generator().manual_seed(5)
+    gal = torch.randn(70000, 128, generator=g).to(DEV)
+    pg = prepare_gallery(gal)
+    for s in range(2):
+        q = torch.randn(300, 128, generator=g).to(DEV)
+        s1, i1 = cosine_topk(q, gal, 20, chunk=16384)
+        s2, i2 = cosine_topk(q, pg, 20, chunk=16384)
+        assert torch.equal(i1, i2)
+        assert torch.allclose(s1, s2, rtol=0, atol=2e-6)
+    with pytest.raises(PfrError):
+        cosine_topk(q, pg, 20, compute_dtype=torch.float32)
+    with pytest.raises(PfrError):
+        cosine_topk(q, pg, 20, rescore=False)
+    keep = i2.clone()
+    gal.copy_(torch.randn(70000, 128, generator=g))          # the caller refills its buffer
+    s3, i3 = cosine_topk(q, pg, 20, chunk=16384)
+    assert torch.equal(i3, keep)
+    s4, i4 = cosine_topk(q, gal, 20, chunk=16384)
+    assert not torch.equal(i4, keep)
