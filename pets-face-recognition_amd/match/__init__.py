@@ -72,7 +72,7 @@ def prepare_gallery(g, compute_dtype=torch.bfloat16, rescore=None, normalize=Tru
 
 
 def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self=False, rescore=None, slack=None,
-                normalize=True, fused_filter=True, merge_every=2):
+                normalize=True, fused_filter=True, merge_every=2, seed_cols="auto"):
     """Top-k gallery rows per query by cosine similarity.  q [Q,D], g [G,D] (any scale; rows are L2-normalised here) or a
     `prepare_gallery(g)` handle (the gallery's normalisation is then not repeated per call).
     → (scores [Q,k] fp32 cosine, idx [Q,k] int32, −1 / −inf padded when fewer than k exist).
@@ -124,6 +124,19 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
         #  same results, 20.8 / 19.3 / 18.7 ms for seeds of 8 k / 16 k / 32 k columns against 18.5 ms: the early segments carry several times
         #  the candidates per query and their merges cost more than the unfused first chunk they replace; profiles/r04_match_seed_ab.txt.)
         segs = [(c0, min(chunk, G - c0), bool(fused and c0 > 0)) for c0 in range(0, G, chunk)]
+        if seed_cols == "auto":     # (a seed pays once the gallery is several chunks long)
+            seed_cols = chunk // 2 if (chunk == 65536 and G >= 4 * chunk) else None
+        if fused and seed_cols and kc + 1 <= seed_cols < chunk:
+            # round 5 (tools/match_seed_ab.py, profiles/r05_ab.txt): an unfused seed of `seed_cols` columns, then fused segments that double
+            # up to `chunk`, each of the early ones merged at once (their thresholds are loose).  Round 4 had measured this form SLOWER
+            # (20.8 / 19.3 / 18.7 ms for seeds of 8 k / 16 k / 32 k against 18.5): the per-winner atomics of the filter epilogue made the
+            # candidate-rich early segments expensive; with the counted epilogue it is 15.2 against 15.5 ms, same results.
+            segs, c0, n = [(0, seed_cols, False)], seed_cols, seed_cols
+            while c0 < G:
+                n = min(max(n, seed_cols) if c0 + n <= chunk else chunk, G - c0)
+                segs.append((c0, n, True))
+                c0 += n
+                n = min(2 * n, chunk)
         ld = (max(n for _, n, f in segs if not f) + 3) // 4 * 4
         if sbuf is None or sbuf.shape[-1] < ld:
             sbuf = torch.empty((Q, 1, 1, ld), dtype=torch.float32, device=q.device)
@@ -137,7 +150,7 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
                 lib.pfr_match_scores_filter(qn.data_ptr(), gn[c0:c0 + n].data_ptr(), dtype_id(T), Q, n, D, c0, kc, state.data_ptr(),
                                             cand.data_ptr(), cap, int(exclude_self), _stream())
                 pending += 1
-                if pending >= merge_every or si + 1 == len(segs):
+                if pending >= merge_every or si + 1 == len(segs) or (seed_cols and c0 < 4 * chunk):
                     lib.pfr_topk_merge(cand.data_ptr(), cap, Q, kc, state.data_ptr(), _stream())
                     pending = 0
                 continue
