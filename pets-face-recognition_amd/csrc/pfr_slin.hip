@@ -10,17 +10,25 @@
 // behind a prologue and a two-pass epilogue, the weight tile re-staged per row tile), and pfr_sconv.hip's geometry rules (K a power
 // of two, panel counts that divide 256) exclude every channel count of the form 96 * 2^k.  Same skeleton as pfr_sconv.hip, simpler
 // parts (round 5):
-//   * persistent workgroups of 4 waves, grid = npanels x nranges; the weight panel [NP = 64 | 96 | 192 couts][K] is copied to LDS ONCE
-//     per workgroup (rows padded by 16 B: row stride = odd multiple of 16 B, so the 16-lane groups of ds_read_b128 are conflict free);
-//     the only workgroup barrier of the kernel follows that copy;
+//   * ONE persistent workgroup of 8 waves per CU, grid = npanels x nranges (the panels of a row range on one XCD); the weight panel
+//     [NP = 64 | 96 couts][K] is copied to LDS once per workgroup (rows padded by 16 B: the row stride is an odd multiple of 16 B, so the
+//     16-lane groups of ds_read_b128 are conflict free); the only workgroup barrier of the loop-carrying part follows that copy (the
+//     column-sum form has one more at the very end).  (A 192-cout panel with 4 waves exists for experiments: it lost every A/B.)
 //   * every wave owns 32-row blocks (interleaved over all waves of the chip: one moving window of the tensor) and walks K in chunks of
-//     96 columns: the chunk [32 rows][96] arrives by plain 16-byte loads in full rows (registers, issued one chunk AHEAD of its use —
-//     the loads of chunk c+1 fly while chunk c is multiplied), is written to the wave's private LDS tile (two buffers, 208-byte
-//     rows) and read back as MFMA fragments.  No LDS-DMA, no hand-counted waits: every wait is the compiler's;
+//     96 columns: the chunk [32 rows][96] arrives by 16-byte buffer loads in whole 192-byte row segments into REGISTERS, one chunk — and,
+//     across a block boundary, one block — ahead of its use (the next block's first chunk and its residual / pre-activation rows are
+//     requested under the current block's last MFMAs; the first block's before the weight copy), is written to the wave's private
+//     6.5 KB LDS tile (208-byte rows) and read back as MFMA fragments;
+//   * the loads are inline asm with HAND-COUNTED s_waitcnt vmcnt(n): the epilogue's stores are inline asm (buffer_store_b128_sync), and
+//     hipcc's own count for a load that is OLDER than such stores comes out as if they did not exist, i.e. it waits for them — the full
+//     write latency once per block.  Every epilogue operand is requested in straight-line code (a load inside a runtime branch, or a
+//     select on a freshly loaded register, is followed by a full wait: the first version ran at 0.5-1.1x of the tile kernel for that);
 //   * epilogue per block: accumulators -> bf16 -> the wave's LDS tile -> whole row segments of 16 bytes per lane (fully contiguous
 //     for a single-panel layer) with residual / bias / GELU applied in the read-back pass — the ARITHMETIC of igemm_kernel's epilogue
 //     (round to bf16, then add in fp32, round again), so results are bit-identical to the tile kernel's (same k order inside and
-//     across the MFMAs).  Stores go through buffer_store_b128_sync (pfr_mma.h).
+//     across the MFMAs); GELU backward can also leave the column sums of its stored output (pfr_gemm_act_colsums: the bias gradient
+//     of the Linear in front), one partial row per row range, reduced in a fixed order without atomics.
+// Measured: profiles/r05_slin.txt (1.08-1.55x the tile kernel cold, Swin-T step -3.4 %), race screen tools/slin_stress.py.
 #include "pfr_igemm.h"
 
 struct SlinParams {

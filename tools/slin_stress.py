@@ -34,5 +34,30 @@ for M, K, N, form in SHAPES:
     lib.pfr_set_tuning(b"slin", 1)
     bad_total += bad
     print(f"M {M} K {K} N {N} {form:5s}: {reps} repetitions under load, {bad} differ from the tile kernel", flush=True)
+# GELU backward + column sums (pfr_gemm_act_colsums): output against the tile kernel's bits, partial sums against the first repetition's
+# (the reduction has a fixed order: they must be bit-reproducible)
+M, K, N = 401408, 96, 384
+g = torch.Generator(device="cuda").manual_seed(7)
+x = torch.randn(M, K, device="cuda", generator=g).bfloat16(); w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+z = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+lib.pfr_set_tuning(b"slin", 0)
+lib.pfr_gemm_act(x.data_ptr(), w.data_ptr(), ref.data_ptr(), 1, M, K, N, 0, 3, z.data_ptr(), st); torch.cuda.synchronize()
+lib.pfr_set_tuning(b"slin", 1)
+parts = lib.pfr_gemm_act_colsum_parts(M, K, N, 1)
+y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); sums = torch.empty(parts, N, device="cuda"); first = None; bad = 0
+for i in range(reps):
+    y.zero_(); sums.fill_(float("nan"))
+    with torch.cuda.stream(side):
+        noise.mul_(1.0000001); noise.add_(1e-9)
+    lib.pfr_gemm_act_colsums(x.data_ptr(), w.data_ptr(), y.data_ptr(), 1, M, K, N, z.data_ptr(), sums.data_ptr(), st)
+    torch.cuda.synchronize()
+    if first is None:
+        first = sums.clone()
+        assert torch.allclose(sums.sum(0), y.float().sum(0), rtol=1e-3, atol=0.5)
+    if not torch.equal(y, ref) or not torch.equal(sums, first):
+        bad += 1
+bad_total += bad
+print(f"M {M} K {K} N {N} gelu' + column sums ({parts} partial rows): {reps} repetitions under load, {bad} differ", flush=True)
 print("TOTAL mismatching repetitions:", bad_total)
 sys.exit(1 if bad_total else 0)
