@@ -48,6 +48,7 @@ int pfr_device_arch(char* buf, int buflen);
  *   "bnb_tile3" (0) with bnb = 2: the 3x3 / stride-1 data gradients on the 256-row tile kernel leave the BatchNorm-backward sums too;
  *   "slin" (1) streaming Linear kernel for K = 96 j (Swin): 0 off, 1 for M >= 65536 rows, 2 whenever eligible;
  *   "attn_mfma" (1) window attention on MFMA;  "match_order" (1) L2-blocked tile order of the persistent filter GEMM of the gallery match.
+ *   "ln_rb" (4) LayerNorm forward, rows in flight per lane group for C <= 512: 4, 6 or 8.
  * Results do not depend on the knobs (same accumulation order per kernel family; alternatives are pinned bit-for-bit or to the oracle by the
  * tests); statistics-partial granularity follows pfr_conv2d_mtile.  pfr_get_tuning reads a knob back. */
 int pfr_set_tuning(const char* key, int value);

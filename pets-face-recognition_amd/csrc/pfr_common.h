@@ -52,6 +52,7 @@ enum PfrKnob {
   KNOB_SLIN,          // streaming Linear kernel (pfr_slin.hip; K a multiple of 96): 0 off, 1 M >= 65536 rows (default), 2 whenever eligible
   KNOB_SLIN_NP,       // experiments: force its weight-panel width (0 auto, 64 / 96 / 192)
   KNOB_MATCH_ORDER,   // persistent filter GEMM of the gallery match: 1 = L2-blocked tile order per XCD (default), 0 = linear order
+  KNOB_LN_RB,         // LayerNorm forward: rows in flight per lane group for C <= 512 (one 16-byte chunk per lane): 4 (default), 6, 8
   KNOB_COUNT
 };
 extern int g_pfr_knob[KNOB_COUNT];

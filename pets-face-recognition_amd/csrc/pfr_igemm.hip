@@ -810,6 +810,8 @@ static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) 
     const long t256 = (long)((M + 255) / 256);
     if (Cout >= 192 && t256 * ((Cout + 255) / 256) >= 160) { *bq = 256; return TILE_256x256; }
     // (Cout = 128, a single column of 256x128 tiles, loses 10-17 % to the 128x128 tile: tools/tile_sweep.py)
+    // (round 5: a 256x192 tile — no idle columns at Cout = 192 / 384 / 576, the Swin widths — was bit-identical and within 1 % of the
+    //  256x256 tile on every Swin-T geometry, 65.6 vs 65.9 us at 25088 x 1536 -> 384: the idle quarter is not what bounds them)
     if (Cout >= 256 && t256 * ((Cout + 127) / 128) >= 320) { *bq = 256; return TILE_256x128; }
   }
   const int bp = Cout > 64 ? 128 : 64;   // (Cout = 96: the 128-wide tile with a quarter of its columns idle still wins by ~10 %)

@@ -12,6 +12,7 @@
 // The shift and the window partition are pure addressing here: token (wy,wx) of window (gy,gx) lives at image position
 // ((gy·w + wy + d) mod H, (gx·w + wx + d) mod W) with d = w/2 for shifted blocks — nothing is rolled or copied.
 #include "pfr_common.h"
+#include "pfr_mma.h"
 #include <stdlib.h>
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -56,64 +57,94 @@ static bool ln_geom(int C, int kp, LnGeom* g) {
   g->cpl = (g->cpr + g->G - 1) / g->G;
   return g->cpl <= 4;
 }
-static int ln_grid(long rows, int G) {
-  const long per_iter = 4L * (64 / G);
-  long nb = (rows + per_iter * 4 - 1) / (per_iter * 4);   // ≥ 4 rows per lane group
-  if (nb > 2048) nb = 2048;
+static int ln_grid(long rows, int G, int rb) {   // one batch of rb x (256 / G) rows per workgroup
+  const long per = (long)rb * 4 * (64 / G);
+  const long nb = (rows + per - 1) / per;
   return (int)(nb < 1 ? 1 : nb);
 }
 
-template <typename T, int CPL>
-__global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+// Sum over the G lanes that own a row, every lane receiving the total.  The 16-lane part is four DPP adds (quad_perm [1,0,3,2] and
+// [2,3,0,1], row_half_mirror, row_mirror: the same pairings, hence the same bits, as the xor-1/2/4/8 butterfly); with G a run-time
+// value it was a loop of ds_bpermute + lgkmcnt(0) round trips, 8-12 per row and the longest stretch between a row's loads and its
+// stores (round 5: 53 -> ? us for the 401 408 x 96 forward).
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int G>
+__device__ __forceinline__ float ln_group_sum(float s) {
+  s += ln_dpp<0xB1>(s);
+  s += ln_dpp<0x4E>(s);
+  s += ln_dpp<0x141>(s);
+  s += ln_dpp<0x140>(s);
+  if constexpr (G >= 32) s += __shfl_xor(s, 16, 64);
+  if constexpr (G >= 64) s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+template <typename T, int CPL, int G, int RB>
+__global__ __launch_bounds__(256, (CPL == 1 ? (RB == 8 ? 6 : 8) : (CPL == 2 ? 5 : 2))) void layernorm_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, T* __restrict__ y,
                                                              float* __restrict__ mean, float* __restrict__ rstd, long rows,
-                                                             int C, float eps, int G, int cpr) {
+                                                             int C, float eps, int cpr) {
   constexpr int KP = DT<T>::KPACK;
-  // rows in flight per lane group: the row loop is a chain of memory round trips (load → statistics → store), so a lane keeps
-  // the chunks of several rows in flight at once (unconditional loads from clamped addresses) — 31.7 → ? µs at 100 352 x 192
-  constexpr int RB = CPL <= 1 ? 4 : 2;
+  // One batch of RB x (256 / G) consecutive rows per workgroup, RB rows in flight per lane group, no row loop.  Round 5 (53.3 → ? µs at
+  // 401 408 x 96, 18.3 → ? at 6 272 x 768):
+  //  * the former grid-stride loop of 2048 resident workgroups ran ceil(3.06) = 4 latency-bound iterations on the stage-1 tensor, the
+  //    last one 6 % full; with one batch per workgroup the hardware scheduler balances the tail;
+  //  * BUFFER addressing: a 32-bit byte offset per lane + a wave-uniform offset per row of the batch instead of RB 64-bit addresses
+  //    each for x, y, mean and rstd (the kernel spilled at eight waves per SIMD), and the descriptor's range check instead of clamps
+  //    and branches: rows past the end and the lanes past a row's last chunk read zeros and their stores are dropped — straight-line code;
+  //  * γ / β go to LDS AFTER the x loads are issued (as 2 x CPL x KP registers per lane they cost two of the eight waves per SIMD).
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & (G - 1), grp = lane / G, rpw = 64 / G;
-  float gm[CPL][KP], bt[CPL][KP];
+  const int sub = lane & (G - 1), grp = lane / G;
+  constexpr int rpw = 64 / G;
+  const uint32_t rowb = (uint32_t)C * (uint32_t)sizeof(T);
+  const uint32_t total = (uint32_t)rows * rowb;   // (host: < 2^31)
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)total, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)total, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(mean, 0, mean ? (int)(rows * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rstd, 0, rstd ? (int)(rows * 4) : 0, 0x00020000);
   bool okc[CPL];
-  int cch[CPL];
+  uint32_t cb[CPL];
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
     const int c = sub + G * k;
     okc[k] = c < cpr;
-    cch[k] = okc[k] ? c : 0;
-#pragma unroll
-    for (int e = 0; e < KP; ++e) {
-      gm[k][e] = okc[k] ? gamma[c * KP + e] : 0.f;
-      bt[k][e] = okc[k] ? beta[c * KP + e] : 0.f;
-    }
+    cb[k] = okc[k] ? (uint32_t)c * 16u : 0x7ffffff0u;   // past the descriptor's range: loads give 0, stores are dropped
   }
   const float invC = 1.f / (float)C;
-  const long stride = (long)gridDim.x * 4 * rpw;
-  for (long row0 = ((long)blockIdx.x * 4 + wave) * rpw + grp; row0 < rows; row0 += RB * stride) {
+  constexpr uint32_t stride = 4u * rpw;                  // rows between two rows of a lane group's batch: the workgroup's rows are contiguous
+  const uint32_t strideb = stride * rowb;
+  const uint32_t row = blockIdx.x * (RB * stride) + wave * rpw + grp;
+  const uint32_t voff = row * rowb;
+  {
     u32x4 raw[RB][CPL];
 #pragma unroll
-    for (int b = 0; b < RB; ++b) {
-      const long row = row0 + b * stride < rows ? row0 + b * stride : row0;
+    for (int b = 0; b < RB; ++b)
 #pragma unroll
-      for (int k = 0; k < CPL; ++k) raw[b][k] = ld16(x + row * C + cch[k] * KP);
+      for (int k = 0; k < CPL; ++k)
+        raw[b][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(voff + cb[k]), (int)(b * strideb), 0));
+    __shared__ __attribute__((aligned(16))) float sgam[2048], sbet[2048];
+    for (int c = threadIdx.x; c < C; c += 256) {
+      sgam[c] = gamma[c];
+      sbet[c] = beta[c];
     }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);   // every load of the batch is issued before the first is consumed (hipcc hoists row 0's unpack, and its wait, above the other loads)
+    // statistics of every row in flight first, all stores afterwards
+    float mus[RB], rss[RB];
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-      const long row = row0 + b * stride;
-      if (row >= rows) break;
       float f[CPL][KP];
       float s = 0.f;
 #pragma unroll
       for (int k = 0; k < CPL; ++k) {
         Chunk<T>::unpack(raw[b][k], f[k]);
 #pragma unroll
-        for (int e = 0; e < KP; ++e) {
-          if (!okc[k]) f[k][e] = 0.f;
-          s += f[k][e];
-        }
+        for (int e = 0; e < KP; ++e) s += f[k][e];
       }
-      for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o, 64);
+      s = ln_group_sum<G>(s);
       const float mu = s * invC;
       float v = 0.f;
 #pragma unroll
@@ -123,19 +154,29 @@ __global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const T* __restrict
           const float d = okc[k] ? f[k][e] - mu : 0.f;
           v = fmaf(d, d, v);
         }
-      for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
-      const float rs = rsqrtf(v * invC + eps);
-      if (sub == 0) {
-        if (mean) mean[row] = mu;
-        if (rstd) rstd[row] = rs;
+      v = ln_group_sum<G>(v);
+      mus[b] = mu;
+      rss[b] = rsqrtf(v * invC + eps);
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const float mu = mus[b], rs = rss[b];
+#pragma unroll
+      for (int k = 0; k < CPL; ++k)   // (opaque copy: without it the unpacked floats of all RB rows stay live from the statistics phase — spills)
+        asm volatile("" : "+v"(raw[b][k]));
+      const uint32_t moff = sub == 0 ? row * 4u : 0x7ffffff0u;   // one lane per row stores; the others' are dropped by the range check
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, mu), mr, (int)moff, (int)(b * stride * 4u), 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rs), rr, (int)moff, (int)(b * stride * 4u), 0);
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        float f[KP];
+        Chunk<T>::unpack(raw[b][k], f);
+        const float* gp = sgam + ((sub + G * k) & 255) * KP;   // (lanes past the row: any in-range LDS address; their store is dropped)
+        const float* bp = sbet + ((sub + G * k) & 255) * KP;
+#pragma unroll
+        for (int e = 0; e < KP; ++e) f[e] = fmaf((f[e] - mu) * rs, gp[e], bp[e]);
+        buffer_store_b128_sync(Chunk<T>::pack(f), yr, voff + cb[k], b * strideb);
       }
-#pragma unroll
-      for (int k = 0; k < CPL; ++k)
-        if (okc[k]) {
-#pragma unroll
-          for (int e = 0; e < KP; ++e) f[k][e] = fmaf((f[k][e] - mu) * rs, gm[k][e], bt[k][e]);
-          st16(y + row * C + (sub + G * k) * KP, Chunk<T>::pack(f[k]));
-        }
     }
   }
 }
@@ -145,13 +186,17 @@ static bool ln_fwd2_launch(const void* x, const float* gamma, const float* beta,
                            int C, float eps, hipStream_t st) {
   LnGeom g;
   if (!ln_geom(C, DT<T>::KPACK, &g)) return false;
-  const dim3 grid(ln_grid(rows, g.G));
-#define PFR_LNF(K)                                                                                                      \
-  if (g.cpl == K) {                                                                                                     \
-    hipLaunchKernelGGL((layernorm_fwd2_kernel<T, K>), grid, dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, g.G, g.cpr); \
+  if ((double)rows * C * sizeof(T) >= 2147483648.0 * 0.75) return false;   // 32-bit buffer offsets (the batch's last row may lie past the end)
+  const int rbk = pfr_knob(KNOB_LN_RB);
+  const int rb = g.cpl > 1 ? 2 : (rbk == 6 || rbk == 8 ? rbk : 4);
+  const dim3 grid(ln_grid(rows, g.G, rb));
+#define PFR_LNF(K, GG, R)                                                                                               \
+  if (g.cpl == K && g.G == GG && rb == R) {                                                                             \
+    hipLaunchKernelGGL((layernorm_fwd2_kernel<T, K, GG, R>), grid, dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, g.cpr); \
     return true;                                                                                                        \
   }
-  PFR_LNF(1) PFR_LNF(2) PFR_LNF(3) PFR_LNF(4)
+  PFR_LNF(1, 16, 4) PFR_LNF(1, 32, 4) PFR_LNF(1, 64, 4) PFR_LNF(1, 16, 6) PFR_LNF(1, 32, 6) PFR_LNF(1, 64, 6) PFR_LNF(1, 16, 8) PFR_LNF(1, 32, 8)
+  PFR_LNF(1, 64, 8) PFR_LNF(2, 64, 2) PFR_LNF(3, 64, 2) PFR_LNF(4, 64, 2)
 #undef PFR_LNF
   return false;
 }
@@ -244,12 +289,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-template <typename T, int CPL>
+template <typename T, int CPL, int G>
 __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, const T* __restrict__ dres,
                                                              T* __restrict__ dx, float* __restrict__ part, float* __restrict__ dxsum, long rows,
-                                                             int C, int G, int cpr) {
+                                                             int C, int cpr) {
   constexpr int KP = DT<T>::KPACK;
   extern __shared__ float sh[];  // [4 waves][3][C]   (third row set: column sums of the stored dx, optional)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -298,10 +343,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
         b = fmaf(g, xh[k][e], b);
       }
     }
-    for (int o = 1; o < G; o <<= 1) {
-      a += __shfl_xor(a, o, 64);
-      b += __shfl_xor(b, o, 64);
-    }
+    a = ln_group_sum<G>(a);
+    b = ln_group_sum<G>(b);
     a *= invC;
     b *= invC;
 #pragma unroll
@@ -401,10 +444,12 @@ extern "C" int pfr_layernorm_bwd_dxsum(const void* dy, const void* x, const floa
     const int kp = dtype == PFR_BF16 ? 8 : 4;
     if (ln_geom(C, kp, &g)) {
       const size_t shb = (size_t)12 * C * sizeof(float);
-#define PFR_LNB(TT, K)                                                                                                  \
-  if (g.cpl == K) hipLaunchKernelGGL((layernorm_bwd2_kernel<TT, K>), dim3(nb), dim3(256), shb, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, part, dxsum_part, rows, C, g.G, g.cpr);
-      if (dtype == PFR_BF16) { PFR_LNB(bf16_t, 1) PFR_LNB(bf16_t, 2) PFR_LNB(bf16_t, 3) PFR_LNB(bf16_t, 4) }
-      else { PFR_LNB(float, 1) PFR_LNB(float, 2) PFR_LNB(float, 3) PFR_LNB(float, 4) }
+#define PFR_LNB(TT, K, GG)                                                                                              \
+  if (g.cpl == K && g.G == GG) hipLaunchKernelGGL((layernorm_bwd2_kernel<TT, K, GG>), dim3(nb), dim3(256), shb, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, part, dxsum_part, rows, C, g.cpr);
+#define PFR_LNB_ALL(TT) PFR_LNB(TT, 1, 16) PFR_LNB(TT, 1, 32) PFR_LNB(TT, 1, 64) PFR_LNB(TT, 2, 64) PFR_LNB(TT, 3, 64) PFR_LNB(TT, 4, 64)
+      if (dtype == PFR_BF16) { PFR_LNB_ALL(bf16_t) }
+      else { PFR_LNB_ALL(float) }
+#undef PFR_LNB_ALL
 #undef PFR_LNB
       PFR_CHECK_LAUNCH();
       return PFR_OK;

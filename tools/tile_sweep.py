@@ -43,7 +43,7 @@ def worker(path):
             out = ops.conv2d_wgrad(x, dy, R, R, s, pad, workspace=ws)
             run = lambda: ops.conv2d_wgrad(x, dy, R, R, s, pad, out=out, workspace=ws)
         else:
-            kw = dict(stride=s, pad=pad, idil_log2=dil, out_hw=(OH, OH), stats=(dil == 0))
+            kw = dict(stride=s, pad=pad, idil_log2=dil, out_hw=(OH, OH), stats=(dil == 0 and H > 1))   # (H = 1: the Linear layers of Swin, no BatchNorm statistics)
             y, part = ops.conv2d_fwd(x, w, **kw)
             run = lambda: ops.conv2d_fwd(x, w, out=y, stats_buf=part, **kw)
         for _ in range(4):
