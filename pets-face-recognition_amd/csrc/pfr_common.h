@@ -202,7 +202,11 @@ __host__ __device__ __forceinline__ TopkState topk_state(void* state, int rows, 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 // streaming (last-use) load: non-temporal hint, the line need not stay in L2 / MALL
+#ifdef PFR_NO_NT   // A/B builds: plain loads
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+#else
 __device__ __forceinline__ u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -30,6 +30,9 @@
 //     of the Linear in front), one partial row per row range, reduced in a fixed order without atomics.
 // Measured: profiles/r05_slin.txt (1.08-1.55x the tile kernel cold, Swin-T step -3.4 %), race screen tools/slin_stress.py.
 #include "pfr_igemm.h"
+#ifndef PFR_SLIN_NT   // A/B builds: -DPFR_SLIN_NT='" nt"' marks the row loads non-temporal — measured: Swin-T step 11.85 -> 11.57 k img/s, off
+#define PFR_SLIN_NT ""
+#endif
 
 struct SlinParams {
   const bf16_t* x;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const uint32_t off = (uint32_t)(((bk * 32 + crow(j)) * K + c * 96 + cpc(j) * 8) * 2);
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(R[j]) : "v"(off), "s"(xrsrc) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" PFR_SLIN_NT : "=v"(R[j]) : "v"(off), "s"(xrsrc) : "memory");
     }
   };
   // wait until at most n vector-memory operations issued after the x chunk in R are outstanding; R (and everything older) has landed
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(NT == 6 ? 256 : 512, 1) void slin_kernel(SlinParams
         const int row = i / CPH, c16 = (ps / PH) * CPH + (i - row * CPH);
         const int m = bk * 32 + row, co = n0 + c16 * 8;
         const uint32_t off = (m < p.M && co < p.N) ? (uint32_t)(((size_t)m * p.N + co) * 2) : 0xF0000000u;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(RSx[ps]) : "v"(off), "s"(r2rsrc) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" PFR_SLIN_NT : "=v"(RSx[ps]) : "v"(off), "s"(r2rsrc) : "memory");
       }
     }
   };

@@ -82,6 +82,17 @@ __device__ __forceinline__ float ln_group_sum(float s) {
   return s;
 }
 
+// Non-temporal hint on the row loads of the LayerNorm kernels (A/B builds: -DPFR_LN_NT=1 forward, -DPFR_LNB_NT=2 backward = the `nt`
+// cache-policy bit).  Measured (round 5, profiles/r05_ln.txt): COLD the hint is worth 1.4x (forward 44.5 -> 31.9 us at 401 408 x 96, 4.9 TB/s,
+// faster than a device copy), but inside the Swin-T step, where every operand was written by the kernel before, it costs 0.5-0.8 % of
+// the step (the lines are dropped from L2 / MALL before their next reader) — so both default to plain loads.
+#ifndef PFR_LNB_NT
+#define PFR_LNB_NT 0
+#endif
+#ifndef PFR_LN_NT
+#define PFR_LN_NT 0
+#endif
+static constexpr bool pfr_ln_nt = PFR_LN_NT != 0;
 template <typename T, int CPL, int G, int RB>
 __global__ __launch_bounds__(256, (CPL == 1 ? (RB == 8 ? 6 : 8) : (CPL == 2 ? 5 : 2))) void layernorm_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, T* __restrict__ y,
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256, (CPL == 1 ? (RB == 8 ? 6 : 8) : (CPL == 2 ? 5 
     for (int b = 0; b < RB; ++b)
 #pragma unroll
       for (int k = 0; k < CPL; ++k)
-        raw[b][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(voff + cb[k]), (int)(b * strideb), 0));
+        raw[b][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(voff + cb[k]), (int)(b * strideb), pfr_ln_nt ? 2 : 0));
     __shared__ __attribute__((aligned(16))) float sgam[2048], sbet[2048];
     for (int c = threadIdx.x; c < C; c += 256) {
       sgam[c] = gamma[c];
@@ -171,8 +182,8 @@ __global__ __launch_bounds__(256, (CPL == 1 ? (RB == 8 ? 6 : 8) : (CPL == 2 ? 5 
       for (int k = 0; k < CPL; ++k) {
         float f[KP];
         Chunk<T>::unpack(raw[b][k], f);
-        const float* gp = sgam + ((sub + G * k) & 255) * KP;   // (lanes past the row: any in-range LDS address; their store is dropped)
-        const float* bp = sbet + ((sub + G * k) & 255) * KP;
+        const float* gp = sgam + (okc[k] ? sub + G * k : 0) * KP;   // (lanes past the row: γ[0..], a defined value — 0 x uninitialised LDS could be NaN; their store is dropped)
+        const float* bp = sbet + (okc[k] ? sub + G * k : 0) * KP;
 #pragma unroll
         for (int e = 0; e < KP; ++e) f[e] = fmaf((f[e] - mu) * rs, gp[e], bp[e]);
         buffer_store_b128_sync(Chunk<T>::pack(f), yr, voff + cb[k], b * strideb);
@@ -401,6 +412,152 @@ __global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const T* __restrict
   }
 }
 
+// The same pass with BUFFER addressing and RB rows in flight per lane group (tensors below 1.5 GB; round 5).  The row loop of
+// layernorm_bwd2_kernel is latency-bound — 16 resident waves per CU x one row x three 16-byte loads per lane ≈ 49 KB in flight per
+// CU per ~2.7 µs iteration = the 4.6 TB/s it measures at 401 408 x 96 — so this one keeps two rows per lane group in flight at the same
+// register budget: 32-bit lane offsets + wave-uniform row offsets instead of 64-bit addresses per operand, γ in LDS, the range check
+// of the descriptor instead of row / chunk predicates (rows past the end and lanes past the row read zeros — they add 0 to every sum —
+// and their stores are dropped), a missing residual = an empty descriptor.  Every row's result is computed BEFORE the first store of
+// the iteration is issued (the stores are inline asm: a compiler-counted wait for a younger load would also wait for them).
+// Per lane the rows are visited in the same order as before: dγ / dβ / Σdx partials are bit-identical to layernorm_bwd2_kernel's.
+template <typename T, int CPL, int G>
+__global__ __launch_bounds__(256, (CPL == 1 ? 4 : (CPL == 2 ? 2 : 1))) void layernorm_bwd3_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                             T* __restrict__ dx, float* __restrict__ part, float* __restrict__ dxsum, long rows,
+                                                             int C, int cpr) {
+  constexpr int KP = DT<T>::KPACK;
+  constexpr int RB = CPL == 1 ? 2 : 1;
+  extern __shared__ float sh[];  // [4 waves][3][C] partial sums at the end, then [C] γ
+  float* const sgam = sh + 12 * C;
+  for (int c = threadIdx.x; c < C; c += 256) sgam[c] = gamma[c];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1), grp = lane / G;
+  constexpr int rpw = 64 / G;
+  const uint32_t rowb = (uint32_t)C * (uint32_t)sizeof(T);
+  const uint32_t total = (uint32_t)rows * rowb;
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy), 0, (int)total, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)total, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dres ? dres : dy), 0, dres ? (int)total : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc(dx, 0, (int)total, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mean), 0, (int)(rows * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rstd), 0, (int)(rows * 4), 0x00020000);
+  float ag[CPL][KP], ab[CPL][KP], ad[CPL][KP];
+  bool okc[CPL];
+  uint32_t cb[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = sub + G * k;
+    okc[k] = c < cpr;
+    cb[k] = okc[k] ? (uint32_t)c * 16u : 0x7ffffff0u;
+#pragma unroll
+    for (int e = 0; e < KP; ++e) {
+      ag[k][e] = 0.f;
+      ab[k][e] = 0.f;
+      ad[k][e] = 0.f;
+    }
+  }
+  const float invC = 1.f / (float)C;
+  const uint32_t stride = gridDim.x * 4u * rpw;
+  const uint32_t strideb = __builtin_amdgcn_readfirstlane(stride * rowb);
+  const uint32_t nit = ((uint32_t)rows + RB * stride - 1) / (RB * stride);
+  uint32_t row = (blockIdx.x * 4u + wave) * rpw + grp;
+  uint32_t voff = row * rowb;
+  for (uint32_t it = 0; it < nit; ++it, row += RB * stride, voff += RB * stride * rowb) {
+    u32x4 rx[RB][CPL], rd[RB][CPL], rs_[RB][CPL], po[RB][CPL];
+    float mus[RB], rss[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      mus[b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mr, (int)(row * 4u), (int)(b * stride * 4u), 0));
+      rss[b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (int)(row * 4u), (int)(b * stride * 4u), 0));
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        rx[b][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(voff + cb[k]), (int)(b * strideb), PFR_LNB_NT));
+        rd[b][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dyr, (int)(voff + cb[k]), (int)(b * strideb), PFR_LNB_NT));
+        rs_[b][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(voff + cb[k]), (int)(b * strideb), PFR_LNB_NT));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const float mu = mus[b], rs = rss[b];
+      float xh[CPL][KP], dv[CPL][KP];
+      float a = 0.f, bsum = 0.f;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        Chunk<T>::unpack(rx[b][k], xh[k]);
+        Chunk<T>::unpack(rd[b][k], dv[k]);
+        const float* gp = sgam + (okc[k] ? sub + G * k : 0) * KP;
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          xh[k][e] = okc[k] ? (xh[k][e] - mu) * rs : 0.f;
+          const float g = dv[k][e] * gp[e];
+          a += g;
+          bsum = fmaf(g, xh[k][e], bsum);
+        }
+      }
+      a = ln_group_sum<G>(a);
+      bsum = ln_group_sum<G>(bsum);
+      a *= invC;
+      bsum *= invC;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        float r[KP], o[KP];
+        Chunk<T>::unpack(rs_[b][k], r);
+        const float* gp = sgam + (okc[k] ? sub + G * k : 0) * KP;
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          float v = rs * (dv[k][e] * gp[e] - a - xh[k][e] * bsum);
+          if (dres) v += r[e];
+          o[e] = okc[k] ? v : 0.f;
+          ag[k][e] = fmaf(dv[k][e], xh[k][e], ag[k][e]);
+          ab[k][e] += dv[k][e];
+        }
+        po[b][k] = Chunk<T>::pack(o);
+        if (dxsum) {   // Σ rows of dx AS STORED: the bias gradient of the layer that produced this LayerNorm's input
+          Chunk<T>::unpack(po[b][k], o);
+#pragma unroll
+          for (int e = 0; e < KP; ++e) ad[k][e] += o[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) buffer_store_b128_sync(po[b][k], dxr, voff + cb[k], b * strideb);
+  }
+  // lane groups of the wave own the same channels: fold them (xor offsets ≥ G), then the 4 waves through LDS
+#pragma unroll
+  for (int k = 0; k < CPL; ++k)
+#pragma unroll
+    for (int e = 0; e < KP; ++e)
+      for (int o = G; o < 64; o <<= 1) {
+        ag[k][e] += __shfl_xor(ag[k][e], o, 64);
+        ab[k][e] += __shfl_xor(ab[k][e], o, 64);
+        if (dxsum) ad[k][e] += __shfl_xor(ad[k][e], o, 64);
+      }
+  if (grp == 0) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      if (okc[k]) {
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          sh[(wave * 3 + 0) * C + (sub + G * k) * KP + e] = ag[k][e];
+          sh[(wave * 3 + 1) * C + (sub + G * k) * KP + e] = ab[k][e];
+          sh[(wave * 3 + 2) * C + (sub + G * k) * KP + e] = ad[k][e];
+        }
+      }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < (dxsum ? 3 : 2) * C; c += 256) {
+    const int q = c / C, cc = c % C;
+    const float v = sh[(0 * 3 + q) * C + cc] + sh[(1 * 3 + q) * C + cc] + sh[(2 * 3 + q) * C + cc] + sh[(3 * 3 + q) * C + cc];
+    if (q < 2) part[((size_t)q * gridDim.x + blockIdx.x) * C + cc] = v;
+    else dxsum[(size_t)blockIdx.x * C + cc] = v;
+  }
+}
+
 extern "C" int pfr_layernorm_bwd_blocks(long rows) {
   long nb = (rows + 15) / 16;   // >= 4 rows per wave: the row loop is latency-bound, so favour many resident waves
   if (nb > 1024) nb = 1024;     // (measured: 1024 workgroups 0.73 ms per Swin-T step, 2048 0.79, 512 0.87)  grid-stride kernels: the partial rows [2][nb][C] are summed by pfr_colsum afterwards
@@ -443,9 +600,13 @@ extern "C" int pfr_layernorm_bwd_dxsum(const void* dy, const void* x, const floa
     LnGeom g;
     const int kp = dtype == PFR_BF16 ? 8 : 4;
     if (ln_geom(C, kp, &g)) {
-      const size_t shb = (size_t)12 * C * sizeof(float);
+      const size_t shb = (size_t)13 * C * sizeof(float);
+      const bool small = (double)rows * C * (dtype == PFR_BF16 ? 2 : 4) < 1.5e9;   // 32-bit buffer offsets
 #define PFR_LNB(TT, K, GG)                                                                                              \
-  if (g.cpl == K && g.G == GG) hipLaunchKernelGGL((layernorm_bwd2_kernel<TT, K, GG>), dim3(nb), dim3(256), shb, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, part, dxsum_part, rows, C, g.cpr);
+  if (g.cpl == K && g.G == GG) {                                                                                        \
+    if (small) hipLaunchKernelGGL((layernorm_bwd3_kernel<TT, K, GG>), dim3(nb), dim3(256), shb, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, part, dxsum_part, rows, C, g.cpr); \
+    else hipLaunchKernelGGL((layernorm_bwd2_kernel<TT, K, GG>), dim3(nb), dim3(256), shb, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, part, dxsum_part, rows, C, g.cpr); \
+  }
 #define PFR_LNB_ALL(TT) PFR_LNB(TT, 1, 16) PFR_LNB(TT, 1, 32) PFR_LNB(TT, 1, 64) PFR_LNB(TT, 2, 64) PFR_LNB(TT, 3, 64) PFR_LNB(TT, 4, 64)
       if (dtype == PFR_BF16) { PFR_LNB_ALL(bf16_t) }
       else { PFR_LNB_ALL(float) }

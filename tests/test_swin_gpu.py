@@ -204,6 +204,46 @@ def test_gemm_with_fused_gelu_epilogues(dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(64, 96), (1000, 96), (401408, 96), (100, 192), (25088, 384), (2, 768), (3, 768), (6272, 768), (37, 1024), (5000, 32)])
+@pytest.mark.parametrize("use_res", [1, 0])
+def test_layernorm_shapes_vs_torch(dtype, rows, C, use_res):
+    """pfr_layernorm_fwd / pfr_layernorm_bwd_dxsum against torch over the batch / lane-group geometries of the kernels: one to four
+    16-byte chunks per lane, rows that do not fill the last batch of a workgroup, lanes past the row's last chunk (C = 96, 192, 384: the
+    range-checked buffer addressing reads zeros there and drops the stores), with and without the residual gradient
+    (reference: nn.LayerNorm of /root/reference/models/swin.py:28-36 PreNorm)"""
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    dev = "cuda:0"
+    st = torch.cuda.current_stream().cuda_stream
+    did = dtype_id(dtype)
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).to(dev, dtype)
+    dy = torch.randn(rows, C, generator=g).to(dev, dtype)
+    res = torch.randn(rows, C, generator=g).to(dev, dtype)
+    gam = (torch.rand(C, generator=g) + 0.5).to(dev)
+    bet = (torch.randn(C, generator=g) * 0.1).to(dev)
+    xr = x.float().clone().requires_grad_(True); gr = gam.clone().requires_grad_(True); br = bet.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    y.backward(dy.float())
+    yd = torch.empty_like(x); mu = torch.empty(rows, device=dev); rs = torch.empty(rows, device=dev)
+    lib.pfr_layernorm_fwd(x.data_ptr(), gam.data_ptr(), bet.data_ptr(), yd.data_ptr(), mu.data_ptr(), rs.data_ptr(), did, rows, C, 1e-5, st)
+    nb = lib.pfr_layernorm_bwd_blocks(rows)
+    part = torch.empty(2, nb, C, device=dev); dx = torch.empty_like(x)
+    ok = lib.pfr_layernorm_bwd_dxsum_ok(did, C)
+    dsum = torch.empty(nb, C, device=dev) if ok else None
+    lib.pfr_layernorm_bwd_dxsum(dy.data_ptr(), x.data_ptr(), mu.data_ptr(), rs.data_ptr(), gam.data_ptr(), res.data_ptr() if use_res else 0,
+                                dx.data_ptr(), part.data_ptr(), dsum.data_ptr() if ok else 0, did, rows, C, st)
+    torch.cuda.synchronize()
+    t = 3e-2 if dtype == torch.bfloat16 else 1e-4
+    assert rel(yd, y.detach()) < t
+    assert rel(mu, x.float().mean(1)) < 1e-4 and rel(rs, (x.float().var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-4
+    assert rel(dx, xr.grad + (res.float() if use_res else 0)) < t
+    assert rel(part[0].sum(0), gr.grad) < t and rel(part[1].sum(0), br.grad) < t
+    if ok:
+        assert rel(dsum.sum(0), dx.float().sum(0)) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,C", [(300, 96), (4099, 192), (257, 768)])
 def test_layernorm_bwd_dxsum_partials(dtype, rows, C):
     """pfr_layernorm_bwd_dxsum: dx and the dγ/dβ partials are those of pfr_layernorm_bwd, and the extra partial rows sum to the
