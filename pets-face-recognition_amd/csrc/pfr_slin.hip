@@ -30,7 +30,9 @@
 //     of the Linear in front), one partial row per row range, reduced in a fixed order without atomics.
 // Measured: profiles/r05_slin.txt (1.08-1.55x the tile kernel cold, Swin-T step -3.4 %), race screen tools/slin_stress.py.
 #include "pfr_igemm.h"
-#ifndef PFR_SLIN_NT   // A/B builds: -DPFR_SLIN_NT='" nt"' marks the row loads non-temporal — measured: Swin-T step 11.85 -> 11.57 k img/s, off
+#ifdef PFR_SLIN_NT_ON   // A/B builds (-DPFR_SLIN_NT_ON): the row loads non-temporal — measured inside the Swin-T step: profiles/r05_ln.txt; off
+#define PFR_SLIN_NT " nt"
+#else
 #define PFR_SLIN_NT ""
 #endif
 
