@@ -808,11 +808,15 @@ static int pick_tile(int M, int Cout, int K, int dtype, int out_dtype, int* bq) 
   // (8-wave tiles for K < 512 and 64-row tiles for the short-K layers were measured: no gain / slower)
   if (allow_big && dtype == PFR_BF16 && out_dtype == PFR_BF16 && K >= 512 && (K % 64) == 0) {
     const long t256 = (long)((M + 255) / 256);
-    if (Cout >= 192 && t256 * ((Cout + 255) / 256) >= 160) { *bq = 256; return TILE_256x256; }
+    // one 8-wave tile per CU: a launch of T tiles runs ceil(T / 256) rounds — 257..365 tiles (a second round less than 43 % full) go to
+    // the 4-wave tiles instead (Swin-T stage 4, 6272 x 768 -> 3072: 300 tiles, 79 / 103 us against 71 / 88 us for GELU / GELU backward)
+    const long T = t256 * ((Cout + 255) / 256);
+    const bool rounds_ok = T * 10 >= ((T + 255) / 256) * 256 * 7;
+    if (Cout >= 192 && T >= 160 && rounds_ok) { *bq = 256; return TILE_256x256; }
     // (Cout = 128, a single column of 256x128 tiles, loses 10-17 % to the 128x128 tile: tools/tile_sweep.py)
     // (round 5: a 256x192 tile — no idle columns at Cout = 192 / 384 / 576, the Swin widths — was bit-identical and within 1 % of the
     //  256x256 tile on every Swin-T geometry, 65.6 vs 65.9 us at 25088 x 1536 -> 384: the idle quarter is not what bounds them)
-    if (Cout >= 256 && t256 * ((Cout + 127) / 128) >= 320) { *bq = 256; return TILE_256x128; }
+    if (rounds_ok && Cout >= 256 && t256 * ((Cout + 127) / 128) >= 320) { *bq = 256; return TILE_256x128; }
   }
   const int bp = Cout > 64 ? 128 : 64;   // (Cout = 96: the 128-wide tile with a quarter of its columns idle still wins by ~10 %)
   const long tiles128 = (long)((M + 127) / 128) * ((Cout + bp - 1) / bp);

@@ -2,7 +2,7 @@
 under every forced tile of the tile kernel and the streaming kernel (slin = 2), cold operands.   python tools/gemm_act_tiles.py"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pets_face_recognition_amd._hip import lib
+from pets_face_recognition_amd._hip import lib, ops
 TILES = {-1: "heur", 0: "128x128", 1: "64x128", 4: "256x256", 5: "256x128"}
 big = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
@@ -12,8 +12,12 @@ for M, K, N in [(25088, 384, 1536), (6272, 768, 3072), (100352, 192, 768)]:
     bias = torch.randn(N, device="cuda")
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     y2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16).normal_()
-    for form, act, bp in (("gelu", 2, bias.data_ptr()), ("gelu_bwd", 3, 0)):
-        run = lambda: lib.pfr_gemm_act(x.data_ptr(), w.data_ptr(), y.data_ptr(), 1, M, K, N, bp, act, y2.data_ptr(), st)
+    for form, act, bp in (("bias", 0, bias.data_ptr()), ("gelu", 2, bias.data_ptr()), ("gelu_bwd", 3, 0)):
+        if act == 0:
+            x4, w4, y4 = x.view(M, 1, 1, K), w.view(N, 1, 1, K), y.view(M, 1, 1, N)
+            run = lambda: ops.conv2d_fwd(x4, w4, bias=bias, out=y4)
+        else:
+            run = lambda: lib.pfr_gemm_act(x.data_ptr(), w.data_ptr(), y.data_ptr(), 1, M, K, N, bp, act, y2.data_ptr(), st)
         out = []
         for slin, tile in [(0, t) for t in TILES] + [(2, -1)]:
             lib.pfr_set_tuning(b"slin", slin); lib.pfr_set_tuning(b"igemm_tile", tile)
