@@ -373,7 +373,9 @@ static int slin_launch(IgemmParams& p, int dtype, int out_dtype, float* colsum, 
   const int K = p.K, N = p.Cout, M = p.M;
   if (K % 96 || K > 768 || N % 32 || N < 64) return 1;
   if ((long)M * K * 2 >= (1L << 31) || (long)M * N * 2 >= (1L << 31) || M < 4096) return 1;
-  if (mode == 1 && M < 65536) return 1;
+  // below 65536 rows only the Swin-T stage-3 shapes it wins cold by 8-20 % (25088 x 384 -> 1536 all forms, -> 384 with residual; tools/gemm_act_tiles.py)
+  const bool st3 = M >= 16384 && M < 65536 && K == 384 && (N == 1536 || N == 384);
+  if (mode == 1 && M < 65536 && !st3) return 1;
   // panel: the widest of 192 / 96 / 64 couts that divides N and fits the LDS next to the waves' tiles
   constexpr int XBUF = 32 * 208;                   // a wave's chunk buffer
   const int force = pfr_knob(KNOB_SLIN_NP);        // experiments: force the panel width (0: the widest that fits)
@@ -387,7 +389,8 @@ static int slin_launch(IgemmParams& p, int dtype, int out_dtype, float* colsum, 
   if (!np) return 1;
   // Measured inside the Swin-T step (warm operands, tools/swin_ab.sh + bench.py --detail, profiles/r05_slin.txt): the 8-wave forms
   // (64- / 96-cout panels) win 15-25 % over the tile kernel; the 4-wave 192-cout-panel form loses 10-30 % and is kept for experiments only.
-  if (mode == 1 && p.act != 0 && K != 96) return 1;      // (fused GELU at K = 192: 133 vs 130 us for the tile kernel; at K = 96: 183 vs 222)
+  // (round 5, same-box A/B of the step: + GELU backward at K = 192 (118 vs 148 us cold) and the stage-3 forms: 11708 -> 11735 img/s)
+  if (mode == 1 && p.act != 0 && K != 96 && !st3 && !(K == 192 && p.act == 3)) return 1;      // (fused GELU at K = 192: 133 vs 130 us for the tile kernel; at K = 96: 183 vs 222)
   const int nw = np == 192 ? 4 : 8;
   const int lds = ((np * (K * 2 + 16) + 127) & ~127) + nw * XBUF;
   const int npanels = N / np;
