@@ -1069,6 +1069,9 @@ __device__ __forceinline__ void wa_store_tile(char* stage, const f32x16& acc, fl
   __builtin_amdgcn_wave_barrier();
 }
 
+// (round 5: a PERSISTENT form — one wave walking its XCD's units with the next unit's q / k / v rows and bias rows in flight during the
+//  current unit's products, 216 instead of 156 VGPRs — was bit-identical and slower: 111 vs 101 us at 128 x 56² x 3 heads cold, 65 vs 60 at
+//  28², no difference inside the Swin-T step.  The kernel is bound by instruction issue at 2-3 waves per SIMD, not by the exposed loads.)
 __global__ __launch_bounds__(64) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ tab,
                                                                   bf16_t* __restrict__ out, WinAttn a) {
   __shared__ __attribute__((aligned(16))) char lq[64 * WA_RS], lk[64 * WA_RS], lv[64 * WA_RS], lo[32 * WA_TS];
