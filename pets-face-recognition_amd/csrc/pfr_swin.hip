@@ -695,7 +695,20 @@ extern "C" int pfr_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, 
 struct WinAttn {
   int B, H, W, heads, hd, w, shift;  // shift = displacement d (0 for regular blocks)
   float scale;
+  // windows per column / row and multiply-shift reciprocals of the divisors of the unit / token decode (a workgroup is one wave and one
+  // (window, head): its ~0.5 µs of index arithmetic — five integer divisions by run-time values, ~150 instructions — ran before the
+  // first load could be issued)
+  int nwh, nww;
+  FastDiv dheads, dnww, dnwh, dw;
 };
+static WinAttn wa_make(int B, int H, int W, int heads, int hd, int w, int shift, float scale) {
+  WinAttn a;
+  a.B = B; a.H = H; a.W = W; a.heads = heads; a.hd = hd; a.w = w; a.shift = shift; a.scale = scale;
+  a.nwh = H / w; a.nww = W / w;
+  a.dheads = make_fastdiv((uint32_t)heads); a.dnww = make_fastdiv((uint32_t)a.nww); a.dnwh = make_fastdiv((uint32_t)a.nwh);
+  a.dw = make_fastdiv((uint32_t)w);
+  return a;
+}
 
 // bias(+mask) table of one attention block: tab[variant][i][j], variant = 2*(last window row) + (last window column),
 // rows padded to WA_MAXT = 64 with −inf outside the w² x w² block (one tiny launch per block and step instead of integer
@@ -728,7 +741,8 @@ __global__ void window_bias_table_kernel(const float* __restrict__ pos, float* _
 }
 
 __device__ __forceinline__ size_t wa_token_off(const WinAttn& a, int b, int gy, int gx, int t) {
-  int y = gy * a.w + t / a.w + a.shift, x = gx * a.w + t % a.w + a.shift;
+  const int tr = (int)fdiv((uint32_t)t, a.dw);
+  int y = gy * a.w + tr + a.shift, x = gx * a.w + (t - tr * a.w) + a.shift;
   if (y >= a.H) y -= a.H;
   if (x >= a.W) x -= a.W;
   return ((size_t)b * a.H + y) * a.W + x;
@@ -1016,13 +1030,16 @@ __device__ __forceinline__ int wa_xcd_unit(int blk, int n) {
 }
 struct WaUnit { int b, gy, gx, h, var, unit; };
 __device__ __forceinline__ WaUnit wa_decode(const WinAttn& a, int unit) {
-  const int nwh = a.H / a.w, nww = a.W / a.w;
+  const int nwh = a.nwh, nww = a.nww;
   WaUnit u;
   u.unit = unit;
-  u.h = unit % a.heads; unit /= a.heads;
-  u.gx = unit % nww; unit /= nww;
-  u.gy = unit % nwh;
-  u.b = unit / nwh;
+  int q = (int)fdiv((uint32_t)unit, a.dheads);
+  u.h = unit - q * a.heads; unit = q;
+  q = (int)fdiv((uint32_t)unit, a.dnww);
+  u.gx = unit - q * nww; unit = q;
+  q = (int)fdiv((uint32_t)unit, a.dnwh);
+  u.gy = unit - q * nwh;
+  u.b = q;
   u.var = ((u.gy == nwh - 1) ? 2 : 0) + ((u.gx == nww - 1) ? 1 : 0);
   return u;
 }
@@ -1385,7 +1402,7 @@ extern "C" int pfr_window_attn_fwd(const void* qkv, const float* pos, void* out,
   PFR_CHECK_ARG(qkv && pos && out, "pfr_window_attn_fwd: null pointer");
   PFR_CHECK_ARG(head_dim % (dtype == PFR_BF16 ? 8 : 4) == 0, "pfr_window_attn_fwd: head_dim must be a multiple of the 16-byte chunk");
   if (int rc = wa_check(B, H, W, heads, head_dim, window, shift)) return rc;
-  WinAttn a{B, H, W, heads, head_dim, window, shift, scale};
+  const WinAttn a = wa_make(B, H, W, heads, head_dim, window, shift, scale);
   const dim3 grid((unsigned)(B * (H / window) * (W / window) * heads));
   if (wa_use_mfma(dtype, head_dim, window)) hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, pos, (bf16_t*)out, a);
   else if (dtype == PFR_BF16) hipLaunchKernelGGL(window_attn_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, pos, (bf16_t*)out, a);
@@ -1401,7 +1418,7 @@ extern "C" int pfr_window_attn_bwd(const void* qkv, const float* pos, const void
   PFR_CHECK_ARG(qkv && pos && dout && dqkv && dpos_part, "pfr_window_attn_bwd: null pointer");
   PFR_CHECK_ARG(head_dim % (dtype == PFR_BF16 ? 8 : 4) == 0, "pfr_window_attn_bwd: head_dim must be a multiple of the 16-byte chunk");
   if (int rc = wa_check(B, H, W, heads, head_dim, window, shift)) return rc;
-  WinAttn a{B, H, W, heads, head_dim, window, shift, scale};
+  const WinAttn a = wa_make(B, H, W, heads, head_dim, window, shift, scale);
   const dim3 grid((unsigned)(B * (H / window) * (W / window) * heads));
   if (wa_use_mfma(dtype, head_dim, window)) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, grid, dim3(64), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
   else if (dtype == PFR_BF16) hipLaunchKernelGGL(window_attn_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, pos, (const bf16_t*)dout, (bf16_t*)dqkv, dpos_part, a);
