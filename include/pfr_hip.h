@@ -332,6 +332,9 @@ int pfr_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, size_t n, p
  * masks (create_mask, models/swin.py:49-62,86-90,122-124); rebuild whenever pos changed */
 long pfr_window_bias_table_floats(int window);
 int pfr_window_bias_table(const float* pos, float* tab, int window, int shift, pfr_stream_t stream);
+/* the tables of n attention blocks in one launch; descs: DEVICE array of {const float* pos; float* tab; int window; int shift;}
+ * (24 bytes each; window * window <= 64 is the caller's to check) */
+int pfr_window_bias_table_batch(const void* descs, int n, pfr_stream_t stream);
 /* qkv [B][H][W][3*heads*head_dim] (q|k|v, each (head, d)); pos: the TABLE built by pfr_window_bias_table;
  * shift = cyclic displacement (0 or w/2); out [B][H][W][heads*head_dim] */
 int pfr_window_attn_fwd(const void* qkv, const float* pos, void* out, int dtype, int B, int H, int W, int heads, int head_dim,

@@ -1388,6 +1388,39 @@ extern "C" long pfr_window_bias_table_floats(int window) {
   (void)window;
   return 8L * WA_MAXT * WA_MAXT;   // natural [4][64][64] + the MFMA kernels' access-order copy
 }
+// the tables of n attention blocks in ONE launch (12 launches of ~6 µs per Swin-T step otherwise); descs: DEVICE array of BiasTabDesc
+struct BiasTabDesc {
+  const float* pos;
+  float* tab;
+  int w, shift;
+};
+__global__ void window_bias_table_batch_kernel(const BiasTabDesc* __restrict__ descs) {
+  const BiasTabDesc d = descs[blockIdx.y];
+  const int w = d.w, shift = d.shift, nt = w * w;
+  constexpr int ntp = WA_MAXT;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 4 * ntp * ntp) return;
+  const int var = e / (ntp * ntp), i = (e / ntp) % ntp, j = e % ntp;
+  float b = -INFINITY;
+  if (i < nt && j < nt) {
+    const int yi = i / w, xi = i % w, yj = j / w, xj = j % w;
+    b = d.pos[(yj - yi + w - 1) * (2 * w - 1) + (xj - xi + w - 1)];
+    if (shift) {
+      if ((var & 2) && ((yi >= w - shift) != (yj >= w - shift))) b = -INFINITY;
+      if ((var & 1) && ((xi >= w - shift) != (xj >= w - shift))) b = -INFINITY;
+    }
+  }
+  d.tab[e] = b;
+  d.tab[4 * ntp * ntp + wa_perm_index(var, i, j)] = b;
+}
+extern "C" int pfr_window_bias_table_batch(const void* descs, int n, hipStream_t st) {
+  PFR_CHECK_ARG(descs && n > 0 && n <= 65535, "pfr_window_bias_table_batch: bad args");
+  const long m = 4L * WA_MAXT * WA_MAXT;
+  hipLaunchKernelGGL(window_bias_table_batch_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)n), dim3(256), 0, st, (const BiasTabDesc*)descs);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
+}
+
 // tab: fp32 [4][64][64] (+ the permuted copy), recomputed whenever pos changes (once per block and step)
 extern "C" int pfr_window_bias_table(const float* pos, float* tab, int window, int shift, hipStream_t st) {
   PFR_CHECK_ARG(pos && tab && window * window <= WA_MAXT, "pfr_window_bias_table: bad args");

@@ -217,6 +217,7 @@ class SwinEngine:
         T, dev, did = self.dtype, self.device, self.did
         fwd, bwd = [], []
         bufs = []
+        tab_recs = []
 
         def A(shape, dtype=None):
             t = torch.empty(shape, dtype=dtype or T, device=dev)
@@ -291,7 +292,7 @@ class SwinEngine:
                 qkv = A((rows, 3 * C))
                 gemm(fwd, ln1, rows, C, b["qkv"], qkv)
                 att = A((rows, C))
-                fwd.append((lib.pfr_window_bias_table, (b["pos"].data_ptr(), b["tab"].data_ptr(), b["w"], b["shift"])))
+                tab_recs.append((b["pos"].data_ptr(), b["tab"].data_ptr(), b["w"], b["shift"]))
                 fwd.append((lib.pfr_window_attn_fwd, (qkv.data_ptr(), b["tab"].data_ptr(), att.data_ptr(), did, N, OH, OW,
                                                       b["heads"], b["hd"], b["w"], b["shift"], float(b["scale"]))))
                 y = A((rows, C))
@@ -322,6 +323,12 @@ class SwinEngine:
                                             hln.data_ptr(), hmu.data_ptr(), hrs.data_ptr(), did, N, Cf, float(self.head_ln.eps))))
         emb = A((N, self.emb_dim), torch.float32)
         gemm(fwd, hln, N, Cf, self.head_fc, emb)
+        # the bias(+mask) tables of every attention block in one launch at the head of the forward pass (their inputs, the relative-position
+        # tables, only change in the optimiser step)
+        import struct
+        tabd = torch.frombuffer(bytearray(b"".join(struct.pack("<QQii", *r) for r in tab_recs)), dtype=torch.uint8).to(dev)
+        bufs.append(tabd)
+        fwd.insert(0, (lib.pfr_window_bias_table_batch, (tabd.data_ptr(), len(tab_recs))))
         plan = {"fwd": fwd, "bufs": bufs, "x_nhwc": x_nhwc, "emb": emb}
         if not with_backward:
             return plan

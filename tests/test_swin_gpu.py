@@ -405,3 +405,27 @@ def test_streaming_linear_gelu_backward_with_column_sums(rows, K, N):
     lib.pfr_colsum_final_batch(tab.data_ptr(), 1, N, st)
     torch.cuda.synchronize()
     assert torch.allclose(out, got, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_bias_tables_of_all_blocks_in_one_launch_equal_the_per_block_launches():
+    """pfr_window_bias_table_batch (one launch per forward pass) writes what pfr_window_bias_table writes per block: regular and shifted
+    windows, both copies of the table (models/swin.py:65-70,93-95 relative position bias, :49-62,86-90 shifted-window masks)"""
+    import struct
+    from pets_face_recognition_amd._hip import lib
+    dev = "cuda:0"
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(11)
+    w = 7
+    n = lib.pfr_window_bias_table_floats(w)
+    blocks = [(torch.randn(2 * w - 1, 2 * w - 1, generator=g).to(dev), s) for s in (0, 3, 0, 3, 0)]
+    one = [torch.full((n,), float("nan"), device=dev) for _ in blocks]
+    allb = [torch.full((n,), float("nan"), device=dev) for _ in blocks]
+    for (pos, s), t in zip(blocks, one):
+        lib.pfr_window_bias_table(pos.data_ptr(), t.data_ptr(), w, s, st)
+    raw = b"".join(struct.pack("<QQii", pos.data_ptr(), t.data_ptr(), w, s) for (pos, s), t in zip(blocks, allb))
+    descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    lib.pfr_window_bias_table_batch(descs.data_ptr(), len(blocks), st)
+    torch.cuda.synchronize()
+    for a, b in zip(one, allb):
+        assert torch.equal(a, b) and not torch.isnan(a).any()
