@@ -996,19 +996,30 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
 // of the accumulator rows is (r&3) + 8(r>>2) + 4(lane>>5); the A operand (Vᵀ, Kᵀ, Qᵀ, dOᵀ) is read from a natural
 // [token][d] LDS tile with ds_read_b64_tr_b16 at exactly those rows, so the reduction index is permuted identically on
 // both sides.
-#define WA_RS 80   // LDS row stride in bytes of a [64 tokens][32 d] bf16 tile (64 B + 16 B pad)
+// [64 tokens][32 d] bf16 tiles: UNPADDED 64-byte rows whose four 16-byte chunks are XOR-swizzled with (row >> 2) & 3 (round 5).  Both read
+// patterns are then bank-conflict free: the row fragments (ds_read_b128, 16-lane groups of rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}:
+// rows with equal row % 4 share a 16-dword bank window and differ in (row >> 2) & 3, i.e. in the chunk position) and the transposed
+// fragments (ds_read_b64_tr_b16, four consecutive rows x 16 dwords per 32-lane group: same swizzle value, windows 0-15 / 16-31 / 32-47 /
+// 48-63).  The 80-byte padded rows before were conflict free for the row fragments only: PMC SQ_LDS_BANK_CONFLICT was 36 % (forward) /
+// 31 % (backward) of SQ_LDS_IDX_ACTIVE, and the LDS array the busiest unit of both kernels.
+#define WA_RS 64
+__device__ __forceinline__ int wa_swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
 __device__ __forceinline__ bf16x8 wa_rowfrag(const char* tile, int tok_tile, int ks, int lane) {
   // A/B operand with the reduction over d: row (token) = lane&31 (+32·tok_tile), d = 16·ks + 8·(lane>>5) … +7
-  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + ((lane & 31) + 32 * tok_tile) * WA_RS + (16 * ks + 8 * (lane >> 5)) * 2));
+  const int row = (lane & 31) + 32 * tok_tile;
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + row * WA_RS + wa_swz(row, 2 * ks + (lane >> 5)) * 16));
 }
 __device__ __forceinline__ bf16x8 wa_trfrag(const char* tile, int tok_tile, int t, int lane) {
   // A operand [M = d][K = token] from the [token][d] tile: lane (d = lane&31, half = lane>>5), reduction slots e = 0..7 ↔
   // token 32·tok_tile + 16·t + 8·(e>>2) + 4·half + (e&3)   (the accumulator-row order, see above)
   const int g = lane >> 4, s4 = lane & 15;
-  const char* a = tile + (32 * tok_tile + 16 * t + (g >> 1) * 4 + (s4 >> 2)) * WA_RS + ((g & 1) * 16 + (s4 & 3) * 4) * 2;
+  // 8 bytes at (row, d = 16·(g&1) + 4·(s4&3) …): chunk 2·(g&1) + ((s4&3) >> 1), second half of the chunk for odd s4&3
+  const int row = 32 * tok_tile + 16 * t + (g >> 1) * 4 + (s4 >> 2), ch = 2 * (g & 1) + ((s4 & 3) >> 1), off = (s4 & 1) * 8;
+  const char* a = tile + row * WA_RS + wa_swz(row, ch) * 16 + off;
+  const char* b = tile + (row + 8) * WA_RS + wa_swz(row + 8, ch) * 16 + off;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 8 * WA_RS));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b));
   u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
   u32x4 u = {l2[0], l2[1], h2[0], h2[1]};
   return __builtin_bit_cast(bf16x8, u);
@@ -1057,7 +1068,7 @@ __device__ __forceinline__ void wa_load_tile(char* tile, const bf16_t* base, con
     const int tk = toff[row];
     u32x4 v = ld16(base + (size_t)(tk < 0 ? ~tk : tk) * rowstride + ch * 8);
     if (tk < 0) v = u32x4{0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(tile + row * WA_RS + ch * 16) = v;
+    *reinterpret_cast<u32x4*>(tile + row * WA_RS + wa_swz(row, ch) * 16) = v;
   }
 }
 
