@@ -24,6 +24,16 @@
 // Results are bit-identical to igemm_kernel's (same k order inside and across MFMAs); statistics partials differ only in how the
 // rows are grouped.
 #include "pfr_igemm.h"
+// Non-temporal hint on the epilogue operand rows: the residual-gradient rows of the data-gradient joins (their last use) and the
+// BatchNorm-input rows of the launches that leave the BatchNorm-backward sums (next read 100+ MB of traffic later).  Same-box A/B of the
+// ResNet-50 step, six interleaved pairs (tools/lib_ab.sh): +0.18 % (+2 … +71 img/s, never negative).  -DPFR_SCONV_NT_OFF: plain loads.
+#ifdef PFR_SCONV_NT_OFF
+#define PFR_SCONV_RES_NT ""
+#define PFR_SCONV_BNX_NT ""
+#else
+#define PFR_SCONV_RES_NT " nt"
+#define PFR_SCONV_BNX_NT " nt"
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
             rso = 0;
           }
           // (s_nop: the scalar offsets come straight from the SALU; nothing inside an asm statement is padded by the compiler)
-          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" PFR_SCONV_RES_NT
                        : "=v"(rres[g][ps])
                        : "v"(rvo), "s"(rrsrc), "s"(rso)
                        : "memory");
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
       for (int g = 0; g < NCG; ++g)
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
-          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" PFR_SCONV_BNX_NT
                        : "=v"(cxr[g][ps])
                        : "v"(y_lane + (uint32_t)(g * 128)), "s"(cxrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
                        : "memory");
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void sconv_kernel(SconvParams p) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           if constexpr (!NOX)
-            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" PFR_SCONV_BNX_NT
                          : "=v"(bxr[g][ps])
                          : "v"(y_lane + (uint32_t)(g * 128)), "s"(bxrsrc), "s"(rbase + (uint32_t)(ps * 8 * p.N * 2))
                          : "memory");
