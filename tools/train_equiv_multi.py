@@ -3,7 +3,7 @@
 which 64 x 64 images never reach), 40 epochs x 50 steps = 2000 optimizer steps, base rate 0.005 with 5 warm-up epochs.
 Variants: fp32 | bf16 (default: BN-input-free form + Gram statistics) | bf16 with PFR_BNFREE=0 (stored form), each with TWO data-order /
 initialisation seeds: the seed-to-seed spread of one precision is the yardstick for the gap between precisions.
-usage: python tools/train_equiv_multi.py [tag] [epochs] [image_size] [n_val_ids] [seeds, e.g. 3,4] [variants, e.g. f32,bf16]
+usage: python tools/train_equiv_multi.py [tag] [epochs] [image_size] [n_val_ids] [seeds, e.g. 3,4] [variants, e.g. f32,bf16] [workers] [arch]
        -> gpurun_out/<tag>_train_equiv_multi.json (rewritten after every run: a run is 12-17 minutes at 224 x 224, loader-bound)"""
 import json, os, re, subprocess, sys, tempfile, textwrap, time
 
@@ -15,6 +15,7 @@ n_val = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 seeds = tuple(int(v) for v in sys.argv[5].split(",")) if len(sys.argv) > 5 else (3, 4)
 only = sys.argv[6].split(",") if len(sys.argv) > 6 and sys.argv[6] != "all" else None
 workers = int(sys.argv[7]) if len(sys.argv) > 7 else 0      # loader workers (0 = the seed-3 record's setting; the data order does not depend on it)
+arch = sys.argv[8] if len(sys.argv) > 8 else "resnet50"     # "swin_t": BASELINE config 4 (the bf16_stored variant does not apply)
 common = os.path.join(ROOT, "pets-face-recognition_amd", "configs", "synthetic")
 VARIANTS = [("f32", "torch.float32", {}), ("bf16", "torch.bfloat16", {}), ("bf16_stored", "torch.bfloat16", {"PFR_BNFREE": "0"})]
 runs = {}
@@ -28,7 +29,7 @@ for seed in seeds:
                 import sys, torch
                 sys.path.insert(0, {common!r})
                 from _common import make as _make
-                _make(globals(), arch='resnet50', n_train_ids=200, n_val_ids={n_val}, photos=8, image_size={size}, train_bs=32,
+                _make(globals(), arch={arch!r}, n_train_ids=200, n_val_ids={n_val}, photos=8, image_size={size}, train_bs=32,
                       test_bs=64, device='cuda:0', n_epochs={epochs}, n_pairs=400, compute_dtype={dt}, seed={seed}, noise=1.0, workers={workers})
                 init_lr = 0.005
                 trainer_kwargs = dict(trainer_kwargs, check_val_every_n_epoch={max(1, epochs // 8)})
@@ -65,7 +66,7 @@ for m in metrics:
         summary[m]["bf16_minus_f32"] = round(mean["bf16"] - mean["f32"], 4)
     if "bf16" in mean and "bf16_stored" in mean:
         summary[m]["bf16_minus_bf16_stored"] = round(mean["bf16"] - mean["bf16_stored"], 4)
-out = {"workload": f"resnet50 + ArcFace(200 ids), synthetic {size}x{size} (pattern + N(0,1) noise), bs 32, {epochs} epochs x 50 steps, FusedSGD base rate 0.005, "
+out = {"workload": f"{arch} + ArcFace(200 ids), synthetic {size}x{size} (pattern + N(0,1) noise), bs 32, {epochs} epochs x 50 steps, FusedSGD base rate 0.005, "
                    f"5 warm-up epochs, decay at 70 % / 90 %, main.py --config; validation on {n_val * 8} images of {n_val} held-out ids",
        "steps": epochs * 50, "final_validation": summary, "runs": runs}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
