@@ -429,3 +429,29 @@ def test_bias_tables_of_all_blocks_in_one_launch_equal_the_per_block_launches():
     torch.cuda.synchronize()
     for a, b in zip(one, allb):
         assert torch.equal(a, b) and not torch.isnan(a).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C", [(1000, 96), (100352, 192), (777, 384)])
+def test_layernorm_forward_rows_in_flight_knob_is_bit_identical(rows, C):
+    """the `ln_rb` knob (rows in flight per lane group of pfr_layernorm_fwd: 4 | 6 | 8) only changes which rows a workgroup takes"""
+    from pets_face_recognition_amd._hip import lib, dtype_id
+    dev = "cuda:0"
+    st = torch.cuda.current_stream().cuda_stream
+    did = dtype_id(torch.bfloat16)
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, C, generator=g) * 1.5 - 0.2).to(dev, torch.bfloat16)
+    gam = (torch.rand(C, generator=g) + 0.5).to(dev); bet = (torch.randn(C, generator=g) * 0.1).to(dev)
+    outs = []
+    try:
+        for rb in (4, 6, 8):
+            assert lib.pfr_set_tuning(b"ln_rb", rb) == 0
+            y = torch.full_like(x, float("nan")); mu = torch.full((rows,), float("nan"), device=dev); rs = torch.full((rows,), float("nan"), device=dev)
+            lib.pfr_layernorm_fwd(x.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), mu.data_ptr(), rs.data_ptr(), did, rows, C, 1e-5, st)
+            torch.cuda.synchronize()
+            outs.append((y, mu, rs))
+    finally:
+        lib.pfr_set_tuning(b"ln_rb", 4)
+    for y, mu, rs in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(mu, outs[0][1]) and torch.equal(rs, outs[0][2])
+    assert not torch.isnan(outs[0][0].float()).any()
