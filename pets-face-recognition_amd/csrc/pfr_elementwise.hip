@@ -1200,6 +1200,61 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// The same gather for even H, W in 2 x 2 INPUT-pixel blocks (round 5): the four pixels of a block lie in the windows (a, b), (a, b+1), (a+1, b),
+// (a+1, b+1) only, so one thread loads those four (dy chunk, argmax bytes) pairs once — 8 loads per 4 outputs instead of 32, of which
+// 14 went to clamped, unused windows — and adds them per pixel in the order of maxpool_bwd_kernel (window rows high to low, columns high to
+// low): bit-identical.  Pixel (2a, 2b) takes tap 4 of W00; (2a, 2b+1) tap 3 of W01, tap 5 of W00; (2a+1, 2b) tap 1 of W10, tap 7 of W00;
+// (2a+1, 2b+1) tap 0 of W11, 2 of W10, 6 of W01, 8 of W00.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd2x2_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                             T* __restrict__ dz, int N, int H, int W, int C, int OH, int OW) {
+  constexpr int KP = DT<T>::KPACK;
+  const int cpr = C / KP, H2 = H >> 1, W2 = W >> 1;
+  const size_t nblk = (size_t)N * H2 * W2 * cpr;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nblk; i += stride) {
+    const int cc = (int)(i % cpr);
+    size_t t = i / cpr;
+    const int b = (int)(t % W2); t /= W2;
+    const int a = (int)(t % H2);
+    const int n = (int)(t / H2);
+    u32x4 gv[4];
+    uint64_t pk[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // q = 2 * (window row a + (q >> 1)) + (window column b + (q & 1)); clamped loads, all issued before use
+      const int oh = a + (q >> 1), ow = b + (q & 1);
+      ok[q] = oh < OH && ow < OW;
+      const size_t o = (((size_t)n * OH + min(oh, OH - 1)) * OW + min(ow, OW - 1)) * cpr + cc;
+      gv[q] = ld16(dy + o * KP);
+      if constexpr (KP == 8) pk[q] = *reinterpret_cast<const uint64_t*>(idx + o * 8);
+      else pk[q] = *reinterpret_cast<const uint32_t*>(idx + o * 4);
+    }
+    float g[4][KP];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Chunk<T>::unpack(gv[q], g[q]);
+    // per output pixel: (window, tap) pairs in the accumulation order of maxpool_bwd_kernel
+    constexpr int NWIN[4] = {1, 2, 2, 4};
+    constexpr int WIN[4][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, 0, 0, 0}, {3, 2, 1, 0}};
+    constexpr int TAP[4][4] = {{4, 0, 0, 0}, {3, 5, 0, 0}, {1, 7, 0, 0}, {0, 2, 6, 8}};
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float acc[KP];
+#pragma unroll
+      for (int e = 0; e < KP; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NWIN[px]; ++k) {
+        const int q = WIN[px][k], tap = TAP[px][k];
+#pragma unroll
+        for (int e = 0; e < KP; ++e) acc[e] += (ok[q] && (int)((pk[q] >> (8 * e)) & 0xff) == tap) ? g[q][e] : 0.f;
+      }
+      const size_t o = (((size_t)n * H + 2 * a + (px >> 1)) * W + 2 * b + (px & 1)) * cpr + cc;
+      st16(dz + o * KP, Chunk<T>::pack(acc));
+    }
+  }
+}
+
 extern "C" int pfr_maxpool_bwd(const void* dy, const uint8_t* idx, void* dz, int dtype, int N, int H, int W, int C,
                                hipStream_t st) {
   PFR_CHECK_ARG(dy && idx && dz, "pfr_maxpool_bwd: null pointer");
@@ -1208,6 +1263,16 @@ extern "C" int pfr_maxpool_bwd(const void* dy, const uint8_t* idx, void* dz, int
   const size_t nch = (size_t)N * H * W * (C / kp);
   unsigned blocks = (unsigned)((nch + 255) / 256);
   if (blocks > 16384) blocks = 16384;
+  if (H % 2 == 0 && W % 2 == 0) {
+    unsigned b2 = (unsigned)((nch / 4 + 255) / 256);
+    if (b2 > 16384) b2 = 16384;
+    if (dtype == PFR_BF16)
+      hipLaunchKernelGGL(maxpool_bwd2x2_kernel<bf16_t>, dim3(b2), dim3(256), 0, st, (const bf16_t*)dy, idx, (bf16_t*)dz, N, H, W, C, OH, OW);
+    else
+      hipLaunchKernelGGL(maxpool_bwd2x2_kernel<float>, dim3(b2), dim3(256), 0, st, (const float*)dy, idx, (float*)dz, N, H, W, C, OH, OW);
+    PFR_CHECK_LAUNCH();
+    return PFR_OK;
+  }
   if (dtype == PFR_BF16)
     hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, idx, (bf16_t*)dz, N, H, W, C, OH, OW);
   else

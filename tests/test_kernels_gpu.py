@@ -245,6 +245,33 @@ def test_bn_relu_maxpool_and_avgpool(dtype):
     assert torch.allclose(d.float().cpu(), (p.float().cpu() / 49)[:, None, None, :].expand(N, 7, 7, 256), **tol(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 17, 17), (2, 64, 18, 22), (1, 64, 112, 112), (2, 16, 6, 4)])
+def test_maxpool_backward_even_and_odd_sizes(dtype, N, C, H, W):
+    """pfr_maxpool_bwd against torch on the sizes of both of its kernels: even H, W take the 2 x 2 input-block gather (112 x 112 is the
+    stem's), odd ones the per-pixel gather (reference: nn.MaxPool2d(3, 2, 1) of torchvision's ResNet stem, models/__init__.py backbones)"""
+    o = ops()
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.5
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    z = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    if dtype == torch.bfloat16:
+        z = z.bfloat16().float()
+    z.requires_grad_(True)
+    y = F.max_pool2d(z, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    y.backward(dy)
+    yd, idx = o.bn_relu_maxpool_fwd(nhwc(x).to(DEV, dtype), sc.to(DEV), sh.to(DEV))
+    dz = o.maxpool_bwd(nhwc(dy).to(DEV, dtype), idx, (H, W))
+    torch.cuda.synchronize()
+    assert rel_err(dz.cpu(), nhwc(z.grad)) < (1e-2 if dtype == torch.bfloat16 else 1e-6)
+
+
 def _arcface_ref(x, w, label, s, m, easy, cosface=False, gamma=0.0):
     cos = F.linear(F.normalize(x), F.normalize(w))
     if cosface:
