@@ -90,6 +90,15 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       return true;
     }
     const uint32_t tt_ = blockIdx.x + it * gridDim.x;
+#ifdef PFR_IGEMM_TRACE
+    if (!FILT && (p.dbg & 16)) {   // experiment: XCDs 0-3 only (launch_tile_k doubled the grid)
+      const uint32_t xcd = blockIdx.x & 7, t4 = (blockIdx.x >> 3) * 4 + xcd;
+      if (xcd >= 4 || t4 >= ntile) return false;
+      tn_ = t4 % p.tilesN;
+      tm_ = t4 / p.tilesN;
+      return true;
+    }
+#endif
     if (tt_ >= ntile) return false;
     const uint32_t t_ = FILT ? tt_ : xcd_remap(blockIdx.x, gridDim.x);
     tn_ = t_ % p.tilesN;
@@ -214,6 +223,16 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
     }
     u_tr = tr0;
     u_ts = ts0;
+    if (!FILT && p.krot && !p.pclass) {
+      // rotated k-loop: this workgroup walks the k-steps kt0, kt0 + 1, ..., nk - 1, 0, ..., kt0 - 1 — concurrently running workgroups then
+      // request DIFFERENT weight columns / taps at any instant instead of all the same ones (fp32 summation order differs per tile)
+      const int spt = p.C / BK;                                   // k-steps per tap
+      const int kt0 = (int)(((uint32_t)(tm * p.tilesN + tn) * (uint32_t)p.krot) % (uint32_t)nk_all);
+      const int tap0 = kt0 / spt;
+      cbyte = (kt0 - tap0 * spt) * BK * (int)sizeof(T);
+      u_tr = tap0 / p.S;
+      u_ts = tap0 - u_tr * p.S;
+    }
     tapbyte = (u_tr * p.S + u_ts) * p.C * (int)sizeof(T);
     newtap();
   }
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
       if (cbyte >= p.C * (int)sizeof(T)) {
         cbyte = 0;
         u_ts += tstep;
-        if (u_ts >= p.S) { u_ts = ts0; u_tr += tstep; }
+        if (u_ts >= p.S) { u_ts = ts0; u_tr += tstep; if (!FILT && p.krot && !p.pclass && u_tr >= p.R) u_tr = 0; }
         tapbyte = (u_tr * p.S + u_ts) * p.C * (int)sizeof(T);
         newtap();
       }
@@ -750,7 +769,11 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
   p.div_cw = make_fastdiv((uint32_t)(p.OW / 2 > 0 ? p.OW / 2 : 1));
   p.tilesM = p.pclass ? 4 * p.tpc : (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
-  const dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(NW * 64);
+  p.krot = pfr_knob(KNOB_IGEMM_KROT);
+  dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(NW * 64);
+#ifdef PFR_IGEMM_TRACE
+  if (p.dbg & 16) grid.x = (grid.x + 3) / 4 * 8;   // experiment: the tiles run on XCDs 0-3 only (blocks of XCDs 4-7 exit at once)
+#endif
   if (p.pro_scale) {
     if (fast) hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, true, KCH, NW, WP, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<T, TO, BQ, BP, true, false, KCH, NW, WP, 2>), grid, block, 0, st, p);

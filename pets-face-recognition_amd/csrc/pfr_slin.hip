@@ -408,8 +408,19 @@ static int slin_launch(IgemmParams& p, int dtype, int out_dtype, float* colsum, 
   if (parts_only) { if (np == 192) return 1; *parts_only = nranges; return PFR_OK; }
   if (colsum && (ep != SLIN_GELU_BWD || np == 192)) return 1;
   const dim3 grid((unsigned)(npanels * nranges)), block((unsigned)(nw * 64));
+  // The kernel's loads are inline asm behind hand-counted s_waitcnt vmcnt(n): a compiler-inserted vector-memory operation between them
+  // (a scratch spill or reload of R / RS / acc under other flags or another hipcc) would shift the count and the MFMAs would read
+  // registers that have not landed — silently.  An instantiation that uses ANY scratch is therefore never launched: the tile kernel
+  // takes the launch (checked once per instantiation; tests/test_host_logic.py asserts the same from the ISA of the shipped flags).
 #define PFR_SLIN_GO(NTV, EPV)                                                              \
   do {                                                                                     \
+    static std::atomic<int> scratch_ok{0};   /* 0 unknown, 1 no scratch, 2 scratch */       \
+    if (!scratch_ok.load(std::memory_order_relaxed)) {                                     \
+      hipFuncAttributes fa;                                                                \
+      const bool ok = hipFuncGetAttributes(&fa, (const void*)slin_kernel<NTV, EPV>) == hipSuccess && fa.localSizeBytes == 0; \
+      scratch_ok.store(ok ? 1 : 2, std::memory_order_relaxed);                             \
+    }                                                                                      \
+    if (scratch_ok.load(std::memory_order_relaxed) != 1) return 1;                         \
     static std::atomic<unsigned long long> attr{0};                                        \
     PFR_MAX_LDS_ONCE(attr, 160 * 1024, (const void*)slin_kernel<NTV, EPV>);                \
     hipLaunchKernelGGL((slin_kernel<NTV, EPV>), grid, block, lds, st, sp);                 \

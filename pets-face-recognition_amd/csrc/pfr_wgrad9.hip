@@ -380,8 +380,10 @@ int wgrad9_launch(const void* x, const void* dy, float* slabs, int N, int H, int
   if ((long)N * H * W * lddy * 2 >= (1L << 31) || (long)N * H * W * C * 2 >= (1L << 31)) return 0;   // (row offsets + the pad lanes' offset stay below 2^32)
   const int sr = 128 / pw, nrows = N * (H + 1);   // extended rows: one all-zero row after every image
   // ("wgrad9_slots" < 256 leaves CUs to the main stream's kernels while this one runs on the side stream: VERDICT r4 item 2-ii)
-  int nsplit = pfr_knob(KNOB_WGRAD9_SLOTS) / npairs;
-  if (nsplit < 1) nsplit = 1;
+  // (clamped to [npairs, 256]: the caller's slab workspace holds wgrad9_max_splits() = 256 / npairs slabs, whatever the knob says)
+  int slots = pfr_knob(KNOB_WGRAD9_SLOTS);
+  slots = slots < npairs ? npairs : (slots > 256 ? 256 : slots);
+  int nsplit = slots / npairs;
   int rps = (nrows + nsplit - 1) / nsplit;
   rps = (rps + sr - 1) / sr * sr;
   nsplit = (nrows + rps - 1) / rps;

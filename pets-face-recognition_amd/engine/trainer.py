@@ -124,14 +124,22 @@ class Trainer:
         # not for a pytorch-lightning checkpoint (callbacks, AttributeDict hyper-parameters, ...).  The checkpoint is the user's own file,
         # as it is for PL's `resume_from_checkpoint`: try the safe load first, fall back to the full unpickler and say so.
         def load(p_):
+            import pickle
             try:
                 return torch.load(str(p_), map_location='cpu', weights_only=True)
-            except Exception as e:   # noqa: BLE001  (pickle.UnpicklingError and friends)
-                print(f'resume_from_checkpoint: {Path(p_).name} holds more than tensors ({type(e).__name__}); loading it with the full unpickler')
+            except pickle.UnpicklingError as e:   # a global the safe unpickler does not allow; truncated files, I/O errors etc. propagate
+                print(f'resume_from_checkpoint: {Path(p_).name} holds more than tensors ({e.__class__.__name__}: {str(e)[:120]}); '
+                      f'loading it with the full unpickler (it can run code: only resume from files you wrote)')
                 return torch.load(str(p_), map_location='cpu', weights_only=False)
         ckpt = load(path)
         if isinstance(ckpt, dict) and 'state_dict' in ckpt:
             sd, loop = ckpt['state_dict'], ckpt
+            if 'optimizer_states' not in ckpt and 'epoch' not in ckpt:
+                # {'state_dict': ...} alone / a PL `save_weights_only` file: the same policy as a bare state dict
+                if not self.resume_weights_only:
+                    raise ValueError(f"resume_from_checkpoint: {path.name} holds a state_dict but no loop state (epoch, optimizer, LR "
+                                     f"schedule); pass Trainer(resume_weights_only=True) to restart at epoch 0 from these weights")
+                loop = {}
         else:
             sd = ckpt
             side = Path(str(path) + '.trainer')
@@ -143,7 +151,7 @@ class Trainer:
                 raise FileNotFoundError(f"resume_from_checkpoint: {path.name} is a bare state dict and its loop state {side.name} is missing "
                                         f"(epoch, optimizer, LR schedule); pass Trainer(resume_weights_only=True) to restart at epoch 0 from these weights")
         controller.load_state_dict(sd, strict=True)
-        if loop:
+        if loop and ('optimizer_states' in loop or 'lr_schedulers' in loop):
             ost, lst = loop.get('optimizer_states', []), loop.get('lr_schedulers', [])
             if len(ost) != len(optims) or len(lst) != len(scheds):
                 raise ValueError(f"resume_from_checkpoint: the checkpoint holds {len(ost)} optimizer / {len(lst)} scheduler states, "

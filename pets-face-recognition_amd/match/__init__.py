@@ -390,6 +390,11 @@ def cosine_topk_sharded(q, g_local, k, g_offset, group=None, **kw):
         pad = k - kk
         sc = torch.cat([sc, torch.full((sc.shape[0], pad), -float("inf"), device=sc.device)], 1)
         idx = torch.cat([idx, torch.full((idx.shape[0], pad), -1, dtype=idx.dtype, device=idx.device)], 1)
+    if sc.dtype != torch.float32:
+        raise PfrError(f"cosine_topk_sharded: scores must be fp32 for the packed all-gather, got {sc.dtype}")
+    if int(g_offset) < 0 or int(g_offset) + int(g_local.shape[0]) >= 2 ** 31:
+        raise PfrError(f"cosine_topk_sharded: global gallery rows up to {int(g_offset) + int(g_local.shape[0])} do not fit the int32 "
+                       f"index half of the packed (score, index) all-gather")
     gidx = torch.where(idx >= 0, idx + int(g_offset), idx).int()
     world = dist.get_world_size(group)
     # ONE collective: (fp32 score bits, int32 global index) pairs of every rank, [world][Q][k][2] int32

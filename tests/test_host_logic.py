@@ -363,6 +363,23 @@ def test_resume_from_checkpoint_continues_the_run(tmp_path):
         assert torch.equal(va, vc), k
     with pytest.raises(FileNotFoundError):
         Trainer(default_root_dir=tmp_path / "d", resume_from_checkpoint=tmp_path / "nope.ckpt", **kw).fit(Controller(_tiny_config()))
+    # {'state_dict': ...} without loop state (PL `save_weights_only`): the bare-state-dict policy — refused unless resume_weights_only
+    torch.save({"state_dict": torch.load(tmp_path / "a" / "epoch=2.ckpt")}, tmp_path / "wonly.ckpt")
+    with pytest.raises(ValueError, match="no loop state"):
+        Trainer(default_root_dir=tmp_path / "e", resume_from_checkpoint=tmp_path / "wonly.ckpt", **kw).fit(Controller(_tiny_config()))
+    e = Controller(_tiny_config())
+    te = Trainer(default_root_dir=tmp_path / "e", resume_from_checkpoint=tmp_path / "wonly.ckpt", resume_weights_only=True,
+                 **dict(kw, max_epochs=0))
+    te.fit(e)
+    assert te.global_step == 0
+    for (k, va), (_, ve) in zip(a.state_dict().items(), e.state_dict().items()):
+        assert torch.equal(va, ve), k
+    # a truncated file is an error of its own, not a reason to try the full unpickler
+    blob = (tmp_path / "a" / "epoch=0.ckpt").read_bytes()
+    (tmp_path / "trunc.ckpt").write_bytes(blob[: len(blob) // 2])
+    with pytest.raises(Exception) as ei:
+        Trainer(default_root_dir=tmp_path / "f", resume_from_checkpoint=tmp_path / "trunc.ckpt", **kw).fit(Controller(_tiny_config()))
+    assert not isinstance(ei.value, (ValueError, FileNotFoundError)) or "loop state" not in str(ei.value)
 
 
 _REBIND_SCRIPT = textwrap.dedent("""
