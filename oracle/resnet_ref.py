@@ -15,6 +15,10 @@ ARCH = {
     # test-only prefix of ResNet-50 (stem + all of layer1 + the first block of layers 2-4): the geometries the BN-input-free form of
     # conv3 + bn3 applies to, small enough for a 256-image CPU oracle step (tests/test_model_gpu.py)
     "resnet50_l1": ("bottleneck", [3, 1, 1, 1]),
+    # test-only one-block-per-layer nets: shallow enough that two correct bf16 evaluations of a train step agree to ~1e-2 in the gradient
+    # (a 16-block random-init net amplifies every rounding difference to ~25 %: tools/diag_bf16cond.py), so a wrong kernel shows
+    "resnet14b": ("bottleneck", [1, 1, 1, 1]),
+    "resnet10": ("basic", [1, 1, 1, 1]),
 }
 
 
@@ -73,19 +77,59 @@ def bf16_round(t):
     return t + (t.detach().bfloat16().to(t.dtype) - t.detach())
 
 
+class _RoundBoth(torch.autograd.Function):
+    """bf16 rounding of the value in forward AND of the incoming gradient in backward: a tensor the bf16 path keeps in bf16 in both
+    directions (every activation it stores has a bf16 gradient tensor of the same shape)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.bfloat16().to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+class _RoundGrad(torch.autograd.Function):
+    """identity in forward, bf16 rounding of the gradient in backward (a bf16 gradient tensor whose forward value is exact already)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+def bf16_round_fb(t):
+    """`quant` callable for forward(): bf16 storage points in BOTH directions — what the HIP bf16 path does: the gradients of raw conv
+    outputs (BatchNorm-backward apply), of normalised activations (data gradients), of block outputs (the residual joins), of the stem's
+    pooled output, of the pooled features and of the embedding are bf16 tensors; weight gradients stay fp32 (split-K fp32 slabs), so
+    weights are rounded straight-through only.  Not part of the reference: test infrastructure for the bf16 gradient tolerances."""
+    return _RoundBoth.apply(t)
+
+
+bf16_round_fb.weights = bf16_round                      # weights: forward rounding, fp32 gradient
+bf16_round_fb.grad_only = _RoundGrad.apply              # gradient-only storage points
+
+
 def forward(sd, x, arch, train=True, new_stats=None, taps=None, quant=None):
     """sd: name → tensor (parameters may require grad).  Returns the embedding (N × emb_dim).
     quant=None is the reference arithmetic (fp32).  quant=bf16_round emulates the storage points of the bf16 path
-    (inputs, weights, raw conv outputs, normalised activations, block outputs) for the bf16 deviation tests."""
+    (inputs, weights, raw conv outputs, normalised activations, block outputs) for the bf16 deviation tests;
+    quant=bf16_round_fb additionally rounds the GRADIENTS at the tensors the bf16 path stores in bf16 (see there)."""
     kind, layers = ARCH[arch]
     q = quant or (lambda t: t)
+    qw = getattr(quant, "weights", q)                   # weights
+    qg = getattr(quant, "grad_only", lambda t: t)       # gradient-only storage points
 
     def conv(inp, name, **kw):
-        return q(F.conv2d(inp, q(sd[name + ".weight"]), **kw))
+        return q(F.conv2d(inp, qw(sd[name + ".weight"]), **kw))
 
-    x = conv(q(x), "conv1", stride=2, padding=3)
+    x = conv(qw(x), "conv1", stride=2, padding=3)
     x = q(F.relu(_bn(sd, "bn1", x, train, new_stats)))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = qg(F.max_pool2d(x, 3, 2, 1))
     if taps is not None:
         taps["stem"] = x
     for li, nblk in enumerate(layers):
@@ -112,7 +156,7 @@ def forward(sd, x, arch, train=True, new_stats=None, taps=None, quant=None):
             if taps is not None:
                 taps[p] = x
     x = q(x.mean(dim=(2, 3)))
-    return F.linear(x, q(sd["fc.weight"]), sd["fc.bias"])
+    return qg(F.linear(x, qw(sd["fc.weight"]), sd["fc.bias"]))
 
 
 def param_names(sd):

@@ -36,6 +36,7 @@ struct IgemmParams {
   int fo_qg = 0, fo_gg = 0;
   FastDiv div_ohow, div_ow;
   int tilesM, tilesN;
+  int dma_sched = 0x101;   // -DPFR_IGEMM_SPREAD builds: parts | first k-group of waves 0-3 << 4 | of waves 4-7 << 8 (KNOB_IGEMM_DMA)
   int krot = 0;   // tile kernel, FAST non-parity-class path: first k-step of workgroup tile t = (t * krot) % nk (KNOB_IGEMM_KROT)
   // parity-class mode (data gradient of a stride-2 conv, FAST path): output rows are processed per (oh%2, ow%2) class so
   // that only the taps that exist for that class are visited (a 3x3/s2 dgrad does 9/4 instead of 9 taps per output).

@@ -238,7 +238,21 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   }
 
   // issues the LDS-DMA of one k-step into ring slot `buf` (weights + gathered activations, zero-filled when invalid)
-  auto gload = [&](int buf, bool issue = true) {   // issue = false: the k-step's DMA is already in flight (FILT), only the walker steps
+  // (FAST) DMA instructions [lo, hi) of the NLD a wave issues per k-step: weights first, then activations; the walker does not move
+  auto gload_part = [&](int buf, int lo, int hi) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j)
+      if (j >= lo && j < hi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(base + (j * NW + wave) * RPI * ROWB),
+                                                 16, (int)(wbase[j] + (uint32_t)(tapbyte + cbyte)), 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < QCH; ++j)
+      if (PCH + j >= lo && PCH + j < hi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(base + (BP + (j * NW + wave) * RPI) * ROWB),
+                                                 16, (int)(qbase[j] + (uint32_t)cbyte), 0, 0, 0);
+  };
+  auto gload = [&](int buf, bool issue = true) {   // issue = false: the k-step's DMA is already in flight (FILT / spread issue), only the walker steps
     char* base = smem + buf * STAGE;
     if constexpr (FAST) {
 #ifdef PFR_IGEMM_TRACE
@@ -367,6 +381,24 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
 #ifdef PFR_GLOAD_FIRST
     if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
     mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc);
+#elif defined(PFR_IGEMM_SPREAD)
+    // experiment (round 6): the next k-step's NLD DMA instructions leave in `np` parts, one behind each of the k-groups kg0 .. kg0 + np - 1,
+    // instead of one burst of NLD instructions (each holds its wave for 60-180 cycles).  dma_sched = np | kg0(waves 0-3) << 4 | kg0(waves 4-7) << 8
+    if constexpr (FAST && !PRO && !FILT && KCH == 8) {
+      const int np = p.dma_sched & 15, kg0 = (NW == 8 && (threadIdx.x >> 8)) ? ((p.dma_sched >> 8) & 15) : ((p.dma_sched >> 4) & 15);
+      const bool more = kt + NST - 1 < nk;
+      mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc, every_kg([&](int kg) {
+        const int rel = kg - kg0;
+        if (more && rel >= 0 && rel < np) {
+          gload_part((kt + NST - 1) % NST, rel * NLD / np, (rel + 1) * NLD / np);
+          if (rel == np - 1) gload((kt + NST - 1) % NST, false);
+        }
+      }));
+    } else {
+      mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc, [&]() {
+        if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
+      }, (NW == 8 && (threadIdx.x >> 8)) ? 1 : 0);
+    }
 #else
     // the next tile's DMA is issued behind the first k-group's MFMAs (see mma_kstep_sw) — behind the SECOND by waves 4-7 of an
     // 8-wave tile: waves w and w + 4 share a SIMD, an LDS-DMA instruction holds its wave for 60-180 cycles, and with both of them
@@ -374,7 +406,7 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
     // two, the DMA lands after the k-step's barrier: 71 / 75 us; profiles/r04_tile_variants.txt)
     mma_kstep_sw<T, KCH, TP, TQ>(base + (wp * (BP / WP)) * ROWB, base + (BP + wq * (BQ / WQ)) * ROWB, lane, acc, [&]() {
       if (kt + NST - 1 < nk) gload((kt + NST - 1) % NST);
-    }, (NW == 8 && (threadIdx.x >> 8)) ? 1 : 0);
+    }, (NW == 8 && (threadIdx.x >> 8)) ? ((p.dma_sched >> 8) & 15) : ((p.dma_sched >> 4) & 15));
 #endif
     if (kt + 1 < nk) {
       const int last = kt + NST - 1 < nk - 1 ? kt + NST - 1 : nk - 1;  // newest k-step in flight
@@ -770,6 +802,7 @@ static int launch_tile_k(IgemmParams& p, hipStream_t st) {
   p.tilesM = p.pclass ? 4 * p.tpc : (p.M + BQ - 1) / BQ;
   p.tilesN = (p.Cout + BP - 1) / BP;
   p.krot = pfr_knob(KNOB_IGEMM_KROT);
+  p.dma_sched = pfr_knob(KNOB_IGEMM_DMA);
   dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(NW * 64);
 #ifdef PFR_IGEMM_TRACE
   if (p.dbg & 16) grid.x = (grid.x + 3) / 4 * 8;   // experiment: the tiles run on XCDs 0-3 only (blocks of XCDs 4-7 exit at once)

@@ -88,6 +88,15 @@ template <int KCH> __device__ __forceinline__ int row_swizzle(int row) {
 }
 
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
+// a Mid with `static constexpr bool every_kgroup = true` is invoked after EVERY k-group's MFMAs with the k-group index (spread DMA issue)
+template <typename M, typename = void> struct MidEvery { static constexpr bool value = false; };
+template <typename M> struct MidEvery<M, decltype((void)M::every_kgroup)> { static constexpr bool value = M::every_kgroup; };
+template <typename F> struct EveryKg {
+  F f;
+  static constexpr bool every_kgroup = true;
+  __device__ __forceinline__ void operator()(int kg) const { f(kg); }
+};
+template <typename F> __device__ __forceinline__ EveryKg<F> every_kg(F f) { return EveryKg<F>{f}; }
 
 // `mid` is invoked after the MFMAs of the first k-group have been ISSUED: work placed there (the next tile's DMA issue and
 // its address arithmetic) executes while the matrix pipe drains those MFMAs instead of in front of an idle pipe.
@@ -129,6 +138,7 @@ __device__ __forceinline__ void mma_kstep_sw(const char* ldsP, const char* ldsQ,
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fp[b][i][e]), __uint_as_float(fq[b][j][e]),
                                                               acc[i][j], 0, 0, 0);
     }
-    if (kg == midkg) mid();
+    if constexpr (MidEvery<Mid>::value) mid(kg);
+    else if (kg == midkg) mid();
   }
 }

@@ -143,3 +143,38 @@ def test_config5_top100_vs_fp64_oracle_on_the_1m_gallery():
         # scores are the fp32 cosines of the returned rows
         assert (sc.cpu().double() - torch.gather(scores, 1, idx)).abs().max() < 5e-6
         assert nd <= 4
+
+
+def test_config5_headline_size_bf16_vs_f32_set_differences_are_fp64_near_ties():
+    """at the HEADLINE size (10 000 queries x 1 000 000 gallery rows, top-100) the bf16 + fp32-re-score path and the f32
+    path return different top-100 SETS for a handful of queries (5 of 10 000 in profiles/r05_i_bench_match.json).  Those very queries are
+    ranked in fp64 on the CPU (oracle/match_ref.topk_query_gallery's arithmetic in float64, chunked) and every entry on which EITHER
+    path disagrees with the fp64 top-100 must lie within 1e-6 of the fp64 score at rank 100 — a genuine near-tie at the cut, not a miss.
+    candR@K (reference engine/controller.py:77-90) of the two paths is identical on the full set."""
+    from pets_face_recognition_amd.match import cosine_topk
+    Q, G, K = 10000, 1000000, 100
+    qry, gal = _config5_data(Q, G)
+    res = {}
+    for dt in (torch.bfloat16, torch.float32):
+        sc, idx = cosine_topk(qry, gal, K, compute_dtype=dt)
+        assert (idx >= 0).all()
+        res[dt] = idx.long()
+    a, b = res[torch.bfloat16].sort(1).values, res[torch.float32].sort(1).values
+    diff = (~(a == b).all(1)).nonzero().flatten().cpu()
+    print(f"[config 5 headline size] queries with different bf16 / f32 top-100 sets: {diff.numel()} of {Q}: {diff.tolist()[:20]}")
+    assert diff.numel() <= 20, diff.numel()                 # (measured: 5)
+    if diff.numel() == 0:
+        return
+    q64 = torch.nn.functional.normalize(qry[diff.to(DEV)].double().cpu(), dim=1)
+    scores = torch.empty(diff.numel(), G, dtype=torch.float64)
+    for lo in range(0, G, 125000):
+        gc = torch.nn.functional.normalize(gal[lo:lo + 125000].double().cpu(), dim=1)
+        scores[:, lo:lo + 125000] = q64 @ gc.t()
+    ref_sc, ref_ix = torch.topk(scores, K, dim=1)
+    cut = ref_sc[:, K - 1]
+    for dt, idx in res.items():
+        sub = idx[diff.to(DEV)].cpu()
+        for r in range(diff.numel()):
+            got, want = set(sub[r].tolist()), set(ref_ix[r].tolist())
+            for j in got ^ want:
+                assert abs(scores[r, j].item() - cut[r].item()) < 1e-6, (dt, int(diff[r]), j, scores[r, j].item(), cut[r].item())

@@ -434,3 +434,26 @@ def test_bench_launches_its_own_ranks_when_no_launcher_is_around_it():
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], capture_output=True, text=True, timeout=300, env=env2)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_hand_counted_vmcnt_kernels_use_no_scratch(tmp_path):
+    """pfr_slin.hip counts its vector-memory operations by hand (inline-asm buffer loads behind `s_waitcnt vmcnt(n)`); a
+    compiler-inserted scratch spill / reload between them would shift the count silently.  The ISA of the SHIPPED flags (csrc/build.sh)
+    must therefore show no private segment and no scratch instruction for any slin_kernel instantiation (the launch path checks the same
+    through hipFuncGetAttributes and falls back to the tile kernel otherwise)."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    csrc = os.path.join(ROOT, "pets-face-recognition_amd", "csrc")
+    flags = re.search(r'^FLAGS="([^"]*)"', open(os.path.join(csrc, "build.sh")).read(), re.M).group(1)
+    flags = flags.replace("$ARCH", "gfx950").replace("${PFR_EXTRA_FLAGS}", "").split()
+    out = tmp_path / "pfr_slin.s"
+    subprocess.run(["hipcc", *flags, "--cuda-device-only", "-S", os.path.join(csrc, "pfr_slin.hip"), "-o", str(out)], check=True,
+                   stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    kernels = re.findall(r"\.name:\s+(\S*slin_kernel\S*)\s+\.private_segment_fixed_size:\s+(\d+)", text)
+    assert len(kernels) >= 15, kernels
+    assert all(int(sz) == 0 for _, sz in kernels), [k for k in kernels if int(k[1])]
+    assert not re.search(r"^\s+scratch_(load|store)", text, re.M)

@@ -96,7 +96,32 @@ def test_backbone_fwd_bwd_vs_oracle(arch, dtype, tol_emb, grad_factor):
     # bf16-activation training does) is itself at cos 0.93 (R50) / 0.98 (R18) to the fp64 gradient — measured with
     # tools/diag_bf16grad.py; the HIP bf16 path sits at the same distance, so the bound below is that floor.
     assert cos_all > (0.9999 if dtype == torch.float32 else 0.9), f"whole-gradient cosine similarity {cos_all}"
-    assert cos_min > (0.999 if dtype == torch.float32 else 0.4), f"min per-parameter gradient cosine similarity {cos_min}"
+    if dtype == torch.float32:
+        assert cos_min > 0.999, f"min per-parameter gradient cosine similarity {cos_min}"
+    else:
+        # Against the oracle that ALSO rounds the gradients where the bf16 path stores them in bf16 (resnet_ref.bf16_round_fb) the two
+        # differ only in accumulation order and in where fp32 intermediates live.  On a 16-block random-init train-mode-BN net that is
+        # NOT small: the same oracle evaluated in fp32 and in fp64 arithmetic (identical storage points) is 0.14 (R18) / 0.26 (R50)
+        # apart in the gradient (tools/diag_bf16cond.py) — every rounding that flips is amplified ~1.5x per block.  The bound is
+        # therefore that floor, measured here: the HIP path must be as close to the oracle as another CORRECT evaluation is.  (The
+        # tolerance that catches a wrong kernel is asserted on a shallow net: test_bf16_step_of_a_shallow_net_vs_gradient_rounding_oracle.)
+        def oracle_grads(f64):
+            f = (lambda v: v.double()) if f64 else (lambda v: v.clone())
+            pq = {k: (f(v).requires_grad_(True) if k in names else (f(v) if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
+            resnet_ref.forward(pq, f(x), arch, train=True, quant=resnet_ref.bf16_round_fb).backward(f(demb))
+            return {k: pq[k].grad.double().flatten() for k in names}
+        gq, gq64 = oracle_grads(False), oracle_grads(True)
+        gh = {k: p.grad.double().cpu().flatten() for k, p in m.named_parameters()}
+        cat = lambda d: torch.cat([d[k] for k in names])   # noqa: E731
+        err_q = ((cat(gh) - cat(gq)).norm() / cat(gq).norm()).item()
+        floor = ((cat(gq64) - cat(gq)).norm() / cat(gq).norm()).item()
+        cosn = {k: (gh[k] @ gq[k] / (gh[k].norm() * gq[k].norm() + 1e-30)).item() for k in names}
+        cosf = {k: (gq64[k] @ gq[k] / (gq64[k].norm() * gq[k].norm() + 1e-30)).item() for k in names}
+        wk = min(cosn, key=cosn.get)
+        print(f"[{arch} bf16 vs gradient-rounding oracle] overall rel err {err_q:.4f} (floor: two oracle evaluations {floor:.4f}), worst tensor "
+              f"{wk} cos {cosn[wk]:.4f} (floor {min(cosf.values()):.4f}); vs fp64: cos_all {cos_all:.4f} cos_min {cos_min:.4f}")
+        assert err_q <= 1.3 * floor + 1e-2, f"gradient rel err vs the gradient-rounding bf16 oracle {err_q}, floor {floor}"
+        assert cosn[wk] >= min(cosf.values()) - 0.05, f"per-tensor gradient cosine vs the gradient-rounding bf16 oracle: {wk} {cosn[wk]}"
     # eval mode uses the running statistics
     m.eval()
     with torch.no_grad():
@@ -641,13 +666,15 @@ def test_bs256_bf16_train_step_of_the_stem_and_layer1_prefix_vs_bf16_emulating_o
     oracle instead of against itself.  Net = the ResNet-50 prefix `resnet50_l1` (stem, all three 56x56 blocks of layer1, then one block per
     later layer so that every layer1 block keeps its real successor), 256 x 3 x 224 x 224, bf16, train-mode BatchNorm, one forward + backward,
     in BOTH forms (PFR_BNFREE=0: conv3's output stored; 1: the BN-input-free form, the default).
-    Checked against oracle/resnet_ref.py with bf16 rounding emulated at the forward's storage points (fp32 arithmetic, autograd backward):
+    Checked against oracle/resnet_ref.py with bf16 rounding emulated at the path's storage points in both directions (bf16_round_fb: fp32
+    arithmetic, autograd backward whose gradients are rounded to bf16 where the HIP path stores them in bf16; round 6 — the forward-only
+    emulation of round 5 gave the same distances, i.e. they are conditioning, tools/diag_bf16cond.py, not the missing gradient rounding):
       * the embeddings (<= 5e-2 relative; measured 6e-3);
       * the running statistics layer1's bn3 layers leave — from the Gram matrix of conv3's INPUT in the default form
         (pfr_bn_finalize_from_gram), from conv3's bf16 output in the oracle: mean to 1e-2 of the running std, variance to 2e-2 relative;
-      * the gradient of every stem / layer1 parameter.  The oracle's backward keeps fp32 gradients while the HIP path stores every
-        gradient tensor in bf16, so the two differ by the bf16 noise of ~50 stored gradient tensors (measured: cosine 0.96 over all
-        parameters, 0.84 on the stem's BatchNorm bias, the tensor furthest from the loss).  Asserted: no non-finite value; overall cosine
+      * the gradient of every stem / layer1 parameter.  Two correct bf16 evaluations of such a step differ wherever a pre-rounding value
+        sits on a bf16 rounding boundary, and the six blocks amplify each flip (measured: cosine 0.96-0.97 over all parameters, relative
+        error 0.25-0.27; the tolerance that catches a wrong kernel is test_bf16_step_of_a_shallow_net_vs_gradient_rounding_oracle).  Asserted: no non-finite value; overall cosine
         >= 0.95; and the default form is NOT further from the oracle than the stored form — overall relative error <= 1.10x (measured 0.2675 against 0.2543), per
         tensor cosine >= the stored form's - 0.03."""
     from oracle import resnet_ref
@@ -662,7 +689,7 @@ def test_bs256_bf16_train_step_of_the_stem_and_layer1_prefix_vs_bf16_emulating_o
     names = [k for k in resnet_ref.param_names(sd) if k.startswith(("conv1", "bn1", "layer1"))]
     sdo = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
     stats = {}
-    eo = resnet_ref.forward(sdo, x, "resnet50_l1", train=True, new_stats=stats, quant=resnet_ref.bf16_round)
+    eo = resnet_ref.forward(sdo, x, "resnet50_l1", train=True, new_stats=stats, quant=resnet_ref.bf16_round_fb)
     (eo * proj).sum().backward()
     eo = eo.detach()
     ref = torch.cat([sdo[k].grad.flatten().double() for k in names])
@@ -705,6 +732,55 @@ def test_bs256_bf16_train_step_of_the_stem_and_layer1_prefix_vs_bf16_emulating_o
     assert res["1"]["err"] <= 1.10 * res["0"]["err"], (res["1"]["err"], res["0"]["err"])
     drop = max(res["0"]["cosn"][k] - res["1"]["cosn"][k] for k in names)
     assert drop < 0.03, drop
+
+
+def test_bf16_step_of_a_shallow_net_vs_gradient_rounding_oracle():
+    """a gradient tolerance that a wrong kernel cannot pass.  One bottleneck per layer (`resnet14b`: stem, 4 blocks with
+    projection shortcuts, every kernel family of the bf16 step: streaming 1x1, halo / tile 3x3, stride-2 parity-class data gradients, the
+    residual joins with their BatchNorm-backward sums, the pool), 16 x 3 x 128 x 128, damped residual branches — shallow and wide enough
+    in rows that two CORRECT bf16 evaluations of the step agree to 4e-2 in the gradient (tools/diag_bf16cond.py: fp32 vs fp64
+    arithmetic between the same storage points: 0.039, worst per-tensor cosine 0.994).  Against oracle/resnet_ref.py with bf16 rounding
+    at the path's storage points in BOTH directions (bf16_round_fb): embedding <= 2e-2 relative, overall gradient error <= 8e-2
+    relative, every parameter tensor's gradient cosine >= 0.98."""
+    from oracle import resnet_ref
+    from pets_face_recognition_amd.models.resnet import ResNet, Bottleneck
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    arch, N, HW = "resnet14b", 16, 128
+    sd = resnet_ref.init_state_dict(arch, 512, seed=3)
+    for k in sd:
+        if k.startswith("layer") and k.endswith(".bn3.weight"):
+            sd[k] = torch.full_like(sd[k], 0.2)
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(N, 3, HW, HW, generator=g)
+    demb = torch.randn(N, 512, generator=g) * 0.05
+    names = resnet_ref.param_names(sd)
+    pq = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd.items()}
+    eq = resnet_ref.forward(pq, x, arch, train=True, quant=resnet_ref.bf16_round_fb)
+    eq.backward(demb)
+    m = ResNet(Bottleneck, [1, 1, 1, 1], compute_dtype=torch.bfloat16)
+    m.fc = torch.nn.Linear(m.fc.in_features, 512)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    e = m(x.to(DEV))
+    e.backward(demb.to(DEV))
+    torch.cuda.synchronize()
+    r_e = rel(e.detach(), eq.detach())
+    gh = {k: p.grad.double().cpu().flatten() for k, p in m.named_parameters()}
+    gq = {k: pq[k].grad.double().flatten() for k in names}
+    assert all(torch.isfinite(v).all() for v in gh.values())
+    fh, fq = torch.cat([gh[k] for k in names]), torch.cat([gq[k] for k in names])
+    err = ((fh - fq).norm() / fq.norm()).item()
+    cosn = {k: (gh[k] @ gq[k] / (gh[k].norm() * gq[k].norm() + 1e-30)).item() for k in names}
+    wk = min(cosn, key=cosn.get)
+    line = f"resnet14b 16x3x128x128 bf16 train step vs gradient-rounding oracle: emb_rel={r_e:.3e} grad_rel_err={err:.4f} worst tensor {wk}: cos {cosn[wk]:.4f}"
+    print("[shallow bf16] " + line)
+    out = os.environ.get("PFR_PARITY_LOG")
+    if out:
+        with open(out, "a") as f:
+            f.write(line + "\n")
+    assert r_e < 2e-2, r_e
+    assert err <= 8e-2, err
+    assert cosn[wk] >= 0.98, (wk, cosn[wk])
 
 
 def test_backward_refuses_to_replay_under_changed_tuning_knobs():

@@ -21,14 +21,18 @@ kw = dict(a.split('=') for a in sys.argv[4:])
 DATAS = kw.get('data', 'randn').split(','); KROTS = [int(v) for v in kw.get('krot', '0').split(',')]
 dbg = int(kw.get('dbg', 0)); reps = int(kw.get('reps', 30))
 secs = float(kw.get('secs', 0)); SPLITS = [int(v) for v in kw.get('splits', '0').split(',')]
+DMAS = [int(v, 0) for v in kw.get('dma', '0x101').split(',')]
+tile = int(kw.get('tile', -1))   # pfr_set_tuning("igemm_tile"): 4 = the 8-wave 256x256 tile whatever the tile count
 if dbg:
     dll = ctypes.CDLL(os.environ['PFR_LIB_PATH'])
     dll.pfr_debug_igemm_flags(dbg)
 H, C, Co, R, p = FWD[case]
 
 
-def run(N, data, krot, splits):
+def run(N, data, krot, splits, dma=0x101):
+    lib.pfr_set_tuning(b"igemm_dma", dma)
     lib.pfr_set_tuning(b"igemm_krot", krot)
+    lib.pfr_set_tuning(b"igemm_tile", tile)
     lib.pfr_set_tuning(b"wgrad_splits", splits)
     mk = (lambda *s: torch.zeros(*s, device='cuda')) if data == 'zeros' else (lambda *s: torch.randn(*s, device='cuda'))
     x = mk(N, H, H, C).bfloat16()
@@ -64,11 +68,13 @@ def run(N, data, krot, splits):
     M = N * H * H
     fl = 2.0 * M * Co * R * R * C
     tiles = (M + 255) // 256 * ((Co + 255) // 256)
-    print(f'{kind:5s} {case:18s} N {N:4d} tiles256 {tiles:4d} data {data:5s} krot {krot:2d} dbg {dbg:2d} splits {splits:2d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s', flush=True)
+    chk = int(y.view(torch.int16).to(torch.int64).sum().item()) if kind == 'fwd' else 0
+    print(f'{kind:5s} {case:18s} N {N:4d} tiles256 {tiles:4d} data {data:5s} dma {dma:#05x} chk {chk:14d} tile {tile:2d} krot {krot:2d} dbg {dbg:2d} splits {splits:2d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s', flush=True)
 
 
 for N in NS:
     for data in DATAS:
         for krot in KROTS:
             for sp in SPLITS:
-                run(N, data, krot, sp)
+                for dma in DMAS:
+                    run(N, data, krot, sp, dma)
