@@ -243,7 +243,7 @@ def extras(args, device):
     try:
         import subprocess
         env = dict(os.environ, PFR_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-extras",
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "15", "--no-extras",
                             "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=600)
         j = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][-1]
         out["ddp_path_w1"] = {"value": j["value"], "unit": "images/sec", "ms_per_step": j["ms_per_step"], "rccl_ranks": j["config"]["rccl_ranks"]}

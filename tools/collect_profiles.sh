@@ -21,6 +21,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -o pmc -- $CMD > $OUT/${TAG}_pmc_$c.log 2>&1 )
 done
 python tools/hbm_traffic.py $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE 10 > $OUT/${TAG}_traffic.json
+# one SQ pass (its own run: never together with the TCC passes or another trace domain): where the matrix pipe waits, for the five longest kernels
+SQSET="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+( cd /tmp && rocprofv3 --kernel-trace --pmc $SQSET --output-format csv -d $OUT/pmc_${TAG}_SQ -o pmc -- $CMD > $OUT/${TAG}_pmc_SQ.log 2>&1 )
+python tools/pmc_top5.py $OUT/pmc_${TAG}_SQ 5 > $OUT/${TAG}_pmc_top5.txt 2>&1
+rm -rf $OUT/pmc_${TAG}_SQ
 # per-geometry table of the conv launches against max(MFMA, HBM) bounds (serialised launches, HIP events)
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --detail $OUT/${TAG}_detail.json > /dev/null 2>&1
 python tools/layer_roofline.py $OUT/${TAG}_detail.json $OUT/${TAG}_layer_roofline.md > /dev/null
@@ -33,6 +38,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_swin_$c -o pmc -- $SCMD > $OUT/${TAG}_pmc_swin_$c.log 2>&1 )
 done
 python tools/hbm_traffic.py $OUT/pmc_${TAG}_swin_FETCH_SIZE $OUT/pmc_${TAG}_swin_WRITE_SIZE 10 "swin_t bs128 bf16 224x224 train step" > $OUT/${TAG}_traffic_swin.json
+( cd /tmp && rocprofv3 --kernel-trace --pmc $SQSET --output-format csv -d $OUT/pmc_${TAG}_swin_SQ -o pmc -- $SCMD > $OUT/${TAG}_pmc_swin_SQ.log 2>&1 )
+python tools/pmc_top5.py $OUT/pmc_${TAG}_swin_SQ 5 > $OUT/${TAG}_pmc_top5_swin.txt 2>&1
+rm -rf $OUT/pmc_${TAG}_swin_SQ
 # 10k x 1M x 512 match (BASELINE config 5): kernel stats
 MCMD="python $PWD/tools/bench_match.py"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_match -o stats -- $MCMD > $OUT/${TAG}_bench_match.json 2> $OUT/${TAG}_prof_match_run.log )
