@@ -990,6 +990,41 @@ __global__ __launch_bounds__(256) void s2d_input_kernel(const float* __restrict_
     }
   }
 }
+// The stem's own form (3 input channels, 16-channel pixels, W % 4 == 0): a thread makes TWO horizontally adjacent space-to-depth pixels from
+// six 16-byte loads (4 consecutive columns of the 2 rows of each of the 3 planes) and writes their 64 contiguous bytes; the generic kernel above
+// issues 12 scalar loads per pixel (round 6: 78 -> ~50 us for 256 x 3 x 224 x 224, bit-identical).
+__global__ __launch_bounds__(256) void s2d_input3_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W) {
+  const int H2 = H >> 1, W4 = W >> 2;
+  const size_t npair = (size_t)N * H2 * W4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npair; i += (size_t)gridDim.x * 256) {
+    const int j4 = (int)(i % W4);
+    const int i2 = (int)((i / W4) % H2);
+    const size_t n = i / ((size_t)W4 * H2);
+    f32x4 v[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        v[c][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + ((n * 3 + c) * H + 2 * i2 + r) * W + 4 * j4));
+    bf16_t* o = y + ((n * H2 + i2) * (size_t)(W >> 1) + 2 * j4) * 16;
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+      float a[8], b[8];
+      // channel ch = pq * 3 + c, pq = (row parity << 1) | column parity
+#pragma unroll
+      for (int ch = 0; ch < 16; ++ch) {
+        float val = 0.f;
+        if (ch < 12) {
+          const int pq = ch / 3, c = ch - pq * 3;
+          val = v[c][pq >> 1][2 * px + (pq & 1)];
+        }
+        if (ch < 8) a[ch] = val; else b[ch - 8] = val;
+      }
+      st16(o + px * 16, Chunk<bf16_t>::pack(a));
+      st16(o + px * 16 + 8, Chunk<bf16_t>::pack(b));
+    }
+  }
+}
 template <typename T>
 __global__ void s2d_weight_kernel(const float* __restrict__ w, T* __restrict__ ws, int Co, int C, int Cp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over Co*4*4*Cp
@@ -1016,7 +1051,12 @@ extern "C" int pfr_s2d_input(const float* x, void* y, int dtype, int N, int C, i
   const size_t npix = (size_t)N * (H / 2) * (W / 2);
   unsigned blocks = (unsigned)((npix + 255) / 256);
   if (blocks > 16384) blocks = 16384;
-  if (dtype == PFR_BF16) hipLaunchKernelGGL(s2d_input_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, x, (bf16_t*)y, N, C, H, W, Cp);
+  if (dtype == PFR_BF16 && C == 3 && Cp == 16 && W % 4 == 0 && H % 2 == 0) {
+    const size_t npair = npix / 2;
+    unsigned b2 = (unsigned)((npair + 255) / 256);
+    if (b2 > 16384) b2 = 16384;
+    hipLaunchKernelGGL(s2d_input3_kernel, dim3(b2), dim3(256), 0, st, x, (bf16_t*)y, N, H, W);
+  } else if (dtype == PFR_BF16) hipLaunchKernelGGL(s2d_input_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, x, (bf16_t*)y, N, C, H, W, Cp);
   else hipLaunchKernelGGL(s2d_input_kernel<float>, dim3(blocks), dim3(256), 0, st, x, (float*)y, N, C, H, W, Cp);
   PFR_CHECK_LAUNCH();
   return PFR_OK;

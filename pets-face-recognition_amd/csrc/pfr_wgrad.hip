@@ -1058,6 +1058,9 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(GramParams p) {
   }
 }
 
+// (round 6: an LDS-free form — the four split-lanes as adjacent lanes of one wave, merged by two shuffles, bit-identical — lets the launch run
+//  beside the main stream's 160 KB-LDS streaming workgroups instead of waiting 35-85 us for them; the step got 0.09 ms SLOWER (17.35 vs 17.26 ms,
+//  four interleaved rounds, profiles/r06_ab.txt): what the side stream gains the main stream's kernels lose.  Not kept.)
 // sums the split slabs: block = 64 columns (of 4 floats) x 4 split-lanes; every lane keeps 4 independent loads in flight
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4,
                                                            int splits, float scale, int accumulate) {
