@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")"
 ARCH=gfx950
 FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast ${PFR_EXTRA_FLAGS}"
-SOURCES="pfr_api pfr_comm pfr_plan pfr_igemm pfr_igemm_p pfr_sconv pfr_sconv3 pfr_slin pfr_wgrad pfr_wgrad9 pfr_elementwise pfr_bnfree pfr_head pfr_match pfr_swin pfr_augment"
+SOURCES="pfr_api pfr_comm pfr_plan pfr_igemm pfr_igemm_p pfr_sconv pfr_sconv3 pfr_sstem pfr_slin pfr_wgrad pfr_wgrad9 pfr_elementwise pfr_bnfree pfr_head pfr_match pfr_swin pfr_augment"
 HEADERS="pfr_common.h pfr_mma.h pfr_igemm.h ../../include/pfr_hip.h pfr_thunks_gen.inc"
 # Variant builds for A/B runs: PFR_BUILD_TAG=nt PFR_EXTRA_FLAGS="-DPFR_LN_NT=1" build.sh  ->  build_nt/*.o, libpfr_hip_nt.so (load it with
 # PFR_LIB_PATH=...).  The flags of the last build are recorded next to the objects: a change of flags rebuilds everything (the objects'

@@ -33,7 +33,7 @@ static const struct { const char* name; int def; } kKnobs[KNOB_COUNT] = {
   {"igemm_p", 1}, {"igemm_ptile", -1}, {"igemm_pkch", 8}, {"igemm_ppf", 0}, {"igemm_tile", -1}, {"igemm_kch", 0}, {"igemm_big", 1},
   {"sconv", 1}, {"sconv3", 1}, {"bnb", 0}, {"swgrad", 1}, {"wgrad_big", 0}, {"wgrad_tile", -1}, {"wgrad_splits", 0}, {"wgrad9", 1},
   {"wgrad9_slots", 256}, {"attn_mfma", 1}, {"bnb_tile3", 0}, {"slin", 1}, {"slin_np", 0}, {"match_order", 1},
-  {"ln_rb", 4}, {"igemm_dma", 0x101}, {"igemm_krot", 0},
+  {"ln_rb", 4}, {"sstem", 1}, {"igemm_dma", 0x101}, {"igemm_krot", 0},
 };
 int g_pfr_knob[KNOB_COUNT];
 static const bool g_knobs_ready = [] { for (int k = 0; k < KNOB_COUNT; ++k) g_pfr_knob[k] = kKnobs[k].def; return true; }();   // (order = enum PfrKnob)

@@ -53,6 +53,7 @@ enum PfrKnob {
   KNOB_SLIN_NP,       // experiments: force its weight-panel width (0 auto, 64 / 96 / 192)
   KNOB_MATCH_ORDER,   // persistent filter GEMM of the gallery match: 1 = L2-blocked tile order per XCD (default), 0 = linear order
   KNOB_LN_RB,         // LayerNorm forward: rows in flight per lane group for C <= 512 (one 16-byte chunk per lane): 4 (default), 6, 8
+  KNOB_SSTEM,         // halo-staged stem convolution (pfr_sstem.hip: 4x4 over 16 channels -> 64): 1 on (default), 0 = the tile kernel
   KNOB_IGEMM_DMA,     // -DPFR_IGEMM_SPREAD experiment builds only: DMA issue schedule of the 128-byte-k-step tile kernels (IgemmParams::dma_sched)
   KNOB_IGEMM_KROT,    // tile kernel: workgroup t starts its k-loop at k-step (t * krot) % nk (0 = every workgroup at k-step 0; summation order changes)
   KNOB_COUNT

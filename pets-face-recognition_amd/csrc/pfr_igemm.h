@@ -72,6 +72,10 @@ int sconv_mtile(int M, int N, int K, long in_rows, int dtype, int out_dtype);
 bool sconv3_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int dtype,
                  int out_dtype, int* bpw);
 int sconv3_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
+// halo-staged stem convolution, 4x4 / pad 2 over 16 channels -> 64 (pfr_sstem.hip); same conventions as sconv3_*
+bool sstem_geom(int N, int H, int W, int C, int Cout, int R, int S, int stride, int pad, int idil_log2, int OH, int OW, int dtype,
+                int out_dtype, int* bpw);
+int sstem_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
 // streaming Linear kernel for K = 96 * j (pfr_slin.hip): returns 1 when it does not take the launch
 int slin_try_launch(IgemmParams& p, int dtype, int out_dtype, hipStream_t st);
 int slin_colsum_parts(IgemmParams& p, int dtype);

@@ -918,6 +918,8 @@ static int launch_igemm(IgemmParams& p, int dtype, int out_dtype, hipStream_t st
     if (!stats_postop) {
       int rc = sconv3_try_launch(p, dtype, out_dtype, st);
       if (rc != 1) return rc;
+      rc = sstem_try_launch(p, dtype, out_dtype, st);
+      if (rc != 1) return rc;
       rc = sconv_try_launch(p, dtype, out_dtype, st);
       if (rc != 1) return rc;
     }
@@ -964,6 +966,7 @@ extern "C" int pfr_conv2d_mtile(int N, int H, int W, int C, int Cout, int R, int
   if (!fused_prologue) {
     int bpw;
     if (sconv3_geom(N, H, W, C, Cout, R, S, stride, pad, 0, OH, OW, dtype, out_dtype, &bpw)) return bpw * 32;
+    if (sstem_geom(N, H, W, C, Cout, R, S, stride, pad, 0, OH, OW, dtype, out_dtype, &bpw)) return bpw * 32;
     if (R == 1 && S == 1 && pad == 0 && (stride == 1 || (H == OH * stride && W == OW * stride))) {
       // 1x1: the streaming kernel publishes one partial per workgroup row range
       const int mt = sconv_mtile(M, Cout, K, (long)N * H * W, dtype, out_dtype);

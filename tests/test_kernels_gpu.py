@@ -604,6 +604,48 @@ def test_halo_staged_3x3_kernel_bit_identical(case):
     assert torch.allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", [(16, 112, 112), (64, 32, 32), (176, 16, 24), (5, 112, 112), (70, 28, 40), (2100, 4, 8), (300, 8, 8), (7, 60, 88)])
+def test_halo_staged_stem_kernel_bit_identical(case):
+    """pfr_sstem.hip (the space-to-depth stem: 4x4 / stride 1 / pad 2 over 16 channels -> 64; weights resident in LDS, one 7x11-pixel halo tile
+    per 4x8 patch, a tap = one k-group, permuted pixel <-> MFMA-column map) must reproduce the implicit-GEMM tile kernel BIT FOR BIT — with
+    BatchNorm statistics (finalised mean / invstd equal to 2e-4) and without — and match torch; the inference epilogue (bias + ReLU) within
+    the one-extra-bf16-rounding bound of test_halo_staged_3x3_inference_epilogue.  Small cases fall back to the tile kernel (too few patches):
+    the knob must then change nothing."""
+    from pets_face_recognition_amd._hip import lib
+    o = ops()
+    N, H, W = case
+    g = torch.Generator().manual_seed(H * W + N)
+    x = torch.randn(N, H, W, 16, generator=g).to(DEV).bfloat16()
+    x[..., 12:] = 0                                          # the space-to-depth image's padding channels
+    w = (torch.randn(64, 4, 4, 16, generator=g) / 14.0).to(DEV).bfloat16()
+    bias = torch.randn(64, generator=g).to(DEV)
+    outs = []
+    try:
+        for mode in (0, 1):
+            lib.pfr_set_tuning(b"sstem", mode)
+            y, part = o.conv2d_fwd(x, w, stride=1, pad=2, out_hw=(H, W), stats=True)
+            mt = lib.pfr_conv2d_mtile(N, H, W, 16, 64, 4, 4, 1, 2, H, W, 1, 1, 0)
+            st = o.bn_finalize(part, mt, N * H * W, None, None, 1e-5, 0.1, None, None)[:2].clone()
+            y2, _ = o.conv2d_fwd(x, w, stride=1, pad=2, out_hw=(H, W), stats=False)
+            yi, _ = o.conv2d_fwd(x, w, stride=1, pad=2, out_hw=(H, W), bias=bias, out_relu=True)
+            torch.cuda.synchronize()
+            outs.append((y.clone(), st, y2.clone(), yi.clone()))
+    finally:
+        lib.pfr_set_tuning(b"sstem", 1)
+    xf, wf = x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2)
+    conv = torch.nn.functional.conv2d(torch.nn.functional.pad(xf, (2, 1, 2, 1)), wf).permute(0, 2, 3, 1)
+    assert conv.shape == outs[0][0].shape
+    assert (outs[0][0].float() - conv).abs().max() <= 2e-2 * conv.abs().max()
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][2], outs[0][2])
+    assert torch.equal(outs[1][0], outs[1][2])
+    assert torch.allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=1e-5)
+    ref = torch.relu(conv + bias)
+    bound = 2.0 ** -8 * ref.abs() + 2.0 ** -8 * conv.abs() + 1e-6
+    assert bool(((outs[1][3].float() - ref).abs() <= bound).all())
+    assert bool(((outs[0][3].float() - ref).abs() <= bound).all())
+    assert (outs[1][3] != outs[0][3]).float().mean().item() < 0.35
+
+
 @pytest.mark.parametrize("case", [
     # (N, H, C, Cout, stride, residual, relu): the BN-folded inference convolutions the streaming kernel takes
     (8, 56, 64, 256, 1, True, True), (8, 56, 256, 64, 1, False, True), (8, 56, 64, 64, 1, False, True), (16, 28, 512, 128, 1, False, True),
