@@ -22,14 +22,14 @@ DATAS = kw.get('data', 'randn').split(','); KROTS = [int(v) for v in kw.get('kro
 dbg = int(kw.get('dbg', 0)); reps = int(kw.get('reps', 30))
 secs = float(kw.get('secs', 0)); SPLITS = [int(v) for v in kw.get('splits', '0').split(',')]
 DMAS = [int(v, 0) for v in kw.get('dma', '0x101').split(',')]
-tile = int(kw.get('tile', -1))   # pfr_set_tuning("igemm_tile"): 4 = the 8-wave 256x256 tile whatever the tile count
+TILES = [int(v) for v in kw.get('tile', '-1').split(',')]   # pfr_set_tuning("igemm_tile"): 4 = the 8-wave 256x256 tile whatever the tile count
 if dbg:
     dll = ctypes.CDLL(os.environ['PFR_LIB_PATH'])
     dll.pfr_debug_igemm_flags(dbg)
 H, C, Co, R, p = FWD[case]
 
 
-def run(N, data, krot, splits, dma=0x101):
+def run(N, data, krot, splits, dma=0x101, tile=-1):
     lib.pfr_set_tuning(b"igemm_dma", dma)
     lib.pfr_set_tuning(b"igemm_krot", krot)
     lib.pfr_set_tuning(b"igemm_tile", tile)
@@ -77,4 +77,5 @@ for N in NS:
         for krot in KROTS:
             for sp in SPLITS:
                 for dma in DMAS:
-                    run(N, data, krot, sp, dma)
+                    for tile in TILES:
+                        run(N, data, krot, sp, dma, tile)
