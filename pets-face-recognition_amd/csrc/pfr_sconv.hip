@@ -712,9 +712,12 @@ bool sconv_plan(int M, int N, int K, long in_rows, int dtype, int out_dtype, Sco
   // re-reading x once per panel (from L2: the panels of a row range run on one XCD) must stay cheaper than what the tile kernels do
   if (mode == 1) {
     // (measured, tools/sconv_bench.py: K = 512 with 4 panels 81 vs 94 us for the tile kernel, with 16 panels 68-72 vs 76-78)
-    constexpr int maxp = 16, maxk = 512;
+    // (round 6: up to 32 panels and down to 8192 rows — the 7x7 layers of ResNet-50 at bs 256, 12 544 rows: 512 -> 2048 forward and its
+    //  data-gradient join, the furthest launch from its bound on the tile kernel (0.17) — train step 17.13 -> 17.03 ms over six interleaved
+    //  rounds, profiles/r06_ab.txt #9; either limit alone changes no launch)
+    constexpr int maxp = 32, maxk = 512;
     if (npanels > maxp || (!k2 && K > maxk) || (K < 512 && npanels > 8)) return false;
-    if (M < 256 * 64) return false;    // too few rows per workgroup for a pipeline
+    if (M < 256 * 32) return false;    // too few rows per workgroup for a pipeline
   }
   int nranges = 256 / npanels;
   long R = ((long)M + nranges - 1) / nranges;
