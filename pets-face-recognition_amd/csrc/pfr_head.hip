@@ -37,9 +37,13 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const TI* __restrict__ 
   }
 }
 
+extern "C" int pfr_l2norm_dual(const float* x, void* xn_bf16, float* xn_f32, float* inv_norm, int rows, int D, float eps, hipStream_t st);
 extern "C" int pfr_l2norm_fwd(const void* x, int in_dtype, void* xn, void* xnT, int out_dtype, float* inv_norm, int rows,
                               int D, int ldt, float eps, hipStream_t st) {
   PFR_CHECK_ARG(x && xn && inv_norm, "pfr_l2norm_fwd: null pointer");
+  // fp32 rows without the transposed copy: the register-resident float4 kernel of the match (one read of x, all loads in flight)
+  if (in_dtype == PFR_F32 && !xnT && D % 4 == 0 && D <= 2048 && rows > 0 && (out_dtype == PFR_F32 || out_dtype == PFR_BF16))
+    return pfr_l2norm_dual((const float*)x, out_dtype == PFR_BF16 ? xn : nullptr, out_dtype == PFR_F32 ? (float*)xn : nullptr, inv_norm, rows, D, eps, st);
   const dim3 grid((rows + 3) / 4), block(256);
   if (ldt <= 0) ldt = rows;
 #define L2N(TI, TOo) hipLaunchKernelGGL((l2norm_fwd_kernel<TI, TOo>), grid, block, 0, st, (const TI*)x, (TOo*)xn, (TOo*)xnT, inv_norm, rows, D, ldt, eps)
@@ -168,15 +172,17 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
   return r;
 }
 
-// one 256-thread block per sample row
+// one block per sample row: 256 threads, or 1024 for long rows (three dependent passes over the row — at 10 000 classes and
+// one wave per SIMD each pass is ~40 exposed memory round trips: 30 us with 256 threads)
 template <typename TG>
-__global__ __launch_bounds__(256) void margin_ce_kernel(const float* __restrict__ cosv, const int64_t* __restrict__ label,
+__global__ __launch_bounds__(1024) void margin_ce_kernel(const float* __restrict__ cosv, const int64_t* __restrict__ label,
                                                         MarginParams mp, float* __restrict__ logits, float* __restrict__ loss_rows,
                                                         TG* __restrict__ dcos, int C, int ldc, float gscale,
                                                         const float* __restrict__ gscale_dev) {
-  __shared__ float sh[4];
+  __shared__ float sh[16];
   if (gscale_dev) gscale *= gscale_dev[0];
   const int row = blockIdx.x;
+  const int nt = blockDim.x;
   const float* cr = cosv + (size_t)row * ldc;
   const int t = (int)label[row];
   // target logit and d(phi)/d(cos)
@@ -198,13 +204,13 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(const float* __restrict_
   }
   const float lt = mp.s * phi;
   float mx = -INFINITY;
-  for (int j = threadIdx.x; j < C; j += 256) {
+  for (int j = threadIdx.x; j < C; j += nt) {
     const float l = (j == t) ? lt : mp.s * cr[j];
     mx = fmaxf(mx, l);
   }
   mx = block_reduce_max(mx, sh);
   float se = 0.f;
-  for (int j = threadIdx.x; j < C; j += 256) {
+  for (int j = threadIdx.x; j < C; j += nt) {
     const float l = (j == t) ? lt : mp.s * cr[j];
     se += expf(l - mx);
   }
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(const float* __restrict_
   }
   if (threadIdx.x == 0 && loss_rows) loss_rows[row] = lossv;
   const float gs = gscale * f;
-  for (int j = threadIdx.x; j < C; j += 256) {
+  for (int j = threadIdx.x; j < C; j += nt) {
     const float l = (j == t) ? lt : mp.s * cr[j];
     if (logits) logits[(size_t)row * C + j] = l;
     if (dcos) {
@@ -243,10 +249,11 @@ extern "C" int pfr_margin_ce(const float* cosv, const int64_t* label, int B, int
   mp.th = (float)cos(M_PI - (double)m);
   mp.mm = (float)(sin(M_PI - (double)m) * (double)m);
   if (ldc <= 0) ldc = C;
+  const int nt = C >= 4096 ? 1024 : 256;
   if (dcos_dtype == PFR_BF16)
-    hipLaunchKernelGGL(margin_ce_kernel<bf16_t>, dim3(B), dim3(256), 0, st, cosv, label, mp, logits, loss_rows, (bf16_t*)dcos, C, ldc, grad_scale, grad_scale_dev);
+    hipLaunchKernelGGL(margin_ce_kernel<bf16_t>, dim3(B), dim3(nt), 0, st, cosv, label, mp, logits, loss_rows, (bf16_t*)dcos, C, ldc, grad_scale, grad_scale_dev);
   else
-    hipLaunchKernelGGL(margin_ce_kernel<float>, dim3(B), dim3(256), 0, st, cosv, label, mp, logits, loss_rows, (float*)dcos, C, ldc, grad_scale, grad_scale_dev);
+    hipLaunchKernelGGL(margin_ce_kernel<float>, dim3(B), dim3(nt), 0, st, cosv, label, mp, logits, loss_rows, (float*)dcos, C, ldc, grad_scale, grad_scale_dev);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

@@ -13,6 +13,11 @@ def _cpad(C, dtype):
     return (C + k - 1) // k * k
 
 
+def _dxn_by_rows(B, Cp, T):
+    """dx̂ as a row-split reduction over the classes (see _cosine_bwd) rather than a plain GEMM against ŵᵀ"""
+    return B % (8 if T == torch.bfloat16 else 4) == 0 and Cp >= 2048
+
+
 def _cosine_fwd(emb, weight, T):
     """→ cos [B, Cpad] f32 and the saved normalised operands"""
     B, D = emb.shape
@@ -20,7 +25,9 @@ def _cosine_fwd(emb, weight, T):
     Cp = _cpad(C, T)
     xn, _, inv_x = ops.l2norm_fwd(emb, T)
     wn_full = torch.zeros((Cp, D), dtype=T, device=emb.device) if Cp != C else torch.empty((C, D), dtype=T, device=emb.device)
-    wn, wnT, inv_w = ops.l2norm_fwd(weight, T, want_t=True, ldt=Cp, xn=wn_full[:C])
+    # ŵᵀ is the operand of the plain-GEMM form of dx̂ only: _cosine_bwd's row-split form reads ŵ itself (and the transposed
+    # write, 2-byte elements a class apart, is most of this kernel's time at 10 000 classes)
+    wn, wnT, inv_w = ops.l2norm_fwd(weight, T, want_t=not _dxn_by_rows(B, Cp, T), ldt=Cp, xn=wn_full[:C])
     cos = torch.empty((B, 1, 1, Cp), dtype=torch.float32, device=emb.device)
     ops.conv2d_fwd(xn.view(B, 1, 1, D), wn.view(C, 1, 1, D), out=cos)
     return cos.view(B, Cp), (xn, wnT, inv_x, inv_w, wn_full)
@@ -32,8 +39,7 @@ def _cosine_bwd(dcos, emb, weight, saved, T):
     B, D = emb.shape
     C = weight.shape[0]
     Cp = dcos.shape[1]
-    kp = 8 if T == torch.bfloat16 else 4
-    if B % kp == 0 and Cp >= 2048:
+    if _dxn_by_rows(B, Cp, T):
         # dxn[b][d] = Σ_c dcos[b][c]·wn[c][d]: the reduction runs over the CLASS dimension (10 000), the output is only B x D —
         # as a plain GEMM that is 8-16 tiles with a 10 000-long k-loop (0.2 ms on 8 CUs); as a "weight gradient" over the rows
         # of (wn, dcosᵀ) it is split over ~40 row ranges and takes ~20 µs
