@@ -368,6 +368,14 @@ int pfr_topk_finish(const void* state, int rows, int K, float* out_scores, int* 
  * and no normalised fp32 copy of the gallery has to exist (2 GB less written per 1 M x 512 match) */
 int pfr_topk_rescore(const float* q, const float* g, const float* g_scale, int rows, int D, const int* cand, int KC, int K,
                      float* out_scores, int* out_idx, pfr_stream_t stream);
+/* the same, and the certificate of the two-precision match (the reference scores every pair in fp32 — utils/calc_scores.py's torch.mm — so a
+ * reduced-precision candidate selection has to show that it lost nothing): cand_scores [rows][KC] = the selection scores pfr_topk_finish
+ * returned with cand; cert [rows][2] fp32: cert[r][0] = max |fp32 score - selection score| over r's candidates, cert[r][1] = (K-th best
+ * fp32 score) - (selection score of r's last candidate), +inf when the list holds every eligible gallery row.  A gallery row outside the list
+ * can belong to r's exact top-K only if its selection error exceeds cert[r][1]; the host compares that gap with the errors measured on all
+ * candidates and re-matches the rows that fail (match.cosine_topk). */
+int pfr_topk_rescore_cert(const float* q, const float* g, const float* g_scale, int rows, int D, const int* cand, const float* cand_scores,
+                          int KC, int K, float* out_scores, int* out_idx, float* cert, pfr_stream_t stream);
 /* out[p] = (cos(emb[idx_a[p]], emb[idx_b[p]]) + 1) / 2, norms clamped at eps (F.cosine_similarity) */
 int pfr_pair_similarity(const float* emb, int D, const long* idx_a, const long* idx_b, int P, float eps, float* out,
                         pfr_stream_t stream);

@@ -362,11 +362,18 @@ extern "C" int pfr_topk_finish(const void* state, int rows, int K, float* out_sc
 
 // exact fp32 re-scoring of candidate lists: score = <q[r], g[idx]> on the fp32 (normalised) rows, then re-sort and keep K.
 // one workgroup per query; a wave computes one dot product at a time.
+// With cand_scores (the reduced-precision scores the candidates were selected on, aligned with cand) it also leaves the row's certificate:
+//   cert[row][0] = max |fp32 score - selection score| over the row's candidates (how far the selection scores are off, measured)
+//   cert[row][1] = (K-th best fp32 score) - (selection score of the LAST candidate): every gallery row outside the list scored at most that
+//                  last selection score, so it can belong to the exact top-K only if its own selection error exceeds this gap (+inf when
+//                  the list holds every eligible row)
 __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q, const float* __restrict__ g,
                                                       const float* __restrict__ g_scale, int D,
-                                                      const int* __restrict__ cand, int KC, int K,
-                                                      float* __restrict__ out_scores, int* __restrict__ out_idx) {
+                                                      const int* __restrict__ cand, const float* __restrict__ cand_scores, int KC, int K,
+                                                      float* __restrict__ out_scores, int* __restrict__ out_idx, float* __restrict__ cert) {
   __shared__ unsigned long long list[512];
+  __shared__ unsigned s_err;
+  if (threadIdx.x == 0) s_err = 0u;
   const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* qr = q + (size_t)row * D;
   int p2 = 1;
@@ -400,7 +407,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
       float v = wave_sum(a[u]);
       if (gi[u] >= 0) {
         if (g_scale) v *= g_scale[gi[u]];      // g = the RAW gallery rows, g_scale = 1 / max(|g_i|, eps): no normalised fp32 copy of the gallery
-        if (lane == 0) list[c0 + u] = ((unsigned long long)fkey(v) << 32) | (uint32_t)(~(uint32_t)gi[u]);
+        if (lane == 0) {
+          list[c0 + u] = ((unsigned long long)fkey(v) << 32) | (uint32_t)(~(uint32_t)gi[u]);
+          if (cand_scores) atomicMax(&s_err, __float_as_uint(fabsf(v - cand_scores[(size_t)row * KC + c0 + u])));   // (>= 0: bit order = value order)
+        }
       }
     }
   }
@@ -416,13 +426,27 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
       out_idx[(size_t)row * K + i] = -1;
     }
   }
+  if (cert && threadIdx.x == 0) {
+    const bool full = cand[(size_t)row * KC + KC - 1] >= 0 && list[K - 1] != 0ull;
+    cert[2 * row] = __uint_as_float(s_err);
+    cert[2 * row + 1] = full ? fkey_inv((uint32_t)(list[K - 1] >> 32)) - cand_scores[(size_t)row * KC + KC - 1] : INFINITY;
+  }
+}
+
+extern "C" int pfr_topk_rescore_cert(const float* q, const float* g, const float* g_scale, int rows, int D, const int* cand,
+                                     const float* cand_scores, int KC, int K, float* out_scores, int* out_idx, float* cert, hipStream_t st) {
+  PFR_CHECK_ARG(q && g && cand && cand_scores && cert && out_scores && out_idx, "pfr_topk_rescore_cert: null pointer");
+  PFR_CHECK_ARG(D % 4 == 0 && KC <= 512 && K >= 1 && K <= KC, "pfr_topk_rescore_cert: need D %% 4 == 0, 1 <= K <= KC <= 512");
+  hipLaunchKernelGGL(rescore_kernel, dim3(rows), dim3(256), 0, st, q, g, g_scale, D, cand, cand_scores, KC, K, out_scores, out_idx, cert);
+  PFR_CHECK_LAUNCH();
+  return PFR_OK;
 }
 
 extern "C" int pfr_topk_rescore(const float* q, const float* g, const float* g_scale, int rows, int D, const int* cand, int KC, int K,
                                 float* out_scores, int* out_idx, hipStream_t st) {
   PFR_CHECK_ARG(q && g && cand && out_scores && out_idx, "pfr_topk_rescore: null pointer");
   PFR_CHECK_ARG(D % 4 == 0 && KC <= 512 && K <= KC, "pfr_topk_rescore: need D %% 4 == 0, K <= KC <= 512");
-  hipLaunchKernelGGL(rescore_kernel, dim3(rows), dim3(256), 0, st, q, g, g_scale, D, cand, KC, K, out_scores, out_idx);
+  hipLaunchKernelGGL(rescore_kernel, dim3(rows), dim3(256), 0, st, q, g, g_scale, D, cand, (const float*)nullptr, KC, K, out_scores, out_idx, (float*)nullptr);
   PFR_CHECK_LAUNCH();
   return PFR_OK;
 }

@@ -71,14 +71,26 @@ def prepare_gallery(g, compute_dtype=torch.bfloat16, rescore=None, normalize=Tru
     return PreparedGallery(gn, gn32, T, bool(rescore), bool(normalize))
 
 
-def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self=False, rescore=None, slack=None,
-                normalize=True, fused_filter=True, merge_every=2, seed_cols="auto"):
+#: what the last certified `cosine_topk` call on this process did: queries, candidates per query, the largest selection-score error measured,
+#: queries re-matched with a wider candidate list, queries re-matched exactly in fp32
+last_match_stats = {}
+_CERT_SAFETY = 2.0     # a query is certified when its gap is at least this many times the LARGEST selection error measured on any candidate
+
+
+def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=131072, exclude_self=False, rescore=None, slack=None,
+                normalize=True, fused_filter=True, merge_every=2, seed_cols="auto", certify=None):
     """Top-k gallery rows per query by cosine similarity.  q [Q,D], g [G,D] (any scale; rows are L2-normalised here) or a
     `prepare_gallery(g)` handle (the gallery's normalisation is then not repeated per call).
     → (scores [Q,k] fp32 cosine, idx [Q,k] int32, −1 / −inf padded when fewer than k exist).
     exclude_self: q and g are the same set, the diagonal is skipped (the reference excludes the query itself).
     rescore (default: True for bf16): candidates are selected on bf16-input scores with `slack` extra entries, then
-    re-scored exactly in fp32 and re-sorted, so that the final order is the fp32 order."""
+    re-scored exactly in fp32 and re-sorted, so that the final order is the fp32 order.
+    certify (default: with rescore): the selection is CHECKED instead of trusted.  Every gallery row outside a query's candidate list has a
+    selection score of at most the list's last one, so it can belong to the exact top-k only if its selection error exceeds
+    gap = (k-th best fp32 score) − (last selection score).  The re-scoring measures the selection error on every candidate (Q x kc samples of
+    the same data); a query whose gap is below twice the largest error seen is matched again with a four times wider slack, and in fp32
+    (exactly the reference's arithmetic) if it fails again.  With the check the default slack is max(28, k / 4) instead of max(28, 1.5 k):
+    13.5 instead of 15.0 ms at 10 k x 1 M x 512 on one box, same results (`last_match_stats` records what the check did)."""
     prepared = g if isinstance(g, PreparedGallery) else None
     if not q.is_cuda:
         if prepared is not None:
@@ -89,6 +101,9 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
     T = compute_dtype
     if rescore is None:
         rescore = T != torch.float32
+    if certify is None:
+        certify = bool(rescore)
+    certify = bool(certify and rescore)
     if prepared is not None and (prepared.compute_dtype != T or prepared.rescore != bool(rescore) or prepared.normalized != bool(normalize)
                                  or prepared.shape[1] != D or prepared.device != q.device):
         raise PfrError("cosine_topk: the PreparedGallery was built for other settings "
@@ -97,24 +112,75 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
         # the running lists of the top-K kernels hold at most 512 entries per query (pfr_match.hip); silently returning
         # fewer columns, or re-scoring past the candidate list, would be wrong answers
         raise PfrError(f"cosine_topk: k={k} exceeds the 512-entry running list of the gfx950 top-K kernels")
-    kc = k
-    if rescore:
-        kc = max(k, min(512, k + (slack if slack is not None else max(28, k // 2 + k))))
+    if slack is None:
+        slack = max(28, (k + 3) // 4) if certify else max(28, k // 2 + k)
+    kc = max(k, min(512, k + slack)) if rescore else k
     q32 = q.float().contiguous()
     qn, qn32 = _prep_rows(q32, T, rescore, normalize)
     if prepared is not None:
         gn, gn32, gscale = prepared.gn, prepared.gn32, None      # (a handle owns a normalised copy: the caller may refill its buffer)
     else:
         gn, gn32, gscale = _prep_rows(g.float().contiguous(), T, rescore, normalize, borrow=True)
+    sched = dict(chunk=chunk, exclude_self=exclude_self, fused_filter=fused_filter, merge_every=merge_every, seed_cols=seed_cols)
+    if not rescore:
+        return _topk_pass(qn, None, gn, None, None, k, k, T, False, **sched)[:2]
+    sc, idx, cert = _topk_pass(qn, qn32, gn, gn32, gscale, k, kc, T, certify, **sched)
+    if not certify:
+        return sc, idx
+    # ---- the certificate (see the docstring).  One host synchronisation; the re-matches below run only for the queries that fail.
+    eps = cert[:, 0].max()
+    bad = (cert[:, 1] < _CERT_SAFETY * eps).nonzero().flatten()
+    stats = {"queries": Q, "candidates": kc, "max_selection_error": float(eps), "widened": 0, "exact": 0}
+    if bad.numel():
+        kc2 = max(k, min(512, k + 4 * slack))
+        if kc2 > kc:
+            # (with exclude_self the fused filter identifies "self" by row == column: the whole set is matched again, not a subset)
+            rows = None if exclude_self else bad
+            stats["widened"] = Q if rows is None else int(rows.numel())
+            s2, i2, c2 = _topk_pass(qn if rows is None else qn[rows], qn32 if rows is None else qn32[rows], gn, gn32, gscale, k, kc2, T, True, **sched)
+            eps = torch.maximum(eps, c2[:, 0].max())
+            still = c2[:, 1] < _CERT_SAFETY * eps
+            if rows is None:
+                sc, idx, bad = s2, i2, still.nonzero().flatten()
+            else:
+                sc[rows], idx[rows] = s2, i2
+                bad = rows[still]
+        if bad.numel():
+            # fp32 scores of every pair for these queries: the reference's own arithmetic (utils/calc_scores.py: torch.mm on fp32)
+            rows = None if exclude_self else bad
+            stats["exact"] = Q if rows is None else int(rows.numel())
+            if gscale is None:      # gn32 holds the rows the scores are defined on (normalised, or as given with normalize=False)
+                s3, i3 = cosine_topk(qn32 if rows is None else qn32[rows], gn32, k, compute_dtype=torch.float32, chunk=chunk,
+                                     exclude_self=exclude_self, normalize=False)
+            else:                   # gn32 = the caller's raw rows
+                s3, i3 = cosine_topk(q32 if rows is None else q32[rows], gn32, k, compute_dtype=torch.float32, chunk=chunk,
+                                     exclude_self=exclude_self, normalize=normalize)
+            if rows is None:
+                sc, idx = s3, i3
+            else:
+                sc[rows], idx[rows] = s3, i3
+    stats["max_selection_error"] = float(eps)
+    last_match_stats.clear()
+    last_match_stats.update(stats)
+    return sc, idx
+
+
+def _topk_pass(qn, qn32, gn, gn32, gscale, k, kc, T, certify, chunk=131072, exclude_self=False, fused_filter=True, merge_every=2,
+               seed_cols="auto"):
+    """One pass of prepared query rows over the prepared gallery: running top-kc lists per query (selection scores in T), then — with
+    qn32 / gn32 — the exact fp32 re-scoring that keeps k.  → (scores [Q,k], idx [Q,k], certificate [Q,2] or None)."""
+    Q, D = qn.shape
+    G = gn.shape[0]
+    rescore = qn32 is not None
     chunk = min(chunk, G)
-    state = torch.empty(lib.pfr_topk_state_bytes(Q, kc), dtype=torch.uint8, device=q.device)
-    self_idx = torch.arange(Q, dtype=torch.int32, device=q.device) if exclude_self else None
+    state = torch.empty(lib.pfr_topk_state_bytes(Q, kc), dtype=torch.uint8, device=qn.device)
+    self_idx = torch.arange(Q, dtype=torch.int32, device=qn.device) if exclude_self else None
     # Chunks after the first (every running list is full by then) use the GEMM with the top-K filter in its epilogue: the
     # fp32 score chunk is never written.  A candidate-list overflow (adversarially ordered gallery) is flagged on the
     # device and the whole match is redone on the unfused path.
     fused = fused_filter and G > chunk and chunk >= kc + 1 and D % (64 if T == torch.bfloat16 else 32) == 0
     cap = 1536
-    cand = torch.empty((Q, cap), dtype=torch.int64, device=q.device) if fused else None
+    cand = torch.empty((Q, cap), dtype=torch.int64, device=qn.device) if fused else None
     sbuf = None
     while True:
         lib.pfr_topk_reset(state.data_ptr(), Q, kc, _stream())
@@ -125,7 +191,9 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
         #  the candidates per query and their merges cost more than the unfused first chunk they replace; profiles/r04_match_seed_ab.txt.)
         segs = [(c0, min(chunk, G - c0), bool(fused and c0 > 0)) for c0 in range(0, G, chunk)]
         if seed_cols == "auto":     # (a seed pays once the gallery is several chunks long)
-            seed_cols = chunk // 2 if (chunk == 65536 and G >= 4 * chunk) else None
+            # (round 6, tools/match_sched_ab.py with the certified 128-entry lists: 131 072-column chunks after a 16 384-column seed 13.4 ms,
+            #  65 536 / 32 768 — the round-5 schedule — 13.8, 65 536 / 16 384 13.4-13.7, 262 144 / 32 768 13.7)
+            seed_cols = 16384 if (chunk >= 65536 and G >= 262144) else None
         if fused and seed_cols and kc + 1 <= seed_cols < chunk:
             # round 5 (tools/match_seed_ab.py, profiles/r05_ab.txt): an unfused seed of `seed_cols` columns, then fused segments that double
             # up to `chunk`, each of the early ones merged at once (their thresholds are loose).  Round 4 had measured this form SLOWER
@@ -139,7 +207,7 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
                 n = min(2 * n, chunk)
         ld = (max(n for _, n, f in segs if not f) + 3) // 4 * 4
         if sbuf is None or sbuf.shape[-1] < ld:
-            sbuf = torch.empty((Q, 1, 1, ld), dtype=torch.float32, device=q.device)
+            sbuf = torch.empty((Q, 1, 1, ld), dtype=torch.float32, device=qn.device)
         ld = sbuf.shape[-1]
         # the candidate lists of TWO fused chunks are folded into the running lists by one merge (expected candidates per query for two
         # chunks: <= 2 * kc, cap = 1536; an overflow is flagged and the match redone unfused): 18.4 -> 17.9 ms at 10 k x 1 M, same results;
@@ -164,16 +232,21 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=65536, exclude_self
         if not (flag.value & 2):
             break
         fused = False   # candidate buffer overflow: redo without the fused filter
-    sc = torch.empty((Q, kc), dtype=torch.float32, device=q.device)
-    idx = torch.empty((Q, kc), dtype=torch.int32, device=q.device)
+    sc = torch.empty((Q, kc), dtype=torch.float32, device=qn.device)
+    idx = torch.empty((Q, kc), dtype=torch.int32, device=qn.device)
     lib.pfr_topk_finish(state.data_ptr(), Q, kc, sc.data_ptr(), idx.data_ptr(), _stream())
     if rescore:
-        sc2 = torch.empty((Q, k), dtype=torch.float32, device=q.device)
-        idx2 = torch.empty((Q, k), dtype=torch.int32, device=q.device)
-        lib.pfr_topk_rescore(qn32.data_ptr(), gn32.data_ptr(), 0 if gscale is None else gscale.data_ptr(), Q, D, idx.data_ptr(), kc, k,
-                             sc2.data_ptr(), idx2.data_ptr(), _stream())
-        return sc2, idx2
-    return sc[:, :k].contiguous(), idx[:, :k].contiguous()
+        sc2 = torch.empty((Q, k), dtype=torch.float32, device=qn.device)
+        idx2 = torch.empty((Q, k), dtype=torch.int32, device=qn.device)
+        gs = 0 if gscale is None else gscale.data_ptr()
+        if certify:
+            cert = torch.empty((Q, 2), dtype=torch.float32, device=qn.device)
+            lib.pfr_topk_rescore_cert(qn32.data_ptr(), gn32.data_ptr(), gs, Q, D, idx.data_ptr(), sc.data_ptr(), kc, k,
+                                      sc2.data_ptr(), idx2.data_ptr(), cert.data_ptr(), _stream())
+            return sc2, idx2, cert
+        lib.pfr_topk_rescore(qn32.data_ptr(), gn32.data_ptr(), gs, Q, D, idx.data_ptr(), kc, k, sc2.data_ptr(), idx2.data_ptr(), _stream())
+        return sc2, idx2, None
+    return sc[:, :k].contiguous(), idx[:, :k].contiguous(), None
 
 
 def _cosine_topk_torch(q, g, k, exclude_self, normalize=True):

@@ -392,3 +392,72 @@ def test_prepared_gallery_handle_equals_the_one_shot_match():
     assert torch.equal(i3, keep)
     s4, i4 = cosine_topk(q, gal, 20, chunk=16384)
     assert not torch.equal(i4, keep)
+
+
+def _sets_equal_up_to_fp64_near_ties(idx, ref_idx, q, g, k, tol=2e-6):
+    """every member of one top-k set that is missing from the other scores within `tol` (fp64 cosine) of the k-th best"""
+    qn = torch.nn.functional.normalize(q.double(), dim=1)
+    gn = torch.nn.functional.normalize(g.double(), dim=1)
+    bad = 0
+    for r in range(idx.shape[0]):
+        a, b = set(idx[r].tolist()), set(ref_idx[r].tolist())
+        if a == b:
+            continue
+        kth = torch.sort(gn[ref_idx[r].long()] @ qn[r], descending=True).values[k - 1]
+        diff = torch.tensor(sorted(a ^ b), dtype=torch.long)
+        if ((gn[diff] @ qn[r]) - kth).abs().max() > tol:
+            bad += 1
+    return bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [65536, 16384])
+def test_certified_match_recovers_what_a_short_candidate_list_loses(chunk):
+    """Round 6: the bf16 candidate selection is checked, not trusted (match.cosine_topk `certify`).  Gallery with 6000 near-copies of one
+    direction (fp32 scores 1e-6 apart, bf16 selection errors 1e-3): a 78-entry candidate list cannot contain the exact top-50 of the queries
+    near that direction.  The certificate must flag exactly those queries, the wider list must fail too, and the fp32 re-match must return the
+    reference's answer; queries elsewhere stay on the fast path.  Unfused (one chunk) and fused-filter (four chunks) schedules."""
+    from pets_face_recognition_amd import match
+    g = torch.Generator().manual_seed(11)
+    D, K = 128, 50
+    base = torch.randn(D, generator=g)
+    dense = base[None, :] + 0.02 * torch.randn(6000, D, generator=g)
+    gal = torch.cat([dense, torch.randn(54000, D, generator=g)])[torch.randperm(60000, generator=g)]
+    q_dense = base[None, :] + 0.02 * torch.randn(6, D, generator=g)
+    q_far = torch.randn(40, D, generator=g)
+    qry = torch.cat([q_far[:20], q_dense, q_far[20:]])
+    rs, ri = match.cosine_topk(qry.to(DEV), gal.to(DEV), K, compute_dtype=torch.float32, chunk=chunk)      # the reference's arithmetic
+    sc, idx = match.cosine_topk(qry.to(DEV), gal.to(DEV), K, chunk=chunk)
+    st = dict(match.last_match_stats)
+    assert st["queries"] == 46 and st["candidates"] == 78
+    assert st["widened"] == 6 and st["exact"] == 6, st
+    assert 1e-4 < st["max_selection_error"] < 2e-2, st
+    assert _sets_equal_up_to_fp64_near_ties(idx.cpu(), ri.cpu(), qry, gal, K) == 0
+    far = torch.cat([torch.arange(20), torch.arange(26, 46)])
+    assert _sets_equal_up_to_fp64_near_ties(idx.cpu()[far], ri.cpu()[far], qry[far], gal, K) == 0
+    assert torch.allclose(sc, rs, rtol=0, atol=3e-6)
+    # the uncertified call with the same short list does lose members of those six sets (what the check is for) ...
+    _, i_unc = match.cosine_topk(qry.to(DEV), gal.to(DEV), K, chunk=chunk, slack=28, certify=False)
+    assert _sets_equal_up_to_fp64_near_ties(i_unc.cpu()[20:26], ri.cpu()[20:26], qry[20:26], gal, K) > 0
+    # ... and benign data is certified as it is: nothing re-matched
+    gal2 = torch.randn(60000, D, generator=g)
+    s2, i2 = match.cosine_topk(q_far.to(DEV), gal2.to(DEV), K, chunk=chunk)
+    assert match.last_match_stats["widened"] == 0 and match.last_match_stats["exact"] == 0
+    _, r2 = match.cosine_topk(q_far.to(DEV), gal2.to(DEV), K, compute_dtype=torch.float32, chunk=chunk)
+    assert _sets_equal_up_to_fp64_near_ties(i2.cpu(), r2.cpu(), q_far, gal2, K) == 0
+
+
+@pytest.mark.gpu
+def test_certified_match_with_exclude_self_rematches_the_whole_set():
+    """exclude_self identifies the query by row == column in the fused filter: a failed certificate re-matches every query, not a subset"""
+    from pets_face_recognition_amd import match
+    g = torch.Generator().manual_seed(12)
+    D, K = 64, 20
+    base = torch.randn(D, generator=g)
+    emb = torch.cat([base[None, :] + 0.01 * torch.randn(3000, D, generator=g), torch.randn(30000, D, generator=g)]).to(DEV)
+    rs, ri = match.cosine_topk(emb, emb, K, compute_dtype=torch.float32, exclude_self=True, chunk=8192)
+    sc, idx = match.cosine_topk(emb, emb, K, exclude_self=True, chunk=8192)
+    assert match.last_match_stats["exact"] == emb.shape[0]
+    assert (idx != torch.arange(emb.shape[0], device=DEV, dtype=idx.dtype)[:, None]).all()
+    assert _sets_equal_up_to_fp64_near_ties(idx.cpu()[:200], ri.cpu()[:200], emb.cpu()[:200], emb.cpu(), K) == 0
+    assert torch.allclose(sc, rs, rtol=0, atol=3e-6)

@@ -5,6 +5,7 @@ import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pets_face_recognition_amd.match import cosine_topk
+from pets_face_recognition_amd import match as _match
 
 Q = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
@@ -24,15 +25,19 @@ res, sets = {}, {}
 for name, dt in (("bf16+fp32 rescore", torch.bfloat16), ("f32", torch.float32)):
     sc, idx = cosine_topk(qry, gal, K, compute_dtype=dt)          # warm-up (allocations, first launches)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sc, idx = cosine_topk(qry, gal, K, compute_dtype=dt)
-    torch.cuda.synchronize()
-    dtm = time.perf_counter() - t0
+    ts = []
+    for _ in range(3):                                            # median of three single matches
+        t0 = time.perf_counter()
+        sc, idx = cosine_topk(qry, gal, K, compute_dtype=dt)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dtm = sorted(ts)[1]
     hit = gcls[idx.long().clamp_min(0)] == qcls[:, None]
     r10, r100 = hit[:, :10].any(1).float().mean().item(), hit[:, :100].any(1).float().mean().item()
     sets[name] = idx.long().sort(1).values
     res[name] = dict(seconds=round(dtm, 4), tflops=round(2.0 * Q * G * D / dtm / 1e12, 1), pairs_per_s=round(Q * G / dtm / 1e9, 2),
-                     candR10=round(r10, 4), candR100=round(r100, 4), idx_checksum=int(idx.long().sum().item()))
+                     candR10=round(r10, 4), candR100=round(r100, 4), idx_checksum=int(idx.long().sum().item()),
+                     certificate=dict(_match.last_match_stats) if dt == torch.bfloat16 else None)
 # the two paths return the same top-100 SET unless the fp32 scores at ranks 100 / 101 differ by less than the f32-MFMA vs
 # re-score summation-order noise (checked against an fp64 ranking in tests/test_fullsize_gpu.py)
 a, b = sets["bf16+fp32 rescore"], sets["f32"]
