@@ -436,7 +436,10 @@ int pfr_gemm_act_colsums(const void* x, const void* w, void* y, int dtype, long 
  * For hosts that bind this library directly; replaces DistributedDataParallel's bucket all-reduce (utils/__init__.py:114-119).
  * RCCL is resolved with dlopen at first use (no load-time dependency).  pfr_comm_unique_id: rank 0 fills a 128-byte id, the
  * host distributes it; pfr_comm_init: one communicator per process / GPU (current HIP device), NULL on error;
- * pfr_comm_allreduce: in place, `count` elements of dtype, mean over the ranks when average != 0, asynchronous on `stream`. */
+ * pfr_comm_allreduce: in place, `count` elements of dtype, mean over the ranks when average != 0, asynchronous and ORDERED on `stream`: the
+ * collective itself runs on a high-priority stream the communicator owns (so that it does not share a hardware queue with the caller's compute
+ * streams), tied to `stream` by an event on either side — work enqueued on `stream` before the call is complete before the collective reads
+ * `buf`, work enqueued after it sees the reduced values. */
 int pfr_comm_unique_id(void* id128);
 void* pfr_comm_init(int rank, int world, const void* id128);
 int pfr_comm_allreduce(void* comm, void* buf, size_t count, int dtype, int average, pfr_stream_t stream);
