@@ -62,7 +62,9 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   constexpr int RED = NW * BP * 2 * 4;
   constexpr int PROB = PRO ? 2 * 2048 * 4 : 0;  // fused-prologue coefficients (scale, shift) of up to 2048 channels
   // FILT (top-K filter epilogue, act 4): scores are compared straight from the accumulators — no transpose buffer
-  constexpr int SMEM = FILT ? NST * STAGE : ((NST * STAGE + PROB > EPI + RED) ? NST * STAGE + PROB : EPI + RED);
+  // FILT: + two winner queues of one entry per thread (u64 key|~column and the query row) and their counters: see "deferred append" below
+  constexpr int FQCAP = NW * 64, FQOFF = NST * STAGE, FQBYTES = FILT ? 2 * FQCAP * 12 + 16 : 0;
+  constexpr int SMEM = FILT ? NST * STAGE + FQBYTES : ((NST * STAGE + PROB > EPI + RED) ? NST * STAGE + PROB : EPI + RED);
   static_assert(SMEM <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
@@ -106,10 +108,48 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
     return true;
   };
   bool prefetched = false;   // FILT: k-step 0 of this tile went out under the previous tile's epilogue
+  // FILT, deferred append.  A winner needs a slot of its query's candidate list (one returning global atomic) before it can be written:
+  // done in the epilogue that found it, that dependent round trip ended every tile (1.9 of 20 us: every tile has a wave with a winner, and the
+  // next tile's first barrier waits for it).  Instead the epilogue of tile t only PUSHES its winners into LDS queue t & 1; right after the first
+  // barrier of tile t + 1 (every wave is past that epilogue) thread i takes entry i and issues the atomic; the entry is written to the list after
+  // the first barrier of tile t + 2, when the slot has long arrived — both under a k-loop.  The queues drain after the last tile.  (The order of
+  // a candidate list is irrelevant: pfr_topk_merge sorts by key.)
+  unsigned long long* const fq_key = reinterpret_cast<unsigned long long*>(smem + FQOFF);           // [2][FQCAP]
+  int* const fq_row = reinterpret_cast<int*>(smem + FQOFF + 2 * FQCAP * 8);                           // [2][FQCAP]
+  int* const fq_cnt = reinterpret_cast<int*>(smem + FQOFF + 2 * FQCAP * 12);                          // [2] pushes attempted (may exceed FQCAP)
+  int fq_slot = -1;          // slot of this thread's entry of queue (ft & 1) (atomic in flight / arrived), -1: none
+  uint32_t ft = 0;           // tiles this workgroup has started
+  if constexpr (FILT) {
+    if (tid < 2) fq_cnt[tid] = 0;   // (published by the first tile's first barrier, long before its epilogue pushes)
+  }
+  // after the first barrier of a tile (or at the drain): write the entries whose slot has arrived, take slots for the newer queue
+  auto fq_step = [&]() {
+    if constexpr (FILT) {
+      const int b = (int)(ft & 1);
+      unsigned long long* const cand = reinterpret_cast<unsigned long long*>(p.y);
+      if (fq_slot >= 0) {
+        if (fq_slot < p.cap) cand[(size_t)fq_row[b * FQCAP + tid] * p.cap + fq_slot] = fq_key[b * FQCAP + tid];
+        fq_slot = -1;
+      }
+      const int n = min(fq_cnt[b ^ 1], FQCAP);
+      if (tid < n) fq_slot = atomicAdd(&p.ccnt[fq_row[(b ^ 1) * FQCAP + tid]], 1);
+    }
+  };
   for (uint32_t it = 0;; ++it) {
   int tm, tn;
-  if (!tile_at(it, tm, tn)) break;
+  if (!tile_at(it, tm, tn)) {
+    if constexpr (FILT) {   // drain the winner queues: the last tile's entries have no slot yet, the one before's no write
+      __syncthreads();
+      fq_step();
+      ++ft;
+      if (fq_slot >= 0 && fq_slot < p.cap)
+        reinterpret_cast<unsigned long long*>(p.y)[(size_t)fq_row[(ft & 1) * FQCAP + tid] * p.cap + fq_slot] = fq_key[(ft & 1) * FQCAP + tid];
+    }
+    TSTAMP(6);
+    break;
+  }
   if (tm < 0) continue;
+  TSTAMP(5);
   if (!FILT && it > 0) break;
   const int n0 = tn * BP;
   const int cls = p.pclass ? tm / p.tpc : 0;
@@ -355,6 +395,19 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // FILT: this lane's thresholds (the keys of its query rows' current K-th best) are requested HERE, a whole k-loop before the epilogue compares
+  // against them: loaded in the epilogue they were a memory round trip at the end of every tile (1 us of 20).  A threshold that a concurrent
+  // pfr_topk_merge raises in the meantime is only a looser, still valid bound.
+  uint32_t tks[FILT ? TQ : 1];
+  if constexpr (FILT) {
+    const uint32_t* thrk = reinterpret_cast<const uint32_t*>(p.y2);
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int m = m0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
+      tks[j] = m < p.M ? thrk[m] : 0xFFFFFFFFu;
+    }
+  }
+
   // ---- NST-slot ring with counted waits: the DMA of k-steps kt+2 … kt+NST-1 stays in flight across the barrier that
   //      publishes kt+1 (raw s_barrier: no implicit vmcnt(0) drain); NST = 2 is the classic double buffer.
   auto wait_pending = [&](int tiles) {  // wait until at most `tiles` k-steps of DMA remain outstanding
@@ -375,6 +428,12 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   TSTAMP(2);
+  const int fb = (int)(ft & 1);   // FILT: the winner queue this tile's epilogue pushes into
+  if constexpr (FILT) {
+    fq_step();
+    if (tid == 0) fq_cnt[fb] = 0;   // (its old entries were written just above; the pushes come after this tile's k-loop barriers)
+    ++ft;
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int slot = kt % NST;
     const char* base = smem + slot * STAGE;
@@ -423,16 +482,9 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
   TSTAMP(3);
   if constexpr (FILT) {
     // ---- top-K filter epilogue (gallery match): a lane owns query row m of each 32x32 tile and 16 gallery columns of it
-    const uint32_t* thrk = reinterpret_cast<const uint32_t*>(p.y2);
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(p.y);
-    uint32_t tks[TQ];
-#pragma unroll
-    for (int j = 0; j < TQ; ++j) {
-      const int m = m0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
-      tks[j] = m < p.M ? thrk[m] : 0xFFFFFFFFu;
-    }
     // the first k-step of this workgroup's NEXT tile goes out now, under the compare loops (every wave is past the k-loop's last
-    // barrier: ring slot 0 is free); the thresholds above were requested first, so waiting for them does not wait for the DMA
+    // barrier: ring slot 0 is free)
     if constexpr (FAST) {
       int tmx, tnx;
       if (tile_at(it + 1, tmx, tnx) && tmx >= 0) {
@@ -462,27 +514,50 @@ __global__ __launch_bounds__(NW * 64, (KCH_ == 4 && NW == 4 && NST_ == 2 && size
 #pragma unroll
     for (int j = 0; j < TQ; ++j) fastw = fastw && __all(tks[j] > 0x80000000u);
     if (fastw) {
+      // per 32x32 accumulator block: the lane's maximum of its 16 scores first (8 three-input maxima instead of 16 compare + add pairs); only a
+      // block in which SOME lane of the wave has a winner (one in five in a late chunk) runs the count / push code at all — with the whole
+      // row range of a lane in one pass, 83 % of the waves walked all 128 guarded pushes of it
 #pragma unroll
       for (int j = 0; j < TQ; ++j) {
         const int m = m0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
         const float thr = fkey_inv(tks[j]);
-        int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < TP; ++i)
+        for (int i = 0; i < TP; ++i) {
+          float mx = acc[i][j][0];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) cnt += acc[i][j][r] > thr ? 1 : 0;
-        if (cnt > 0) {
-          int slot = atomicAdd(&p.ccnt[m], cnt);
-          unsigned long long* const row = cand + (size_t)m * p.cap;
+          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
+          if (!__any(mx > thr)) continue;
+          if (mx > thr) {
+            int cnt = 0;
 #pragma unroll
-          for (int i = 0; i < TP; ++i)
+            for (int r = 0; r < 16; ++r) cnt += acc[i][j][r] > thr ? 1 : 0;
+#ifdef PFR_FILT_IMMEDIATE
+            int slot = atomicAdd(&p.ccnt[m], cnt);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               if (acc[i][j][r] > thr) {
                 const int col = n0 + wp * (BP / WP) + i * 32 + acc_row(r, lane);
-                if (slot < p.cap) row[slot] = ((unsigned long long)fkey(acc[i][j][r]) << 32) | (uint32_t)(~(uint32_t)(p.col0 + col));
+                if (slot < p.cap) cand[(size_t)m * p.cap + slot] = ((unsigned long long)fkey(acc[i][j][r]) << 32) | (uint32_t)(~(uint32_t)(p.col0 + col));
                 ++slot;
               }
+#else
+            int pos = atomicAdd(&fq_cnt[fb], cnt);   // LDS: this lane's places in the tile's winner queue
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (acc[i][j][r] > thr) {
+                const int col = n0 + wp * (BP / WP) + i * 32 + acc_row(r, lane);
+                const unsigned long long e = ((unsigned long long)fkey(acc[i][j][r]) << 32) | (uint32_t)(~(uint32_t)(p.col0 + col));
+                if (pos < FQCAP) {
+                  fq_key[fb * FQCAP + pos] = e;
+                  fq_row[fb * FQCAP + pos] = m;
+                } else {                             // queue full (a candidate-rich early segment): appended at once
+                  const int slot = atomicAdd(&p.ccnt[m], 1);
+                  if (slot < p.cap) cand[(size_t)m * p.cap + slot] = e;
+                }
+                ++pos;
+              }
+#endif
+          }
         }
       }
       continue;
