@@ -292,6 +292,66 @@ __global__ __launch_bounds__(256) void rowmerge_kernel(const unsigned long long*
   }
 }
 
+// the same for the common late-chunk case — candidates + running list <= 256 entries: ONE WAVE per query, the 256 keys in four registers per lane
+// (element e = r * 64 + lane), bitonic network through lane shuffles (partner distances < 64) and register pairs (64, 128): no LDS, no
+// workgroup barriers (the block kernel above spends its time in 36 barrier-separated stages per query).  Rows it merges leave ccnt = 0, so the
+// block kernel launched behind it returns at once for them and handles only the long lists (early segments).
+__global__ __launch_bounds__(256) void rowmerge_wave_kernel(const unsigned long long* __restrict__ cand, int cap, int K, int rows,
+                                                            unsigned long long* __restrict__ cur, int* __restrict__ cur_n,
+                                                            uint32_t* __restrict__ thrk, int* __restrict__ ccnt) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c = ccnt[row], have = cur_n[row];
+  if (c == 0 || c > cap || c + have > 256) return;
+  unsigned long long* cl = cur + (size_t)row * K;
+  unsigned long long v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = r * 64 + lane;
+    v[r] = e < c ? cand[(size_t)row * cap + e] : (e < c + have ? cl[e - c] : 0ull);
+  }
+#pragma unroll
+  for (int k = 2; k <= 256; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int rj = j >> 6;   // partner register
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((r & rj) == 0) {
+            const int e = r * 64 + lane;
+            const unsigned long long a = v[r], b = v[r | rj];
+            const bool desc = (e & k) == 0;
+            const unsigned long long hi = a > b ? a : b, lo = a > b ? b : a;
+            v[r] = desc ? hi : lo;
+            v[r | rj] = desc ? lo : hi;
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = r * 64 + lane;
+          const unsigned long long a = v[r];
+          const unsigned long long b = ((unsigned long long)__shfl_xor((unsigned)(a >> 32), j) << 32) | (unsigned)__shfl_xor((unsigned)a, j);
+          const bool keepmax = ((e & k) == 0) == ((e & j) == 0);
+          v[r] = keepmax ? (a > b ? a : b) : (a > b ? b : a);
+        }
+      }
+    }
+  const int total = c + have, keep = min(K, total);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = r * 64 + lane;
+    if (e < keep) cl[e] = v[r];
+    if (keep == K && e == K - 1) thrk[row] = (uint32_t)(v[r] >> 32);
+  }
+  if (lane == 0) {
+    cur_n[row] = keep;
+    if (keep < K) thrk[row] = 0u;
+    ccnt[row] = 0;
+  }
+}
+
 __global__ void topk_unpack_kernel(const unsigned long long* __restrict__ cur, const int* __restrict__ cur_n, int rows, int K,
                                    float* __restrict__ out_scores, int* __restrict__ out_idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,6 +395,9 @@ extern "C" int pfr_topk_update(const float* scores, int rows, int ld, int n, int
 extern "C" int pfr_topk_merge(const void* cand, int cap, int rows, int K, void* state, hipStream_t st) {
   PFR_CHECK_ARG(cand && state && rows > 0 && K >= 1 && K <= 512 && cap >= 1 && cap + K <= SEL_LIST, "pfr_topk_merge: bad args");
   const TopkState t = topk_state(state, rows, K);
+  if (K <= 256)
+    hipLaunchKernelGGL(rowmerge_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const unsigned long long*)cand, cap, K, rows, t.cur, t.cur_n,
+                       t.thrk, t.ccnt);
   hipLaunchKernelGGL(rowmerge_kernel, dim3(rows), dim3(256), 0, st, (const unsigned long long*)cand, cap, K, t.cur, t.cur_n, t.thrk,
                      t.ccnt, t.flags);
   PFR_CHECK_LAUNCH();
