@@ -90,7 +90,8 @@ def cosine_topk(q, g, k, compute_dtype=torch.bfloat16, chunk=131072, exclude_sel
     gap = (k-th best fp32 score) − (last selection score).  The re-scoring measures the selection error on every candidate (Q x kc samples of
     the same data); a query whose gap is below twice the largest error seen is matched again with a four times wider slack, and in fp32
     (exactly the reference's arithmetic) if it fails again.  With the check the default slack is max(28, k / 4) instead of max(28, 1.5 k):
-    13.5 instead of 15.0 ms at 10 k x 1 M x 512 on one box, same results (`last_match_stats` records what the check did)."""
+    1.5 ms less at 10 k x 1 M x 512 (13.5 instead of 15.0 ms on the box that measured it), same results; `last_match_stats` records what the
+    check did."""
     prepared = g if isinstance(g, PreparedGallery) else None
     if not q.is_cuda:
         if prepared is not None:
